@@ -1,0 +1,184 @@
+"""ctypes binding of the C ABI in include/capf.h.  PyTorch is used for device memory and streams
+only (tensor.data_ptr(), torch.cuda.current_stream()); no torch type crosses the ABI."""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
+HRNET, CPN50 = 0, 1
+F32, BF16 = 0, 1
+
+EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
+    "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
+    "capf_set_param", "capf_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
+    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_tensor", "capf_forward_stats",
+]
+
+
+class CapfError(RuntimeError):
+    pass
+
+
+class CapfConfig(ctypes.Structure):
+    _fields_ = [
+        ("backbone", c_int32), ("hr_channels", c_int32 * 4), ("hr_modules", c_int32 * 3), ("hr_blocks", c_int32),
+        ("base_dim", c_int32), ("embed_dim_ratio", c_int32), ("levels", c_int32), ("num_joints", c_int32),
+        ("num_heads", c_int32), ("deform_heads", c_int32), ("deform_samples", c_int32), ("context_blocks", c_int32),
+        ("compute_dtype", c_int32), ("max_batch", c_int32), ("height", c_int32), ("width", c_int32),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libcapf.so; fail loudly (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CapfError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                        "(or make -C contextaware-poseformer_amd/csrc); there is no fallback path")
+    lib = ctypes.CDLL(LIB_PATH)
+    H = c_void_p
+    lib.capf_create.argtypes = [POINTER(CapfConfig), c_int, POINTER(H)]
+    lib.capf_create.restype = c_int
+    lib.capf_destroy.argtypes = [H]
+    lib.capf_destroy.restype = None
+    lib.capf_last_error.argtypes = [H]
+    lib.capf_last_error.restype = c_char_p
+    lib.capf_version.restype = c_char_p
+    lib.capf_num_params.argtypes = [H]
+    lib.capf_param_info.argtypes = [H, c_int, POINTER(c_char_p), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
+    lib.capf_set_param.argtypes = [H, c_char_p, c_void_p, POINTER(c_int64), c_int]
+    lib.capf_params_changed.argtypes = [H, c_void_p]
+    lib.capf_workspace_bytes.argtypes = [H, c_int]
+    lib.capf_workspace_bytes.restype = c_size_t
+    lib.capf_set_workspace.argtypes = [H, c_void_p, c_size_t]
+    lib.capf_forward.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+    lib.capf_backbone_forward.argtypes = [H, c_void_p, c_void_p, c_int]
+    lib.capf_lifter_forward.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+    lib.capf_set_debug.argtypes = [H, c_int]
+    lib.capf_tensor.argtypes = [H, c_char_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int)]
+    lib.capf_forward_stats.argtypes = [H, c_int, POINTER(c_int64), POINTER(c_double)]
+    _lib = lib
+    return lib
+
+
+PARAM_KINDS = {0: "conv_w", 1: "bn_w", 2: "bn_b", 3: "bn_mean", 4: "bn_var", 5: "bn_nbt", 6: "lin_w", 7: "lin_b",
+               8: "ln_w", 9: "ln_b", 10: "raw"}
+
+
+class Engine:
+    """One native handle.  device=None -> plan-only (schema / workspace queries, no GPU)."""
+
+    def __init__(self, cfg: CapfConfig, device=None):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.h = c_void_p()
+        rc = self.lib.capf_create(byref(cfg), -1 if device is None else int(device), byref(self.h))
+        if rc != 0:
+            raise CapfError(f"capf_create failed ({rc}): {self.lib.capf_last_error(None).decode()}")
+        self.device = device
+        self._ws = None
+        self._ws_batch = 0
+        self._bound = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.capf_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise CapfError(f"{what} failed ({rc}): {self.lib.capf_last_error(self.h).decode()}")
+        return rc
+
+    # ---- schema
+    def schema(self):
+        """[(name, shape tuple, kind str)] == the reference's state_dict (incl. BN buffers)."""
+        out = []
+        name, shape, nd, kind = c_char_p(), (c_int64 * 4)(), c_int(), c_int()
+        for i in range(self.lib.capf_num_params(self.h)):
+            self._check(self.lib.capf_param_info(self.h, i, byref(name), shape, byref(nd), byref(kind)), "param_info")
+            out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value)), PARAM_KINDS[kind.value]))
+        return out
+
+    # ---- parameters
+    def bind_state(self, named_tensors, stream=0):
+        """Borrow device pointers for every schema entry from {name: cuda fp32 tensor}; fold/pack."""
+        import torch
+        for name, shape, kind in self.schema():
+            if kind == "bn_nbt":
+                continue
+            t = named_tensors[name]
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise CapfError(f"{name}: need a contiguous fp32 CUDA tensor, got {t.dtype} {t.device}")
+            if self._bound.get(name) == t.data_ptr():
+                continue
+            shp = (c_int64 * 4)(*(list(t.shape) + [0] * (4 - t.dim())))
+            self._check(self.lib.capf_set_param(self.h, name.encode(), c_void_p(t.data_ptr()), shp, t.dim()),
+                        f"set_param({name})")
+            self._bound[name] = t.data_ptr()
+        self.params_changed(stream)
+
+    def params_changed(self, stream=0):
+        self._check(self.lib.capf_params_changed(self.h, c_void_p(stream)), "params_changed")
+
+    # ---- workspace
+    def workspace_bytes(self, batch):
+        return self.lib.capf_workspace_bytes(self.h, batch)
+
+    def ensure_workspace(self, batch):
+        import torch
+        if self._ws is None or batch > self._ws_batch:
+            nbytes = self.workspace_bytes(batch)
+            self._ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._ws_batch = batch
+            self._check(self.lib.capf_set_workspace(self.h, c_void_p(self._ws.data_ptr()), nbytes), "set_workspace")
+
+    # ---- hot path
+    def forward(self, images, k2d, kcrop, out, stream):
+        B = images.shape[0]
+        self.ensure_workspace(B)
+        self._check(self.lib.capf_forward(self.h, c_void_p(stream), c_void_p(images.data_ptr()),
+                                          c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
+                                          c_void_p(out.data_ptr())), "forward")
+
+    def backbone_forward(self, images, stream):
+        B = images.shape[0]
+        self.ensure_workspace(B)
+        self._check(self.lib.capf_backbone_forward(self.h, c_void_p(stream), c_void_p(images.data_ptr()), B),
+                    "backbone_forward")
+
+    def lifter_forward(self, k2d, kcrop, out, stream):
+        B = k2d.shape[0]
+        self.ensure_workspace(B)
+        self._check(self.lib.capf_lifter_forward(self.h, c_void_p(stream), c_void_p(k2d.data_ptr()),
+                                                 c_void_p(kcrop.data_ptr()), B, c_void_p(out.data_ptr())),
+                    "lifter_forward")
+
+    def set_debug(self, on):
+        self._check(self.lib.capf_set_debug(self.h, int(on)), "set_debug")
+
+    def tensor(self, name):
+        """Copy of a named intermediate of the last forward (torch tensor on the device)."""
+        import torch
+        ptr, shape, nd = c_void_p(), (c_int64 * 4)(), c_int()
+        rc = self._check(self.lib.capf_tensor(self.h, name.encode(), byref(ptr), shape, byref(nd)), f"tensor({name})")
+        shp = [shape[i] for i in range(nd.value)]
+        n = 1
+        for s in shp:
+            n *= s
+        off = (ptr.value - self._ws.data_ptr()) // 4
+        flat = self._ws[off:off + n]
+        if rc == 1:
+            flat = flat.view(torch.int32)
+        return flat.view(*shp).clone()
+
+    def stats(self, batch):
+        n, f = c_int64(), c_double()
+        self._check(self.lib.capf_forward_stats(self.h, batch, byref(n), byref(f)), "forward_stats")
+        return n.value, f.value

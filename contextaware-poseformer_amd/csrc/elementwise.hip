@@ -1,0 +1,173 @@
+// Memory-bound helpers of the backbone (gfx950): weight fold/pack, HRNet fuse-sum with nearest
+// upsampling, CPN max-pool and bilinear (align_corners=True) resize.  All tensors NHWC fp32; every
+// kernel moves 16 bytes per lane with consecutive lanes on consecutive addresses.
+#include "kernels.h"
+
+namespace capf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- BN fold + re-layout of a conv weight (eval-mode BatchNorm, pose_hrnet.py:72-75 etc.) ---------
+//   y = (conv(x) - mean) / sqrt(var + eps) * gamma + beta  ==  conv_{w*s}(x) + (beta - mean*s)
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                 const float* __restrict__ var, float eps, float* __restrict__ Wp,
+                                 float* __restrict__ bias, int Cout, int Cin, int ks, int Kpad) {
+    const long total = (long)Cout * Kpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kpad), k = (int)(i - (long)n * Kpad);
+        const int K = ks * ks * Cin;
+        float v = 0.f;
+        const float sc = gamma ? gamma[n] / sqrtf(var[n] + eps) : 1.f;
+        if (k < K) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int kh = tap / ks, kw = tap - kh * ks;
+            v = w[(((long)n * Cin + ci) * ks + kh) * ks + kw] * sc;
+        }
+        Wp[i] = v;
+        if (k == 0 && bias) bias[n] = gamma ? beta[n] - mean[n] * sc : 0.f;
+    }
+}
+
+hipError_t launch_pack_conv(const float* w, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, float* Wp, float* bias, int Cout, int Cin,
+                            int ks, int Kpad, hipStream_t s) {
+    const long total = (long)Cout * Kpad;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, Wp,
+                       bias, Cout, Cin, ks, Kpad);
+    return hipGetLastError();
+}
+
+__global__ void pack_linear_kernel(const float* __restrict__ w, float* __restrict__ Wp, int N, int K, int Kpad) {
+    const long total = (long)N * Kpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kpad), k = (int)(i - (long)n * Kpad);
+        Wp[i] = k < K ? w[(long)n * K + k] : 0.f;
+    }
+}
+
+hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s) {
+    const long total = (long)N * Kpad;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, s, w, Wp, N, K, Kpad);
+    return hipGetLastError();
+}
+
+// ---- HRNet fuse: out = relu(sum_i nearest_up(in_i))  (pose_hrnet.py:294-301, nn.Upsample nearest) --
+// Input i has resolution (H >> shift_i, W >> shift_i); nearest upsampling by 2^s reads (h>>s, w>>s).
+__global__ void fuse_sum_kernel(FuseSumArgs a) {
+    const int C4 = a.C >> 2;
+    const long total = (long)a.B * a.H * a.W * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long pix = i / C4;
+        const int w = (int)(pix % a.W);
+        pix /= a.W;
+        const int h = (int)(pix % a.H);
+        const int b = (int)(pix / a.H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < a.n_in) {
+                const int s = a.shift[k];
+                const int hs = a.H >> s, ws = a.W >> s;
+                const long off = ((((long)b * hs + (h >> s)) * ws + (w >> s)) * C4 + c4);
+                const f32x4 v = reinterpret_cast<const f32x4*>(a.in[k])[off];
+                acc = k == 0 ? v : acc + v;          // same order as the reference: ((x0 + x1) + x2) + x3
+            }
+        }
+        if (a.relu) {
+            acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f);
+            acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
+        }
+        reinterpret_cast<f32x4*>(a.out)[i] = acc;
+    }
+}
+
+hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s) {
+    const long total = (long)a.B * a.H * a.W * (a.C >> 2);
+    const long want = (total + 255) / 256;
+    const int blocks = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(fuse_sum_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- 3x3 stride-2 pad-1 max pool (networks/resnet.py:104, :140) ----------------------------------
+__global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                               int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long pix = i / C4;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * 2 - 1 + kw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = reinterpret_cast<const f32x4*>(in)[(((long)b * H + hi) * W + wi) * C4 + c4];
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]);
+                m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = m;
+    }
+}
+
+hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
+                               hipStream_t s) {
+    const long total = (long)B * Ho * Wo * (C >> 2);
+    const long want = (total + 255) / 256;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
+                       W, C, Ho, Wo);
+    return hipGetLastError();
+}
+
+// ---- bilinear resize, align_corners=True (globalNet.py:40, refineNet.py:61) ----------------------
+// ATen upsample_bilinear2d: src = dst * (in-1)/(out-1) (0 if out == 1); i0 = (int)src, i1 = i0 + (i0 < in-1);
+// l1 = src - i0, l0 = 1 - l1;  out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).
+__global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                int C, int Ho, int Wo, float sh, float sw) {
+    const int C4 = C >> 2;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long pix = i / C4;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        const float fh = sh * ho, fw = sw * wo;
+        const int h0 = (int)fh, w0 = (int)fw;
+        const int h1 = h0 + (h0 < H - 1), w1 = w0 + (w0 < W - 1);
+        const float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(in) + (long)b * H * W * C4 + c4;
+        const f32x4 v00 = src[((long)h0 * W + w0) * C4], v01 = src[((long)h0 * W + w1) * C4];
+        const f32x4 v10 = src[((long)h1 * W + w0) * C4], v11 = src[((long)h1 * W + w1) * C4];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            r[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
+        reinterpret_cast<f32x4*>(out)[i] = r;
+    }
+}
+
+hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
+                                  hipStream_t s) {
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)B * Ho * Wo * (C >> 2);
+    const long want = (total + 255) / 256;
+    hipLaunchKernelGGL(bilinear_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
+                       W, C, Ho, Wo, sh, sw);
+    return hipGetLastError();
+}
+
+}  // namespace capf

@@ -1,0 +1,335 @@
+// Executor + C ABI (include/capf.h).  Walks the static plan and enqueues the gfx950 kernels on the
+// caller's stream; no allocation, no synchronisation, no host round trip inside capf_forward.
+#include <stdio.h>
+#include <string.h>
+
+#include "engine.h"
+
+namespace capf {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return CAPF_ERR_HIP;                                                           \
+        }                                                                                  \
+    } while (0)
+
+// Rebuild the private packed copies from the borrowed parameters.
+int Engine::repack(hipStream_t s) {
+    for (const Param& p : params) {
+        if (p.kind == CAPF_P_BN_NBT) continue;
+        if (!p.ptr) {
+            err = "parameter not set: " + p.name;
+            return CAPF_ERR_STATE;
+        }
+    }
+    for (const Pack& pk : packs) {
+        if (pk.direct) continue;
+        float* W = pack_arena + pk.w_off;
+        float* B = pack_arena + pk.b_off;
+        if (pk.kind == 0) {
+            HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
+                                     params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks,
+                                     pk.Kpad, s));
+        } else {
+            int n0 = 0;
+            for (int i = 0; i < pk.n_lin; ++i) {
+                const int n = (int)params[pk.w[i]].shape[0];
+                HIP_TRY(launch_pack_linear(params[pk.w[i]].ptr, W + (size_t)n0 * pk.Kpad, n, pk.K, pk.Kpad, s));
+                HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+                n0 += n;
+            }
+        }
+    }
+    packed = true;
+    return CAPF_OK;
+}
+
+int Engine::run(hipStream_t s, int batch, int first_op, int last_op) {
+    auto ptr = [&](int buf) -> float* {
+        if (buf >= 0) return bptr(buf, batch);
+        return nullptr;
+    };
+    for (int oi = first_op; oi < last_op; ++oi) {
+        const Op& op = ops[oi];
+        switch (op.kind) {
+            case OP_GEMM: {
+                const Pack& pk = packs[op.pack];
+                GemmArgs a{};
+                a.A = op.in[0] == -2 ? images : ptr(op.in[0]);
+                if (pk.direct) {
+                    a.Wp = params[pk.w[0]].ptr;
+                    a.bias = params[pk.b[0]].ptr;
+                } else {
+                    a.Wp = pack_arena + pk.w_off;
+                    a.bias = pack_arena + pk.b_off;
+                }
+                a.res = op.res_param >= 0 ? params[op.res_param].ptr : ptr(op.aux);
+                a.out = ptr(op.out);
+                a.M = (int)(op.rows_per_frame * batch);
+                a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
+                a.conv = op.conv;
+                a.Cin = op.Cin; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo;
+                a.ks = op.ks; a.stride = op.stride; a.pad = op.pad;
+                a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
+                a.act = op.act;
+                HIP_TRY(launch_gemm_f32(a, s));
+                break;
+            }
+            case OP_FUSE: {
+                if (op.i0 == 1 && !debug) break;
+                FuseSumArgs a{};
+                a.n_in = op.n_in;
+                for (int i = 0; i < op.n_in; ++i) {
+                    a.in[i] = ptr(op.in[i]);
+                    a.shift[i] = op.shift[i];
+                }
+                a.out = ptr(op.out);
+                a.B = batch; a.H = op.H; a.W = op.W; a.C = op.C; a.relu = op.relu;
+                HIP_TRY(launch_fuse_sum(a, s));
+                break;
+            }
+            case OP_MAXPOOL:
+                HIP_TRY(launch_maxpool3x3s2(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s));
+                break;
+            case OP_RESIZE:
+                HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s));
+                break;
+            case OP_PREP_EMBED:
+                HIP_TRY(launch_prep_embed(kcrop, k2d, params[op.p0].ptr, params[op.p1].ptr, params[op.p2].ptr,
+                                          ptr(op.out), batch, op.i0, op.i1, op.C, s));
+                break;
+            case OP_SAMPLE_REF:
+                HIP_TRY(launch_sample_ref(ptr(op.in[0]), kcrop, ptr(op.out), reinterpret_cast<int*>(ptr(op.aux2)),
+                                          batch, op.i0, op.H, op.W, op.C, s));
+                break;
+            case OP_LAYERNORM:
+                HIP_TRY(launch_layernorm(ptr(op.in[0]), op.amap, ptr(op.aux), op.rmap, params[op.p0].ptr,
+                                         params[op.p1].ptr, op.eps, ptr(op.out), (int)(op.rows_per_frame * batch),
+                                         op.C, s));
+                break;
+            case OP_DEFORM: {
+                DeformArgs a{};
+                for (int l = 0; l < op.i1; ++l) {
+                    a.feat[l] = ptr(op.in[l]);
+                    a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.C[l] = op.lvlC[l];
+                    a.U[l] = ptr(op.outs[l]);
+                }
+                a.AO = ptr(op.aux);
+                a.ref = kcrop;
+                a.B = batch; a.J = op.i0; a.L = op.i1; a.NH = op.i2; a.NS = op.i3;
+                HIP_TRY(launch_deform_sample(a, s));
+                break;
+            }
+            case OP_ATTENTION:
+                HIP_TRY(launch_attention(ptr(op.in[0]), ptr(op.out), op.i0 * batch, op.i1, op.i2, op.i3, s));
+                break;
+            case OP_HEAD:
+                HIP_TRY(launch_head(ptr(op.in[0]), params[op.p0].ptr, params[op.p1].ptr, op.eps, params[op.p2].ptr,
+                                    params[op.p3].ptr, out, (int)(op.rows_per_frame * batch), op.C, op.i0, s));
+                break;
+        }
+    }
+    return CAPF_OK;
+}
+
+}  // namespace capf
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+using capf::Engine;
+
+static std::string g_create_error;
+
+extern "C" {
+
+const char* capf_version(void) { return "capf 0.1 (gfx950)"; }
+
+const char* capf_last_error(const capf_handle* h) { return h ? h->e.err.c_str() : g_create_error.c_str(); }
+
+int capf_create(const capf_config* cfg, int device, capf_handle** out) {
+    if (!cfg || !out) {
+        g_create_error = "null argument";
+        return CAPF_ERR_INVALID;
+    }
+    capf_handle* h = new capf_handle();
+    Engine& e = h->e;
+    e.cfg = *cfg;
+    e.device = device;
+    if (cfg->compute_dtype != CAPF_F32) {
+        g_create_error = "compute_dtype: only CAPF_F32 is implemented in this build";
+        delete h;
+        return CAPF_ERR_UNSUPPORTED;
+    }
+    if (cfg->max_batch <= 0) {
+        g_create_error = "max_batch must be positive";
+        delete h;
+        return CAPF_ERR_INVALID;
+    }
+    if (!e.build()) {
+        g_create_error = e.err;
+        delete h;
+        return CAPF_ERR_UNSUPPORTED;
+    }
+    if (device >= 0) {
+        hipError_t r = hipSetDevice(device);
+        if (r == hipSuccess && e.pack_elems) r = hipMalloc(reinterpret_cast<void**>(&e.pack_arena), e.pack_elems * sizeof(float));
+        if (r != hipSuccess) {
+            g_create_error = std::string("hip: ") + hipGetErrorString(r);
+            delete h;
+            return CAPF_ERR_HIP;
+        }
+    }
+    *out = h;
+    return CAPF_OK;
+}
+
+void capf_destroy(capf_handle* h) {
+    if (!h) return;
+    if (h->e.pack_arena) (void)hipFree(h->e.pack_arena);
+    delete h;
+}
+
+int capf_num_params(const capf_handle* h) { return h ? (int)h->e.params.size() : CAPF_ERR_INVALID; }
+
+int capf_param_info(const capf_handle* h, int index, const char** name, int64_t shape[4], int* ndim, int* kind) {
+    if (!h || index < 0 || index >= (int)h->e.params.size()) return CAPF_ERR_INVALID;
+    const capf::Param& p = h->e.params[index];
+    if (name) *name = p.name.c_str();
+    if (shape) memcpy(shape, p.shape, sizeof(p.shape));
+    if (ndim) *ndim = p.ndim;
+    if (kind) *kind = p.kind;
+    return CAPF_OK;
+}
+
+int capf_set_param(capf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int ndim) {
+    if (!h || !name) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    auto it = e.param_index.find(name);
+    if (it == e.param_index.end()) {
+        e.err = std::string("unknown parameter: ") + name;
+        return CAPF_ERR_INVALID;
+    }
+    capf::Param& p = e.params[it->second];
+    bool ok = (ndim == p.ndim);
+    for (int i = 0; ok && i < ndim; ++i) ok = (shape[i] == p.shape[i]);
+    if (!ok) {
+        e.err = std::string("shape mismatch for ") + name;
+        return CAPF_ERR_INVALID;
+    }
+    p.ptr = static_cast<const float*>(dev_ptr);
+    e.packed = false;
+    return CAPF_OK;
+}
+
+int capf_params_changed(capf_handle* h, void* stream) {
+    if (!h) return CAPF_ERR_INVALID;
+    if (h->e.device < 0) {
+        h->e.err = "plan-only handle (device < 0)";
+        return CAPF_ERR_STATE;
+    }
+    return h->e.repack(static_cast<hipStream_t>(stream));
+}
+
+size_t capf_workspace_bytes(const capf_handle* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    return h->e.ws_elems_per_frame * (size_t)batch * sizeof(float);
+}
+
+int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes) {
+    if (!h) return CAPF_ERR_INVALID;
+    h->e.ws = static_cast<float*>(dev_ptr);
+    h->e.ws_bytes = bytes;
+    return CAPF_OK;
+}
+
+int capf_set_debug(capf_handle* h, int on) {
+    if (!h) return CAPF_ERR_INVALID;
+    h->e.debug = on != 0;
+    return CAPF_OK;
+}
+
+static int check_run(Engine& e, int batch) {
+    if (e.device < 0) {
+        e.err = "plan-only handle (device < 0)";
+        return CAPF_ERR_STATE;
+    }
+    if (batch <= 0 || batch > e.cfg.max_batch) {
+        e.err = "batch out of range (1..max_batch)";
+        return CAPF_ERR_INVALID;
+    }
+    if (!e.packed) {
+        e.err = "capf_params_changed has not been called since the last capf_set_param";
+        return CAPF_ERR_STATE;
+    }
+    if (!e.ws || e.ws_bytes < e.ws_elems_per_frame * (size_t)batch * sizeof(float)) {
+        e.err = "workspace missing or too small";
+        return CAPF_ERR_STATE;
+    }
+    return CAPF_OK;
+}
+
+int capf_forward(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
+                 int batch, float* out) {
+    if (!h || !images_nhwc || !k2d || !kcrop_inout || !out) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
+    e.last_batch = batch;
+    return e.run(static_cast<hipStream_t>(stream), batch, 0, (int)e.ops.size());
+}
+
+int capf_backbone_forward(capf_handle* h, void* stream, const float* images_nhwc, int batch) {
+    if (!h || !images_nhwc) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.images = images_nhwc;
+    e.last_batch = batch;
+    return e.run(static_cast<hipStream_t>(stream), batch, 0, e.n_backbone_ops);
+}
+
+int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* kcrop_inout, int batch, float* out) {
+    if (!h || !k2d || !kcrop_inout || !out) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
+    e.last_batch = batch;
+    return e.run(static_cast<hipStream_t>(stream), batch, e.n_backbone_ops, (int)e.ops.size());
+}
+
+int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, int64_t shape[4], int* ndim) {
+    if (!h || !name) return CAPF_ERR_INVALID;
+    const Engine& e = h->e;
+    auto it = e.named.find(name);
+    if (it == e.named.end()) return CAPF_ERR_INVALID;
+    const capf::NamedTensor& t = it->second;
+    if (shape) {
+        for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+        shape[0] = e.last_batch;
+    }
+    if (ndim) *ndim = t.ndim;
+    if (dev_ptr) *dev_ptr = (e.ws && e.last_batch > 0) ? e.bptr(t.buf, e.last_batch) : nullptr;
+    return t.is_int ? 1 : 0;
+}
+
+int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops) {
+    if (!h) return CAPF_ERR_INVALID;
+    int64_t n = 0;
+    double f = 0.0;
+    for (const capf::Op& op : h->e.ops) {
+        if (op.kind == capf::OP_FUSE && op.i0 == 1) continue;
+        ++n;
+        f += op.flops_per_frame * batch;
+    }
+    if (launches) *launches = n;
+    if (flops) *flops = f;
+    return CAPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// Internal model of the hot path: parameter schema, static layer plan, workspace layout.
+// (Public ABI: include/capf.h.)  Host-side C++; no torch types anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "capf.h"
+#include "kernels.h"
+
+namespace capf {
+
+struct Param {
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int ndim = 0;
+    int kind = 0;
+    const float* ptr = nullptr;  // borrowed device pointer (capf_set_param)
+    int64_t numel() const {
+        int64_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= shape[i];
+        return n;
+    }
+};
+
+// Activation buffer inside the caller-owned workspace.  Sizes / offsets are per frame (elements);
+// the run-time address is ws + offset * batch, so one plan serves every batch <= max_batch.
+struct Buffer {
+    size_t elems = 0;       // per frame, rounded up to 64 elements (256 B)
+    size_t offset = 0;      // per frame, assigned by assign_offsets()
+    int def_op = -1;        // first op that writes it
+    int last_op = -1;       // last op that reads it (INT_MAX: persists to the end of forward)
+    std::string tag;        // debug name ("feat0", "tok", ...)
+};
+
+struct Tensor {  // NHWC view of a buffer (per frame), or [rows, C] for the lifter (H = rows, W = 1)
+    int buf = -1;
+    int H = 0, W = 0, C = 0;
+};
+
+// A private packed copy derived from borrowed parameters (rebuilt by capf_params_changed).
+struct Pack {
+    int kind = 0;            // 0 conv+BN fold, 1 linear (possibly several linears concatenated along N)
+    int w[4] = {-1, -1, -1, -1}, b[4] = {-1, -1, -1, -1};   // param indices (linear: up to 4 concatenated)
+    int n_lin = 0;
+    int bn_g = -1, bn_b = -1, bn_m = -1, bn_v = -1;
+    int N = 0, K = 0, Kpad = 0, Cin = 0, ks = 1;
+    size_t w_off = 0, b_off = 0;   // element offsets inside the pack arena
+    bool direct = false;           // linear with Kpad == K and no concat: use the parameter in place
+};
+
+enum OpKind {
+    OP_GEMM = 0, OP_FUSE, OP_MAXPOOL, OP_RESIZE, OP_PREP_EMBED, OP_SAMPLE_REF, OP_LAYERNORM, OP_DEFORM,
+    OP_ATTENTION, OP_HEAD
+};
+
+struct Op {
+    OpKind kind = OP_GEMM;
+    std::string name;
+    // buffers (ids; -1 unused; -2 = external "images" input)
+    int in[4] = {-1, -1, -1, -1};
+    int aux = -1;                 // residual / add input
+    int out = -1;
+    int aux2 = -1;                // secondary output (idx buffer)
+    // gemm
+    int pack = -1;
+    int conv = 0, Cin = 0, H = 0, W = 0, Ho = 0, Wo = 0, ks = 1, stride = 1, pad = 0;
+    long rows_per_frame = 0;      // M = rows_per_frame * batch
+    int N = 0, K = 0, act = 0;
+    RowMap amap{1, 0, 0, 0}, omap{1, 0, 0, 0}, rmap{1, 0, 0, 0};
+    int res_param = -1;           // residual read from a parameter (pos-embed) instead of a buffer
+    // fuse / resize / pool
+    int n_in = 0, shift[4] = {0, 0, 0, 0}, relu = 0, C = 0;
+    // lifter misc
+    int p0 = -1, p1 = -1, p2 = -1, p3 = -1;  // parameter indices (meaning depends on kind)
+    float eps = 0.f;
+    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;      // small ints (meaning depends on kind)
+    int lvlH[4] = {0, 0, 0, 0}, lvlW[4] = {0, 0, 0, 0}, lvlC[4] = {0, 0, 0, 0};
+    int outs[4] = {-1, -1, -1, -1};
+    double flops_per_frame = 0.0;
+};
+
+struct NamedTensor {
+    int buf;
+    int64_t shape[4];   // shape[0] = -1 means "batch"
+    int ndim;
+    int is_int;
+};
+
+struct Engine {
+    capf_config cfg{};
+    int device = -1;
+    std::string err;
+
+    std::vector<Param> params;
+    std::map<std::string, int> param_index;
+    std::vector<Buffer> bufs;
+    std::vector<Pack> packs;
+    std::vector<Op> ops;
+    int n_backbone_ops = 0;
+    std::map<std::string, NamedTensor> named;
+    size_t ws_elems_per_frame = 0;
+    size_t pack_elems = 0;
+
+    float* pack_arena = nullptr;   // device, owned
+    float* ws = nullptr;           // device, borrowed
+    size_t ws_bytes = 0;
+    bool packed = false;
+    bool debug = false;            // run the debug-copy ops (capf_set_debug)
+    int last_batch = 0;
+    const float* images = nullptr;
+    const float* k2d = nullptr;
+    float* kcrop = nullptr;
+    float* out = nullptr;
+
+    // ---- schema / plan construction (plan.cpp)
+    int add_param(const std::string& name, int kind, std::initializer_list<int64_t> shape);
+    int new_buffer(size_t elems, const std::string& tag);
+    Tensor conv_bn(const std::string& conv, const std::string& bn, const Tensor& x, int Cout, int ks, int stride,
+                   int act, const Tensor* residual);
+    void build_hrnet(Tensor img, Tensor feats[4]);
+    void build_cpn(Tensor img, Tensor feats[4]);
+    void build_lifter(const Tensor feats[4]);
+    bool build();
+    void assign_offsets();
+    void use(int buf);   // mark buffer as read by the op being appended
+
+    // ---- execution (engine.cpp)
+    float* bptr(int buf, int batch) const { return ws + bufs[buf].offset * (size_t)batch; }
+    int repack(hipStream_t s);
+    int run(hipStream_t s, int batch, int first_op, int last_op);
+};
+
+}  // namespace capf
+
+struct capf_handle {
+    capf::Engine e;
+};

@@ -1,0 +1,88 @@
+// Launcher declarations for the gfx950 kernels (internal; the public ABI is include/capf.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace capf {
+
+// addr(m) = (m / G) * S1 + (m % G) * S2 + off   (elements).  G == 1 -> plain leading dimension S1.
+struct RowMap {
+    int G;
+    long S1, S2, off;
+};
+inline RowMap row_ld(long ld, long off = 0) { return RowMap{1, ld, 0, off}; }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+// One implicit-GEMM problem:  out[m, n] = act( sum_k A[m, k] * Wp[n, k] + bias[n] + res[m, n] )
+//   conv mode: A[m, k] gathered from an NHWC tensor, m = (b, ho, wo), k = (kh, kw, ci)
+//   rows mode: A[m, k] = A[amap(m) + k]
+struct GemmArgs {
+    const float* A;
+    const float* Wp;    // packed weights [N][Kpad], K-contiguous, zero padded to Kpad (multiple of 32)
+    const float* bias;  // [N] or nullptr
+    const float* res;   // residual, addressed by rmap, or nullptr
+    float* out;         // addressed by omap
+    int M, N, K, Kpad;
+    int conv;           // 1 = conv mode
+    int Cin, H, W, Ho, Wo, ks, stride, pad;
+    RowMap amap, omap, rmap;
+    int act;
+};
+
+hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
+
+// conv weight fold + pack:  Wp[n][(kh*ks+kw)*Cin+ci] = w[n][ci][kh][kw] * gamma[n]/sqrt(var[n]+eps)
+//                            bias[n] = beta[n] - mean[n]*gamma[n]/sqrt(var[n]+eps)
+hipError_t launch_pack_conv(const float* w, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, float* Wp, float* bias, int Cout, int Cin,
+                            int ks, int Kpad, hipStream_t s);
+// linear pack: Wp[n][k] = w[n][k] (zero padded to Kpad); rows [n0, n0+N) of the destination
+hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);
+
+// out = relu( sum_i up_{s_i}(in_i) ), NHWC, s_i = nearest-upsample factor (1 = same resolution)
+struct FuseSumArgs {
+    const float* in[4];
+    int shift[4];  // log2 of the upsample factor
+    int n_in;
+    float* out;
+    int B, H, W, C;
+    int relu;
+};
+hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s);
+
+// 3x3 s2 p1 max-pool NHWC (resnet.py:140), bilinear align_corners=True resize NHWC (+ optional add)
+hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
+                               hipStream_t s);
+hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
+                                  hipStream_t s);
+
+// ---- lifter -----------------------------------------------------------------------------------
+// kcrop -> ref in place (conpose.py:34-35);  X[b,p,0,:] = coord_embed(k2d[b,p]) + pos[0,p,:]
+hipError_t launch_prep_embed(float* kcrop, const float* k2d, const float* w, const float* bias,
+                             const float* pos, float* X, int B, int J, int L1, int C, hipStream_t s);
+// reference-point sampling, padding zeros (pose_dformer.py:216-218): S[b,p,:] = bilinear(feat, ref[b,p])
+hipError_t launch_sample_ref(const float* feat, const float* ref, float* S, int* idx, int B, int J, int H,
+                             int W, int C, hipStream_t s);
+// LayerNorm over rows: out[r,:] = LN(in[imap(r)] (+ add[amap(r)]))   width C
+hipError_t launch_layernorm(const float* in, RowMap imap, const float* add, RowMap amap, const float* g,
+                            const float* b, float eps, float* out, int rows, int C, hipStream_t s);
+// deformable sampling (pose_dformer.py:122-135 minus the embed_proj GEMM):
+//   AO [rows=(b,p,l), NH*NS + 2*NH*NS] = [attention logits | offset pre-activations]
+//   U_l[(b,p,h), :] = sum_s softmax_s(logit[h,s]) * bilinear_border(feat_l, tanh(off[h,s]) + ref[b,p])
+struct DeformArgs {
+    const float* feat[4];
+    int H[4], W[4], C[4];
+    float* U[4];
+    const float* AO;
+    const float* ref;
+    int B, J, L, NH, NS;
+};
+hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s);
+// tiny multi-head attention: QKV [G*N, 3*heads*d] -> O [G*N, heads*d]; N tokens per group
+hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int heads, int d, hipStream_t s);
+// head (pose_dformer.py:240): out[r, 0..2] = Linear(LN(X[r,:]))
+hipError_t launch_head(const float* X, const float* g, const float* b, float eps, const float* w,
+                       const float* wb, float* out, int rows, int C, int NO, hipStream_t s);
+
+}  // namespace capf

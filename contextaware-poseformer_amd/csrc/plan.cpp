@@ -1,0 +1,679 @@
+// Static layer plan + parameter schema of the hot path.
+//
+// Restates, as a flat list of kernel launches over NHWC buffers, the module graphs of
+//   PoseHighResolutionNet   ContextPose/mvn/models/pose_hrnet.py:312-501
+//   CPN50                   ContextPose/mvn/models/networks/{network,resnet,globalNet,refineNet}.py
+//   PoseTransformer         ContextPose/mvn/models/pose_dformer.py:144-241
+// and registers every state_dict entry under the reference's name, so that
+// released checkpoints load strict=True into the host module built from this schema.
+#include <limits.h>
+
+#include <algorithm>
+
+#include "engine.h"
+
+namespace capf {
+
+static const int EXT_IMAGES = -2;
+
+static size_t round64(size_t n) { return (n + 63) / 64 * 64; }
+static int round32(int n) { return (n + 31) / 32 * 32; }
+
+int Engine::add_param(const std::string& name, int kind, std::initializer_list<int64_t> shape) {
+    auto it = param_index.find(name);
+    if (it != param_index.end()) return it->second;
+    Param p;
+    p.name = name;
+    p.kind = kind;
+    p.ndim = (int)shape.size();
+    int i = 0;
+    for (int64_t s : shape) p.shape[i++] = s;
+    params.push_back(p);
+    param_index[name] = (int)params.size() - 1;
+    return (int)params.size() - 1;
+}
+
+int Engine::new_buffer(size_t elems, const std::string& tag) {
+    Buffer b;
+    b.elems = round64(elems);
+    b.def_op = (int)ops.size();
+    b.last_op = (int)ops.size();
+    b.tag = tag;
+    bufs.push_back(b);
+    return (int)bufs.size() - 1;
+}
+
+void Engine::use(int buf) {
+    if (buf >= 0) bufs[buf].last_op = std::max(bufs[buf].last_op, (int)ops.size());
+}
+
+static void keep(Engine& e, int buf) { e.bufs[buf].last_op = INT_MAX; }
+
+static void name_tensor(Engine& e, const std::string& name, int buf, std::initializer_list<int64_t> shape,
+                        int is_int = 0) {
+    NamedTensor t{};
+    t.buf = buf;
+    t.ndim = (int)shape.size();
+    int i = 0;
+    for (int64_t s : shape) t.shape[i++] = s;
+    t.is_int = is_int;
+    e.named[name] = t;
+    keep(e, buf);
+}
+
+// conv (bias=False) + eval BatchNorm (+ residual) (+ ReLU) as ONE implicit-GEMM launch.
+Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Tensor& x, int Cout, int ks,
+                       int stride, int act, const Tensor* residual) {
+    const int pad = ks / 2;
+    Tensor y;
+    y.H = (x.H + 2 * pad - ks) / stride + 1;
+    y.W = (x.W + 2 * pad - ks) / stride + 1;
+    y.C = Cout;
+
+    Pack pk;
+    pk.kind = 0;
+    pk.w[0] = add_param(conv + ".weight", CAPF_P_CONV_W, {Cout, x.C, ks, ks});
+    pk.bn_g = add_param(bn + ".weight", CAPF_P_BN_W, {Cout});
+    pk.bn_b = add_param(bn + ".bias", CAPF_P_BN_B, {Cout});
+    pk.bn_m = add_param(bn + ".running_mean", CAPF_P_BN_MEAN, {Cout});
+    pk.bn_v = add_param(bn + ".running_var", CAPF_P_BN_VAR, {Cout});
+    add_param(bn + ".num_batches_tracked", CAPF_P_BN_NBT, {});
+    pk.N = Cout;
+    pk.Cin = x.C;
+    pk.ks = ks;
+    pk.K = ks * ks * x.C;
+    pk.Kpad = round32(pk.K);
+    packs.push_back(pk);
+
+    Op op;
+    op.kind = OP_GEMM;
+    op.name = conv;
+    op.conv = 1;
+    op.pack = (int)packs.size() - 1;
+    op.in[0] = x.buf;
+    op.Cin = x.C; op.H = x.H; op.W = x.W; op.Ho = y.H; op.Wo = y.W;
+    op.ks = ks; op.stride = stride; op.pad = pad;
+    op.rows_per_frame = (long)y.H * y.W;
+    op.N = Cout; op.K = pk.K; op.act = act;
+    op.omap = row_ld(Cout);
+    op.rmap = row_ld(Cout);
+    op.flops_per_frame = 2.0 * y.H * y.W * (double)Cout * pk.K;
+    use(x.buf);
+    if (residual) {
+        op.aux = residual->buf;
+        use(residual->buf);
+    }
+    y.buf = new_buffer((size_t)y.H * y.W * Cout, conv);
+    op.out = y.buf;
+    ops.push_back(op);
+    return y;
+}
+
+static Tensor fuse_sum(Engine& e, const std::string& name, const Tensor* terms, const int* shifts, int n,
+                       const Tensor& like, int relu) {
+    Op op;
+    op.kind = OP_FUSE;
+    op.name = name;
+    op.n_in = n;
+    for (int i = 0; i < n; ++i) {
+        op.in[i] = terms[i].buf;
+        op.shift[i] = shifts[i];
+        e.use(terms[i].buf);
+    }
+    op.H = like.H; op.W = like.W; op.C = like.C; op.relu = relu;
+    Tensor y = like;
+    y.buf = e.new_buffer((size_t)like.H * like.W * like.C, name);
+    op.out = y.buf;
+    e.ops.push_back(op);
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// HRNet (pose_hrnet.py)
+// ---------------------------------------------------------------------------------------------------
+static Tensor hr_basic_block(Engine& e, const std::string& p, const Tensor& x) {   // :66-95
+    Tensor y = e.conv_bn(p + ".conv1", p + ".bn1", x, x.C, 3, 1, ACT_RELU, nullptr);
+    return e.conv_bn(p + ".conv2", p + ".bn2", y, x.C, 3, 1, ACT_RELU, &x);
+}
+
+static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, int planes, bool down) {  // :98-136
+    Tensor y = e.conv_bn(p + ".conv1", p + ".bn1", x, planes, 1, 1, ACT_RELU, nullptr);
+    y = e.conv_bn(p + ".conv2", p + ".bn2", y, planes, 3, 1, ACT_RELU, nullptr);
+    Tensor r = x;
+    if (down) r = e.conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes * 4, 1, 1, ACT_NONE, nullptr);
+    return e.conv_bn(p + ".conv3", p + ".bn3", y, planes * 4, 1, 1, ACT_RELU, &r);
+}
+
+// HighResolutionModule (:139-303).  xs: in/out; branch_out (optional) receives the branch outputs.
+static void hr_module(Engine& e, const std::string& p, std::vector<Tensor>& xs, int n_out, int blocks,
+                      std::vector<Tensor>* branch_out) {
+    const int nb = (int)xs.size();
+    std::vector<Tensor> br(nb);
+    for (int i = 0; i < nb; ++i) {
+        Tensor y = xs[i];
+        for (int k = 0; k < blocks; ++k)
+            y = hr_basic_block(e, p + ".branches." + std::to_string(i) + "." + std::to_string(k), y);
+        br[i] = y;
+    }
+    if (branch_out) *branch_out = br;
+    std::vector<Tensor> outs(n_out);
+    for (int i = 0; i < n_out; ++i) {
+        Tensor terms[4];
+        int shifts[4] = {0, 0, 0, 0};
+        for (int j = 0; j < nb; ++j) {
+            const std::string fp = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
+            if (j == i) {
+                terms[j] = br[j];
+            } else if (j > i) {   // 1x1 conv + BN at low resolution; nearest x2^(j-i) applied by the fuse kernel
+                terms[j] = e.conv_bn(fp + ".0", fp + ".1", br[j], br[i].C, 1, 1, ACT_NONE, nullptr);
+                shifts[j] = j - i;
+            } else {              // (i-j) stride-2 3x3 convs, ReLU on all but the last
+                Tensor t = br[j];
+                for (int k = 0; k < i - j; ++k) {
+                    const bool last = (k == i - j - 1);
+                    const std::string cp = fp + "." + std::to_string(k);
+                    t = e.conv_bn(cp + ".0", cp + ".1", t, last ? br[i].C : br[j].C, 3, 2,
+                                  last ? ACT_NONE : ACT_RELU, nullptr);
+                }
+                terms[j] = t;
+            }
+        }
+        outs[i] = fuse_sum(e, p + ".fuse" + std::to_string(i), terms, shifts, nb, br[i], 1);
+    }
+    xs = outs;
+}
+
+void Engine::build_hrnet(Tensor img, Tensor feats[4]) {
+    const std::string B = "backbone";
+    Tensor x = conv_bn(B + ".conv1", B + ".bn1", img, 64, 3, 2, ACT_RELU, nullptr);     // :465-467
+    x = conv_bn(B + ".conv2", B + ".bn2", x, 64, 3, 2, ACT_RELU, nullptr);              // :468-470
+    for (int k = 0; k < 4; ++k) x = hr_bottleneck(*this, B + ".layer1." + std::to_string(k), x, 64, k == 0);
+
+    std::vector<Tensor> ys = {x};
+    std::vector<int> pre_ch = {256};
+    for (int stage = 2; stage <= 4; ++stage) {
+        const int nb = stage;
+        // transition (:377-411)
+        std::vector<Tensor> xs(nb);
+        const std::string tp = B + ".transition" + std::to_string(stage - 1) + ".";
+        const int npre = (int)pre_ch.size();
+        for (int i = 0; i < nb; ++i) {
+            const int ch = cfg.hr_channels[i];
+            if (i < npre) {
+                if (ch != pre_ch[i])
+                    xs[i] = conv_bn(tp + std::to_string(i) + ".0", tp + std::to_string(i) + ".1", ys[i], ch, 3, 1,
+                                    ACT_RELU, nullptr);
+                else
+                    xs[i] = ys[i];
+            } else {
+                Tensor t = ys[npre - 1];
+                for (int j = 0; j < i + 1 - npre; ++j) {
+                    const int oc = (j == i - npre) ? ch : pre_ch[npre - 1];
+                    const std::string cp = tp + std::to_string(i) + "." + std::to_string(j);
+                    t = conv_bn(cp + ".0", cp + ".1", t, oc, 3, 2, ACT_RELU, nullptr);
+                }
+                xs[i] = t;
+            }
+        }
+        const int nmod = cfg.hr_modules[stage - 2];
+        for (int m = 0; m < nmod; ++m) {
+            const bool last = (stage == 4 && m == nmod - 1);          // multi_scale_output=False (:359-360)
+            std::vector<Tensor> br;
+            hr_module(*this, B + ".stage" + std::to_string(stage) + "." + std::to_string(m), xs, last ? 1 : nb,
+                      cfg.hr_blocks, (stage == 4 && m == 0) ? &br : nullptr);
+            if (stage == 4 && m == 0) {
+                // forward() returns x_list[1..3], which stage4[0] overwrote in place with its BRANCH
+                // outputs (:289-290, :501).
+                for (int i = 1; i < 4; ++i) feats[i] = br[i];
+            }
+        }
+        ys = xs;
+        pre_ch.assign(cfg.hr_channels, cfg.hr_channels + nb);
+    }
+    feats[0] = ys[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CPN-50 (networks/)
+// ---------------------------------------------------------------------------------------------------
+static Tensor pool_or_resize(Engine& e, OpKind kind, const std::string& name, const Tensor& x, int Ho, int Wo) {
+    Op op;
+    op.kind = kind;
+    op.name = name;
+    op.in[0] = x.buf;
+    e.use(x.buf);
+    op.H = x.H; op.W = x.W; op.C = x.C; op.Ho = Ho; op.Wo = Wo;
+    Tensor y{-1, Ho, Wo, x.C};
+    y.buf = e.new_buffer((size_t)Ho * Wo * x.C, name);
+    op.out = y.buf;
+    e.ops.push_back(op);
+    return y;
+}
+
+static void register_unused_conv_bn(Engine& e, const std::string& conv, const std::string& bn, int Cout, int Cin,
+                                    int ks) {
+    e.add_param(conv + ".weight", CAPF_P_CONV_W, {Cout, Cin, ks, ks});
+    e.add_param(bn + ".weight", CAPF_P_BN_W, {Cout});
+    e.add_param(bn + ".bias", CAPF_P_BN_B, {Cout});
+    e.add_param(bn + ".running_mean", CAPF_P_BN_MEAN, {Cout});
+    e.add_param(bn + ".running_var", CAPF_P_BN_VAR, {Cout});
+    e.add_param(bn + ".num_batches_tracked", CAPF_P_BN_NBT, {});
+}
+
+void Engine::build_cpn(Tensor img, Tensor feats[4]) {
+    const std::string R = "backbone.resnet";
+    Tensor x = conv_bn(R + ".conv1", R + ".bn1", img, 64, 7, 2, ACT_RELU, nullptr);       // resnet.py:137-139
+    x = pool_or_resize(*this, OP_MAXPOOL, R + ".maxpool", x, (x.H + 2 - 3) / 2 + 1, (x.W + 2 - 3) / 2 + 1);
+    const int nblk[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 2, 2};
+    Tensor c[4];
+    for (int li = 0; li < 4; ++li) {
+        for (int k = 0; k < nblk[li]; ++k) {                                               // :58-93, :119-133
+            const std::string p = R + ".layer" + std::to_string(li + 1) + "." + std::to_string(k);
+            const int st = (k == 0) ? strides[li] : 1;
+            Tensor y = conv_bn(p + ".conv1", p + ".bn1", x, planes[li], 1, 1, ACT_RELU, nullptr);
+            y = conv_bn(p + ".conv2", p + ".bn2", y, planes[li], 3, st, ACT_RELU, nullptr);
+            Tensor r = x;
+            if (k == 0) r = conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes[li] * 4, 1, st, ACT_NONE, nullptr);
+            x = conv_bn(p + ".conv3", p + ".bn3", y, planes[li] * 4, 1, 1, ACT_RELU, &r);
+        }
+        c[li] = x;
+    }
+    // globalNet.forward (globalNet.py:61-83); res_out = [x4,x3,x2,x1]
+    const std::string G = "backbone.global_net";
+    Tensor fms[4], up;
+    for (int i = 0; i < 4; ++i) {
+        const Tensor& src = c[3 - i];
+        const std::string lp = G + ".laterals." + std::to_string(i);
+        Tensor lat = conv_bn(lp + ".0", lp + ".1", src, 256, 1, 1, ACT_RELU, nullptr);
+        if (i == 0) {
+            fms[i] = lat;
+        } else {
+            // up = BN(conv1x1(bilinear x2(feature_{i-1})));  feature_i = lateral_i + up  (add in the epilogue)
+            const std::string upn = G + ".upsamples." + std::to_string(i - 1);
+            Tensor u = pool_or_resize(*this, OP_RESIZE, upn + ".0", fms[i - 1], fms[i - 1].H * 2, fms[i - 1].W * 2);
+            fms[i] = conv_bn(upn + ".1", upn + ".2", u, 256, 1, 1, ACT_NONE, &lat);
+        }
+        // predict heads: computed-then-discarded by the reference (:71) -> parameters only
+        const std::string pp = G + ".predict." + std::to_string(i);
+        register_unused_conv_bn(*this, pp + ".0", pp + ".1", 256, 256, 1);
+        register_unused_conv_bn(*this, pp + ".3", pp + ".5", 17, 256, 3);
+    }
+    // refineNet.forward (refineNet.py:72-88)
+    const std::string F = "backbone.refine_net";
+    const int oh = 64, ow = 48;   // cpn/test_config.py:24 output_shape
+    for (int i = 0; i < 4; ++i) {
+        Tensor y = fms[i];
+        for (int k = 0; k < 3 - i; ++k) {
+            const std::string p = F + ".cascade." + std::to_string(i) + "." + std::to_string(k);
+            Tensor t = conv_bn(p + ".conv1", p + ".bn1", y, 128, 1, 1, ACT_RELU, nullptr);
+            t = conv_bn(p + ".conv2", p + ".bn2", t, 128, 3, 1, ACT_RELU, nullptr);
+            Tensor r = conv_bn(p + ".downsample.0", p + ".downsample.1", y, 256, 1, 1, ACT_NONE, nullptr);
+            y = conv_bn(p + ".conv3", p + ".bn3", t, 256, 1, 1, ACT_RELU, &r);
+        }
+        feats[i] = pool_or_resize(*this, OP_RESIZE, F + ".cascade." + std::to_string(i) + ".resize", y, oh, ow);
+    }
+    // final_predict is never called (:76-88): parameters only
+    const std::string fp = F + ".final_predict";
+    register_unused_conv_bn(*this, fp + ".0.conv1", fp + ".0.bn1", 128, 1024, 1);
+    register_unused_conv_bn(*this, fp + ".0.conv2", fp + ".0.bn2", 128, 128, 3);
+    register_unused_conv_bn(*this, fp + ".0.conv3", fp + ".0.bn3", 256, 128, 1);
+    register_unused_conv_bn(*this, fp + ".0.downsample.0", fp + ".0.downsample.1", 256, 1024, 1);
+    register_unused_conv_bn(*this, fp + ".1", fp + ".2", 17, 256, 3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lifter (pose_dformer.py)
+// ---------------------------------------------------------------------------------------------------
+struct LinearRef {
+    int w, b, N, K;
+};
+
+static LinearRef reg_linear(Engine& e, const std::string& p, int N, int K) {
+    LinearRef r;
+    r.w = e.add_param(p + ".weight", CAPF_P_LIN_W, {N, K});
+    r.b = e.add_param(p + ".bias", CAPF_P_LIN_B, {N});
+    r.N = N;
+    r.K = K;
+    return r;
+}
+
+static void reg_ln(Engine& e, const std::string& p, int C) {
+    e.add_param(p + ".weight", CAPF_P_LN_W, {C});
+    e.add_param(p + ".bias", CAPF_P_LN_B, {C});
+}
+
+static int pidx(Engine& e, const std::string& n) { return e.param_index.at(n); }
+
+static int make_linear_pack(Engine& e, const std::vector<std::string>& names) {
+    Pack pk;
+    pk.kind = 1;
+    pk.n_lin = (int)names.size();
+    int N = 0, K = 0;
+    for (int i = 0; i < pk.n_lin; ++i) {
+        pk.w[i] = pidx(e, names[i] + ".weight");
+        pk.b[i] = pidx(e, names[i] + ".bias");
+        N += (int)e.params[pk.w[i]].shape[0];
+        K = (int)e.params[pk.w[i]].shape[1];
+    }
+    pk.N = N;
+    pk.K = K;
+    pk.Kpad = round32(K);
+    pk.direct = (pk.n_lin == 1 && pk.Kpad == K);
+    e.packs.push_back(pk);
+    return (int)e.packs.size() - 1;
+}
+
+// rows-mode GEMM:  out[omap(m) + n] = act(A[amap(m)] . W[n] + b[n] + res[rmap(m) + n])
+static void gemm_rows(Engine& e, const std::string& name, int pack, int a_buf, RowMap amap, long rows_pf, int out_buf,
+                      RowMap omap, int act, int res_buf, RowMap rmap, int res_param = -1) {
+    const Pack& pk = e.packs[pack];
+    Op op;
+    op.kind = OP_GEMM;
+    op.name = name;
+    op.conv = 0;
+    op.pack = pack;
+    op.in[0] = a_buf;
+    op.amap = amap;
+    op.rows_per_frame = rows_pf;
+    op.N = pk.N; op.K = pk.K; op.act = act;
+    op.out = out_buf;
+    op.omap = omap;
+    op.aux = res_buf;
+    op.rmap = rmap;
+    op.res_param = res_param;
+    op.flops_per_frame = 2.0 * rows_pf * (double)pk.N * pk.K;
+    e.use(a_buf);
+    e.use(res_buf);
+    e.use(out_buf);
+    e.ops.push_back(op);
+}
+
+static void layernorm(Engine& e, const std::string& name, const std::string& ln, float eps, int in_buf, RowMap imap,
+                      int add_buf, RowMap amap, int out_buf, long rows_pf, int C) {
+    Op op;
+    op.kind = OP_LAYERNORM;
+    op.name = name;
+    op.in[0] = in_buf;
+    op.amap = imap;
+    op.aux = add_buf;
+    op.rmap = amap;
+    op.out = out_buf;
+    op.p0 = pidx(e, ln + ".weight");
+    op.p1 = pidx(e, ln + ".bias");
+    op.eps = eps;
+    op.rows_per_frame = rows_pf;
+    op.C = C;
+    e.use(in_buf);
+    e.use(add_buf);
+    e.use(out_buf);
+    e.ops.push_back(op);
+}
+
+static void debug_copy(Engine& e, const std::string& name, int src, size_t elems, std::initializer_list<int64_t> shape) {
+    Op op;
+    op.kind = OP_FUSE;       // a 1-input fuse without ReLU is a plain copy
+    op.name = "copy." + name;
+    op.n_in = 1;
+    op.in[0] = src;
+    op.H = 1; op.W = 1; op.C = (int)elems; op.relu = 0;
+    op.i0 = 1;               // debug-only op
+    e.use(src);
+    op.out = e.new_buffer(elems, name);
+    e.ops.push_back(op);
+    name_tensor(e, name, op.out, shape);
+}
+
+void Engine::build_lifter(const Tensor feats[4]) {
+    const std::string V = "volume_net";
+    const int J = cfg.num_joints, L = cfg.levels, L1 = L + 1, C = cfg.embed_dim_ratio, D = C * L1;
+    const int NH = cfg.deform_heads, NS = cfg.deform_samples, HD = C / NH;
+    int Cl[4];
+    for (int l = 0; l < L; ++l) Cl[l] = feats[l].C;
+
+    // ---- schema, in the reference's registration order (pose_dformer.py:174-208)
+    const int pos = add_param(V + ".Spatial_pos_embed", CAPF_P_RAW, {1, L1, J, C});
+    reg_linear(*this, V + ".coord_embed", C, 2);
+    for (int l = 0; l < L; ++l) reg_linear(*this, V + ".feat_embed." + std::to_string(l), C, Cl[l]);
+    auto reg_block = [&](const std::string& p, int dim) {
+        reg_ln(*this, p + ".norm1", dim);
+        reg_linear(*this, p + ".attn.qkv", 3 * dim, dim);
+        reg_linear(*this, p + ".attn.proj", dim, dim);
+        reg_ln(*this, p + ".norm2", dim);
+        reg_linear(*this, p + ".mlp.fc1", 2 * dim, dim);
+        reg_linear(*this, p + ".mlp.fc2", dim, 2 * dim);
+    };
+    for (int i = 0; i < L; ++i) reg_block(V + ".joint_blocks." + std::to_string(i), D);
+    for (int i = 0; i < L; ++i) reg_block(V + ".res_blocks." + std::to_string(i), C);
+    if (cfg.context_blocks) {
+        for (int i = 0; i < L; ++i) {
+            const std::string p = V + ".context_blocks." + std::to_string(i);
+            reg_ln(*this, p + ".norm1", C);
+            reg_linear(*this, p + ".attention_weights", NH * NS, C);
+            reg_linear(*this, p + ".sampling_offsets", 2 * NH * NS, C);
+            for (int l = 0; l < L; ++l) reg_linear(*this, p + ".embed_proj." + std::to_string(l), HD, Cl[l]);
+            reg_ln(*this, p + ".norm2", C);
+            reg_linear(*this, p + ".mlp.fc1", 2 * C, C);
+            reg_linear(*this, p + ".mlp.fc2", C, 2 * C);
+        }
+    }
+    reg_ln(*this, V + ".head.0", D);
+    reg_linear(*this, V + ".head.1", 3, D);
+
+    // ---- buffers (per frame)
+    const int X = new_buffer((size_t)J * D, "tokens");            // [J, L1, C]  ("b p l c")
+    const int Q = new_buffer((size_t)J * D, "ln_out");
+    const int Hb = new_buffer((size_t)J * 2 * D, "mlp_hidden");
+    const int QKV = new_buffer((size_t)J * 3 * D, "qkv");
+    const int O = new_buffer((size_t)J * D, "attn_out");
+    keep(*this, X); keep(*this, Q); keep(*this, Hb); keep(*this, QKV); keep(*this, O);
+
+    // ---- embedding + reference-point sampling (pose_dformer.py:214-226)
+    {
+        Op op;
+        op.kind = OP_PREP_EMBED;
+        op.name = "prep_embed";
+        op.out = X;
+        op.p0 = pidx(*this, V + ".coord_embed.weight");
+        op.p1 = pidx(*this, V + ".coord_embed.bias");
+        op.p2 = pos;
+        op.i0 = J; op.i1 = L1; op.C = C;
+        use(X);
+        ops.push_back(op);
+    }
+    for (int l = 0; l < L; ++l) {
+        const std::string ls = std::to_string(l);
+        Op op;
+        op.kind = OP_SAMPLE_REF;
+        op.name = "sample_ref." + ls;
+        op.in[0] = feats[l].buf;
+        op.H = feats[l].H; op.W = feats[l].W; op.C = Cl[l]; op.i0 = J;
+        use(feats[l].buf);
+        const int S = new_buffer((size_t)J * Cl[l], "sampled" + ls);
+        const int I = new_buffer((size_t)J * 2, "idx" + ls);
+        op.out = S;
+        op.aux2 = I;
+        ops.push_back(op);
+        name_tensor(*this, "sampled" + ls, S, {-1, J, Cl[l]});
+        name_tensor(*this, "idx" + ls, I, {-1, J, 2}, 1);
+        const int pk = make_linear_pack(*this, {V + ".feat_embed." + ls});
+        // out X[b,p,1+l,:] = S W^T + b + pos[0,1+l,p,:]
+        gemm_rows(*this, "feat_embed." + ls, pk, S, row_ld(Cl[l]), J, X, row_ld(D, (long)(1 + l) * C), ACT_NONE, -1,
+                  RowMap{J, 0, C, (long)(1 + l) * J * C}, pos);
+    }
+
+    // ---- deformable context blocks (pose_dformer.py:115-141), tokens 1..L with token 0 as query bias
+    if (cfg.context_blocks) {
+        const int AO = new_buffer((size_t)J * L * 3 * NH * NS, "attn_off");
+        keep(*this, AO);
+        int U[4];
+        for (int l = 0; l < L; ++l) {
+            U[l] = new_buffer((size_t)J * NH * Cl[l], "deform_u" + std::to_string(l));
+            keep(*this, U[l]);
+        }
+        const RowMap tok{L, D, C, C};           // row (b,p,l') -> X[b,p,1+l',:]
+        const RowMap tok0{L, D, 0, 0};          // row (b,p,l') -> X[b,p,0,:]
+        for (int i = 0; i < L; ++i) {
+            const std::string p = V + ".context_blocks." + std::to_string(i);
+            const std::string n = "ctx" + std::to_string(i);
+            layernorm(*this, n + ".norm1", p + ".norm1", 1e-5f, X, tok, X, tok0, Q, (long)J * L, C);
+            const int pk_ao = make_linear_pack(*this, {p + ".attention_weights", p + ".sampling_offsets"});
+            gemm_rows(*this, n + ".attn_off", pk_ao, Q, row_ld(C), (long)J * L, AO, row_ld(3 * NH * NS), ACT_NONE, -1,
+                      row_ld(0));
+            {
+                Op op;
+                op.kind = OP_DEFORM;
+                op.name = n + ".deform";
+                op.aux = AO;
+                use(AO);
+                for (int l = 0; l < L; ++l) {
+                    op.in[l] = feats[l].buf;
+                    op.lvlH[l] = feats[l].H; op.lvlW[l] = feats[l].W; op.lvlC[l] = Cl[l];
+                    op.outs[l] = U[l];
+                    use(feats[l].buf);
+                    use(U[l]);
+                }
+                op.i0 = J; op.i1 = L; op.i2 = NH; op.i3 = NS;
+                ops.push_back(op);
+            }
+            for (int l = 0; l < L; ++l) {
+                const int pk = make_linear_pack(*this, {p + ".embed_proj." + std::to_string(l)});
+                const RowMap dst{NH, D, HD, (long)(1 + l) * C};    // row (b,p,h) -> X[b,p,1+l,h*HD:]
+                gemm_rows(*this, n + ".embed_proj." + std::to_string(l), pk, U[l], row_ld(Cl[l]), (long)J * NH, X, dst,
+                          ACT_NONE, X, dst);
+            }
+            layernorm(*this, n + ".norm2", p + ".norm2", 1e-5f, X, tok, -1, row_ld(0), Q, (long)J * L, C);
+            gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(C), (long)J * L, Hb,
+                      row_ld(2 * C), ACT_GELU, -1, row_ld(0));
+            gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}), Hb, row_ld(2 * C), (long)J * L, X, tok,
+                      ACT_NONE, X, tok);
+        }
+    }
+    debug_copy(*this, "tok_ctx", X, (size_t)J * D, {-1, J, L1, C});
+
+    // ---- Block x L over the L1 level-tokens of each joint, then over the J joint tokens (:231-238)
+    auto attn_blocks = [&](const std::string& group, const std::string& tag, int dim, long rows_pf, int tokens,
+                           int groups_pf) {
+        for (int i = 0; i < L; ++i) {
+            const std::string p = V + "." + group + "." + std::to_string(i);
+            const std::string n = tag + std::to_string(i);
+            layernorm(*this, n + ".norm1", p + ".norm1", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
+            gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}), Q, row_ld(dim), rows_pf, QKV,
+                      row_ld(3 * dim), ACT_NONE, -1, row_ld(0));
+            {
+                Op op;
+                op.kind = OP_ATTENTION;
+                op.name = n + ".attn";
+                op.in[0] = QKV;
+                op.out = O;
+                op.i0 = groups_pf; op.i1 = tokens; op.i2 = cfg.num_heads; op.i3 = dim / cfg.num_heads;
+                op.flops_per_frame = 4.0 * groups_pf * tokens * tokens * dim;
+                use(QKV); use(O);
+                ops.push_back(op);
+            }
+            gemm_rows(*this, n + ".proj", make_linear_pack(*this, {p + ".attn.proj"}), O, row_ld(dim), rows_pf, X,
+                      row_ld(dim), ACT_NONE, X, row_ld(dim));
+            layernorm(*this, n + ".norm2", p + ".norm2", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
+            gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(dim), rows_pf, Hb,
+                      row_ld(2 * dim), ACT_GELU, -1, row_ld(0));
+            gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}), Hb, row_ld(2 * dim), rows_pf, X,
+                      row_ld(dim), ACT_NONE, X, row_ld(dim));
+        }
+    };
+    attn_blocks("res_blocks", "res", C, (long)J * L1, L1, J);
+    debug_copy(*this, "tok_res", X, (size_t)J * D, {-1, J, L1, C});
+    attn_blocks("joint_blocks", "joint", D, (long)J, J, 1);
+    debug_copy(*this, "tok_joint", X, (size_t)J * D, {-1, J, L1, C});
+
+    {   // head (:240)
+        Op op;
+        op.kind = OP_HEAD;
+        op.name = "head";
+        op.in[0] = X;
+        op.p0 = pidx(*this, V + ".head.0.weight");
+        op.p1 = pidx(*this, V + ".head.0.bias");
+        op.p2 = pidx(*this, V + ".head.1.weight");
+        op.p3 = pidx(*this, V + ".head.1.bias");
+        op.eps = 1e-5f;
+        op.rows_per_frame = J;
+        op.C = D;
+        op.i0 = 3;
+        op.flops_per_frame = 2.0 * J * D * 3;
+        use(X);
+        ops.push_back(op);
+    }
+}
+
+// Greedy offset assignment over buffer lifetimes (ops run in order on one stream).
+void Engine::assign_offsets() {
+    struct Live { size_t off, size; int last; };
+    std::vector<int> order(bufs.size());
+    for (size_t i = 0; i < bufs.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bufs[a].def_op < bufs[b].def_op; });
+    std::vector<Live> live;
+    size_t top = 0;
+    for (int id : order) {
+        Buffer& b = bufs[id];
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.last < b.def_op; }), live.end());
+        std::sort(live.begin(), live.end(), [](const Live& x, const Live& y) { return x.off < y.off; });
+        size_t off = 0;
+        for (const Live& l : live) {
+            if (off + b.elems <= l.off) break;
+            off = std::max(off, l.off + l.size);
+        }
+        b.offset = off;
+        live.push_back(Live{off, b.elems, b.last_op});
+        top = std::max(top, off + b.elems);
+    }
+    ws_elems_per_frame = top;
+}
+
+bool Engine::build() {
+    if (cfg.height % 32 != 0 || cfg.width % 32 != 0) {
+        err = "height and width must be multiples of 32";
+        return false;
+    }
+    if (cfg.levels != 4 || cfg.num_joints <= 0 || cfg.embed_dim_ratio % (4 * cfg.num_heads) != 0 ||
+        cfg.embed_dim_ratio % (4 * cfg.deform_heads) != 0 || cfg.deform_samples != 4 || cfg.deform_heads != 4) {
+        err = "unsupported lifter configuration (levels must be 4, 4x4 deformable sampling, embed_dim_ratio % 32 == 0)";
+        return false;
+    }
+    Tensor img{EXT_IMAGES, cfg.height, cfg.width, 3};
+    Tensor feats[4];
+    if (cfg.backbone == CAPF_HRNET) {
+        for (int i = 0; i < 4; ++i)
+            if (cfg.hr_channels[i] <= 0 || cfg.hr_channels[i] % 4 != 0) {
+                err = "HRNet branch widths must be positive multiples of 4";
+                return false;
+            }
+        build_hrnet(img, feats);
+    } else if (cfg.backbone == CAPF_CPN50) {
+        build_cpn(img, feats);
+    } else {
+        err = "unknown backbone";
+        return false;
+    }
+    for (int l = 0; l < 4; ++l) {
+        name_tensor(*this, "feat" + std::to_string(l), feats[l].buf, {-1, feats[l].H, feats[l].W, feats[l].C});
+        const int expect = cfg.backbone == CAPF_CPN50 ? cfg.base_dim : cfg.base_dim << l;
+        if (feats[l].C != expect) {
+            err = "poseformer.base_dim does not match the backbone's context-map widths";
+            return false;
+        }
+    }
+    n_backbone_ops = (int)ops.size();
+    build_lifter(feats);
+    assign_offsets();
+    // pack arena layout
+    size_t off = 0;
+    for (Pack& pk : packs) {
+        if (pk.direct) continue;
+        pk.w_off = off;
+        off += round64((size_t)pk.N * pk.Kpad);
+        pk.b_off = off;
+        off += round64((size_t)pk.N);
+    }
+    pack_elems = off;
+    return true;
+}
+
+}  // namespace capf

@@ -1,0 +1,143 @@
+/*
+ * capf.h — C ABI of the MI355X-native Context-Aware PoseFormer hot path.
+ *
+ * The reference (QitaoZhao/ContextAware-PoseFormer) is pure Python/PyTorch: it has no FFI, plugin or
+ * operator registry.  Its hot path sits behind one nn.Module call,
+ *
+ *     CA_PF.forward(images[B,H,W,3], keypoints_2d[B,17,2], keypoints_2d_crop[B,17,2]) -> [B,1,17,3]
+ *                                                   ContextPose/mvn/models/conpose.py:30-42
+ *
+ * so the "binding a maintainer would add" is a ctypes stub inside that forward.
+ * Every entry point below names the reference code it replaces.  Conventions:
+ *   - plain C types only; device memory is caller-owned (the PyTorch host module keeps owning
+ *     parameters, so optimizers / DDP / checkpoints keep working); the library borrows pointers.
+ *   - every call returns 0 on success or a negative capf_status; capf_last_error() has the text.
+ *   - stream-ordered, no hidden synchronisation, no allocation inside capf_forward.
+ *   - a handle is not thread-safe; one handle per (process, device).
+ */
+#ifndef CAPF_H
+#define CAPF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct capf_handle capf_handle;
+
+enum capf_status {
+    CAPF_OK = 0,
+    CAPF_ERR_INVALID = -1,     /* bad argument / unknown name / shape mismatch */
+    CAPF_ERR_UNSUPPORTED = -2, /* configuration the kernels do not cover */
+    CAPF_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed */
+    CAPF_ERR_STATE = -4        /* call order: params / workspace not set */
+};
+
+enum capf_backbone { CAPF_HRNET = 0, CAPF_CPN50 = 1 };
+enum capf_dtype { CAPF_F32 = 0, CAPF_BF16 = 1 };
+
+/* parameter kinds reported by capf_param_info (lets the host build matching leaf modules) */
+enum capf_param_kind {
+    CAPF_P_CONV_W = 0,   /* nn.Conv2d.weight  [Cout,Cin,kh,kw]  (bias=False everywhere) */
+    CAPF_P_BN_W = 1, CAPF_P_BN_B = 2, CAPF_P_BN_MEAN = 3, CAPF_P_BN_VAR = 4, CAPF_P_BN_NBT = 5,
+    CAPF_P_LIN_W = 6, CAPF_P_LIN_B = 7,     /* nn.Linear [out,in], [out] */
+    CAPF_P_LN_W = 8, CAPF_P_LN_B = 9,       /* nn.LayerNorm */
+    CAPF_P_RAW = 10                         /* bare nn.Parameter (Spatial_pos_embed) */
+};
+
+/*
+ * Model description == the subset of the reference's global config that CA_PF.__init__ reads:
+ *   config.model.backbone.{type,STAGE2..4.NUM_CHANNELS,NUM_MODULES,NUM_BLOCKS}  (conpose.py:14-20,
+ *       pose_hrnet.py:330-370, mvn/utils/cfg.py:24-66)
+ *   config.model.poseformer.{base_dim,embed_dim_ratio,levels}                    (pose_dformer.py:167-172)
+ */
+typedef struct capf_config {
+    int32_t backbone;          /* capf_backbone */
+    int32_t hr_channels[4];    /* HRNet branch widths: {32,64,128,256} (W32) / {48,96,192,384} (W48) */
+    int32_t hr_modules[3];     /* NUM_MODULES of stage2..4: {1,4,3} */
+    int32_t hr_blocks;         /* NUM_BLOCKS per branch: 4 */
+    int32_t base_dim;          /* poseformer.base_dim: 32 / 48 / 256(cpn) */
+    int32_t embed_dim_ratio;   /* 128 */
+    int32_t levels;            /* 4 (also the depth of every block group, pose_dformer.py:169) */
+    int32_t num_joints;        /* 17 */
+    int32_t num_heads;         /* 8  (Block) */
+    int32_t deform_heads;      /* 4  (DeformableBlock, pose_dformer.py:202) */
+    int32_t deform_samples;    /* 4 */
+    int32_t context_blocks;    /* 1 = H36M model; 0 = MPI-INF-3DHP variant without DeformableBlocks */
+    int32_t compute_dtype;     /* capf_dtype: MFMA operand type of the backbone convs / lifter GEMMs */
+    int32_t max_batch;         /* workspace is sized for this many frames */
+    int32_t height, width;     /* input image size (256x256, 256x192, 384x288, ...) */
+} capf_config;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * Replaces CA_PF.__init__ (conpose.py:10-27): builds the layer plan (pose_hrnet.py:312-462 /
+ * networks/network.py:9-28 / pose_dformer.py:144-208) and the parameter schema.
+ * device < 0: "plan only" — no HIP call is made; schema / workspace queries work (CPU tests).   */
+int capf_create(const capf_config* cfg, int device, capf_handle** out);
+void capf_destroy(capf_handle* h);
+const char* capf_last_error(const capf_handle* h);  /* h may be NULL: last create error */
+const char* capf_version(void);
+
+/* ---- parameter schema == the reference's state_dict ------------- */
+int capf_num_params(const capf_handle* h);
+int capf_param_info(const capf_handle* h, int index, const char** name, int64_t shape[4],
+                    int* ndim, int* kind);
+
+/* Borrow a device pointer for one state_dict entry (fp32; BN num_batches_tracked is ignored).
+ * Replaces nn.Module parameter lookup during forward.  The pointer must stay valid until the
+ * next capf_set_param for that name or capf_destroy. */
+int capf_set_param(capf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape,
+                   int ndim);
+
+/* Re-derive the private packed copies (BN folded into conv weights+bias, weights re-laid out
+ * K-major for the MFMA kernels, bf16 copies).  Call after load_state_dict / optimizer.step().
+ * Stream-ordered on `stream` (hipStream_t passed as void*). */
+int capf_params_changed(capf_handle* h, void* stream);
+
+/* ---- workspace (activations); caller-owned so the host allocator (torch) stays in charge ----- */
+size_t capf_workspace_bytes(const capf_handle* h, int batch);
+int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes);
+
+/* ---- the hot path ----------------------------------------------------------------------------
+ * Replaces CA_PF.forward (conpose.py:30-42) = NHWC->NCHW permute (:32, folded into the stem conv's
+ * loads), in-place crop-keypoint normalisation (:34-35, done in place on kcrop_inout exactly like
+ * the reference), backbone forward (:38, pose_hrnet.py:464-501 / networks/network.py:16-22) and
+ * PoseTransformer.forward (:40, pose_dformer.py:210-241).
+ *   images_nhwc [B,H,W,3] fp32, k2d [B,17,2] fp32, kcrop_inout [B,17,2] fp32 (MUTATED),
+ *   out [B,1,17,3] fp32.  All device pointers.  Enqueued on `stream`; returns immediately.      */
+int capf_forward(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
+                 float* kcrop_inout, int batch, float* out);
+
+/* Backbone only: writes nothing to `out`; the four context maps stay in the workspace (NHWC) and
+ * can be read through capf_tensor("feat0".."feat3").  Replaces self.backbone(images) conpose.py:38. */
+int capf_backbone_forward(capf_handle* h, void* stream, const float* images_nhwc, int batch);
+
+/* Lifter only, on the context maps left in the workspace by the last capf_backbone_forward /
+ * capf_forward of the same batch.  Replaces self.volume_net(...) conpose.py:40
+ * (PoseTransformer.forward pose_dformer.py:210-241).  kcrop_inout is normalised in place. */
+int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* kcrop_inout, int batch,
+                        float* out);
+
+/* When on, forward also snapshots the token buffer after each block group (tok_ctx/tok_res/tok_joint). */
+int capf_set_debug(capf_handle* h, int on);
+
+/* Intermediates of the LAST forward, for stage-level parity tests.  Names:
+ *   feat0..feat3   context maps, NHWC [B,h,w,C_l]
+ *   sampled0..3    reference-point samples [B,17,C_l]          (pose_dformer.py:216-218)
+ *   idx0..idx3     int32 [B,17,2] (ix0, iy0) bilinear NW corner of those samples (bit-exact check)
+ *   tok_ctx / tok_res / tok_joint   token buffer [B,17,L+1,c] after each block group (layout b p l c)
+ * Pointers are into the workspace and valid until the next forward on this handle.
+ * Returns 0 for an fp32 tensor, 1 for an int32 tensor, negative on error. */
+int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, int64_t shape[4],
+                int* ndim);
+
+/* Number of kernel launches and algorithmic FLOPs (2*MAC of convs + GEMMs) of one forward at
+ * `batch`; used by bench.py for the roofline line. */
+int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPF_H */

@@ -1,0 +1,368 @@
+"""CPU oracle for the Context-Aware PoseFormer hot path (image + 17 2D keypoints -> 17x3 joints).
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this file, and only as the checker / the timed CPU baseline.  The
+product path (contextaware-poseformer_amd/) never imports it and has no CPU fallback.
+
+What it is: a from-the-math restatement, in plain functional PyTorch-CPU fp32 (floating-point
+path -> a torch fp32 reference is the appropriate oracle; the integer part, the bilinear corner
+indices, is additionally restated in numpy float32 in `bilinear_corners`), of
+
+    CA_PF.forward                      ContextPose/mvn/models/conpose.py:30-42
+    PoseHighResolutionNet.forward      ContextPose/mvn/models/pose_hrnet.py:464-501
+    CPN.forward (+ResNet/global/refine) ContextPose/mvn/models/networks/network.py:16-22
+    PoseTransformer.forward            ContextPose/mvn/models/pose_dformer.py:210-241
+    MPJPE.forward                      ContextPose/mvn/models/loss.py:16-22
+
+It consumes a flat {state_dict_name: tensor} mapping with exactly the reference's names (SURVEY.md
+§8b / Appendix B), so the same synthetic checkpoint feeds the reference (in the build container),
+this oracle and the HIP path.
+
+Parity pin: the reference has no tests / golden vectors of its own, so this oracle is
+pinned against outputs of the reference itself, imported on CPU in the build container by
+oracle/make_goldens.py, which writes tests/golden/*.npz; tests/test_oracle_golden.py replays them
+(runs on CPU, no reference needed).  Third-party arithmetic (ATen conv / grid_sampler / layer_norm,
+timm DropPath, einops.rearrange) is restated from its documented semantics; the bilinear rule follows
+ATen/native/GridSampler.h:27-36,58-60,143-171 of the installed torch (the reference pins 1.11.0).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm2d default, used everywhere in the reference backbones
+
+
+# ----------------------------------------------------------------------------------------------
+# small building blocks
+# ----------------------------------------------------------------------------------------------
+def _conv(P, name, x, stride=1, pad=0):
+    return F.conv2d(x, P[name + ".weight"], None, stride, pad)
+
+
+def _bn(P, name, x):
+    # eval-mode BatchNorm2d: y = (x - mean) / sqrt(var + eps) * gamma + beta
+    return F.batch_norm(x, P[name + ".running_mean"], P[name + ".running_var"],
+                        P[name + ".weight"], P[name + ".bias"], False, 0.0, BN_EPS)
+
+
+def _linear(P, name, x):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _ln(P, name, x, eps):
+    w = P[name + ".weight"]
+    return F.layer_norm(x, (w.shape[0],), w, P[name + ".bias"], eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# HRNet (pose_hrnet.py)
+# ----------------------------------------------------------------------------------------------
+def _basic_block(P, pre, x):
+    """pose_hrnet.py:66-95 (never has a downsample inside HRNet stages: in==out, stride 1)."""
+    y = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x, 1, 1)))
+    y = _bn(P, pre + ".bn2", _conv(P, pre + ".conv2", y, 1, 1))
+    return F.relu(y + x)
+
+
+def _bottleneck(P, pre, x):
+    """pose_hrnet.py:98-136; downsample (1x1 conv + BN) exists iff its keys are present."""
+    y = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x)))
+    y = F.relu(_bn(P, pre + ".bn2", _conv(P, pre + ".conv2", y, 1, 1)))
+    y = _bn(P, pre + ".bn3", _conv(P, pre + ".conv3", y))
+    if (pre + ".downsample.0.weight") in P:
+        x = _bn(P, pre + ".downsample.1", _conv(P, pre + ".downsample.0", x))
+    return F.relu(y + x)
+
+
+def _hr_module(P, pre, xs, n_out):
+    """HighResolutionModule.forward, pose_hrnet.py:285-303.
+
+    Returns (fused outputs, branch outputs).  The reference mutates its input list in place
+    (:289-290); the caller reproduces the aliasing consequence explicitly (see hrnet_forward).
+    """
+    nb = len(xs)
+    br = []
+    for i in range(nb):
+        y = xs[i]
+        for k in range(4):                                   # NUM_BLOCKS = 4 everywhere (cfg.py:44,53,62)
+            y = _basic_block(P, f"{pre}.branches.{i}.{k}", y)
+        br.append(y)
+    outs = []
+    for i in range(n_out):
+        acc = None
+        for j in range(nb):
+            if j == i:
+                t = br[j]
+            elif j > i:                                      # 1x1 conv + BN + nearest upsample (:238-245)
+                fp = f"{pre}.fuse_layers.{i}.{j}"
+                t = _bn(P, fp + ".1", _conv(P, fp + ".0", br[j]))
+                t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
+            else:                                            # chain of 3x3 s2 convs (:249-275)
+                t = br[j]
+                for k in range(i - j):
+                    fp = f"{pre}.fuse_layers.{i}.{j}.{k}"
+                    t = _bn(P, fp + ".1", _conv(P, fp + ".0", t, 2, 1))
+                    if k != i - j - 1:
+                        t = F.relu(t)
+            acc = t if acc is None else acc + t              # summation order j = 0,1,2,.. (:294-300)
+        outs.append(F.relu(acc))
+    return outs, br
+
+
+def hrnet_forward(P, x, pre="backbone"):
+    """PoseHighResolutionNet.forward, pose_hrnet.py:464-501.  x: [B,3,H,W] -> 4 maps (NCHW)."""
+    x = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x, 2, 1)))
+    x = F.relu(_bn(P, pre + ".bn2", _conv(P, pre + ".conv2", x, 2, 1)))
+    for k in range(4):
+        x = _bottleneck(P, f"{pre}.layer1.{k}", x)
+
+    def trans(name, src):
+        # _make_transition_layer pose_hrnet.py:377-411: either one 3x3 s1 conv (same branch,
+        # channel change) or a 3x3 s2 conv from the last branch (new branch); +BN+ReLU.
+        if (name + ".0.weight") in P:
+            return F.relu(_bn(P, name + ".1", _conv(P, name + ".0", src, 1, 1)))
+        return F.relu(_bn(P, name + ".0.1", _conv(P, name + ".0.0", src, 2, 1)))
+
+    xs = [trans(pre + ".transition1.0", x), trans(pre + ".transition1.1", x)]
+    ys, _ = _hr_module(P, pre + ".stage2.0", xs, 2)
+
+    xs = [ys[0], ys[1], trans(pre + ".transition2.2", ys[-1])]
+    for m in range(4):
+        ys, _ = _hr_module(P, f"{pre}.stage3.{m}", xs if m == 0 else ys, 3)
+
+    xs = [ys[0], ys[1], ys[2], trans(pre + ".transition3.3", ys[-1])]
+    ys, br0 = _hr_module(P, pre + ".stage4.0", xs, 4)
+    ys, _ = _hr_module(P, pre + ".stage4.1", ys, 4)
+    ys, _ = _hr_module(P, pre + ".stage4.2", ys, 1)
+    # :501 returns [y_list[0], x_list[1], x_list[2], x_list[3]]; x_list was mutated in place by
+    # stage4[0] (:289-290), so entries 1..3 are stage4[0]'s *branch* outputs.
+    return [ys[0], br0[1], br0[2], br0[3]]
+
+
+# ----------------------------------------------------------------------------------------------
+# CPN-50 (networks/resnet.py, globalNet.py, refineNet.py)
+# ----------------------------------------------------------------------------------------------
+def _res_bottleneck(P, pre, x, stride):
+    """networks/resnet.py:58-93 (expansion 4, stride on the 3x3)."""
+    y = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x)))
+    y = F.relu(_bn(P, pre + ".bn2", _conv(P, pre + ".conv2", y, stride, 1)))
+    y = _bn(P, pre + ".bn3", _conv(P, pre + ".conv3", y))
+    if (pre + ".downsample.0.weight") in P:
+        x = _bn(P, pre + ".downsample.1", _conv(P, pre + ".downsample.0", x, stride))
+    return F.relu(y + x)
+
+
+def cpn_forward(P, x, pre="backbone", out_hw=(64, 48)):
+    """CPN.forward networks/network.py:16-22 -> 4 maps [B,256,64,48].
+
+    The `predict` heads of globalNet (globalNet.py:71) and refineNet.final_predict are computed and
+    discarded / never called by the reference; they have no effect on the outputs and are skipped.
+    """
+    r = pre + ".resnet"
+    x = F.relu(_bn(P, r + ".bn1", _conv(P, r + ".conv1", x, 2, 3)))          # resnet.py:137-139
+    x = F.max_pool2d(x, 3, 2, 1)                                             # :140
+    feats = []
+    for li, (n, s) in enumerate(zip([3, 4, 6, 3], [1, 2, 2, 2])):            # :141-144, resnet50
+        for k in range(n):
+            x = _res_bottleneck(P, f"{r}.layer{li + 1}.{k}", x, s if k == 0 else 1)
+        feats.append(x)
+    res_out = feats[::-1]                                                    # [x4,x3,x2,x1] :147
+
+    g = pre + ".global_net"
+    fms, up = [], None
+    for i in range(4):                                                       # globalNet.py:61-83
+        f = F.relu(_bn(P, f"{g}.laterals.{i}.1", _conv(P, f"{g}.laterals.{i}.0", res_out[i])))
+        if i > 0:
+            f = f + up
+        fms.append(f)
+        if i != 3:
+            u = F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True)
+            up = _bn(P, f"{g}.upsamples.{i}.2", _conv(P, f"{g}.upsamples.{i}.1", u))
+
+    rn = pre + ".refine_net"
+    outs = []
+    for i in range(4):                                                       # refineNet.py:72-88
+        y = fms[i]
+        for k in range(3 - i):
+            bp = f"{rn}.cascade.{i}.{k}"
+            t = F.relu(_bn(P, bp + ".bn1", _conv(P, bp + ".conv1", y)))
+            t = F.relu(_bn(P, bp + ".bn2", _conv(P, bp + ".conv2", t, 1, 1)))
+            t = _bn(P, bp + ".bn3", _conv(P, bp + ".conv3", t))
+            y = F.relu(t + _bn(P, bp + ".downsample.1", _conv(P, bp + ".downsample.0", y)))
+        outs.append(F.interpolate(y, size=out_hw, mode="bilinear", align_corners=True))
+    return outs
+
+
+# ----------------------------------------------------------------------------------------------
+# bilinear sampling (F.grid_sample, bilinear, align_corners=True) — explicit restatement
+# ----------------------------------------------------------------------------------------------
+def bilinear_corners(grid, H, W, padding):
+    """Integer corner indices + fp32 weights of grid_sample(bilinear, align_corners=True).
+
+    grid: float32 array [..., 2] holding (x, y) in normalised [-1, 1] coordinates.
+    padding: 'zeros' (pose_dformer.py:217 default) or 'border' (:128).
+    Returns dict(ix0, iy0 int32; wx1, wy1 float32 = fractional parts; valid masks for the four
+    corners in order nw, ne, sw, se).  Follows ATen GridSampler.h: unnormalise ((g+1)/2*(size-1)),
+    border mode clips the *coordinate* to [0, size-1] before floor; zeros mode keeps the coordinate
+    and drops out-of-range corners.
+    """
+    g = np.asarray(grid, dtype=np.float32)
+    x = (g[..., 0] + np.float32(1)) / np.float32(2) * np.float32(W - 1)
+    y = (g[..., 1] + np.float32(1)) / np.float32(2) * np.float32(H - 1)
+    if padding == "border":
+        x = np.minimum(np.maximum(x, np.float32(0)), np.float32(W - 1))
+        y = np.minimum(np.maximum(y, np.float32(0)), np.float32(H - 1))
+    x0f, y0f = np.floor(x), np.floor(y)
+    ix0, iy0 = x0f.astype(np.int64), y0f.astype(np.int64)
+    wx1 = (x - x0f).astype(np.float32)
+    wy1 = (y - y0f).astype(np.float32)
+    vx0, vx1 = (ix0 >= 0) & (ix0 < W), (ix0 + 1 >= 0) & (ix0 + 1 < W)
+    vy0, vy1 = (iy0 >= 0) & (iy0 < H), (iy0 + 1 >= 0) & (iy0 + 1 < H)
+    return dict(ix0=ix0.astype(np.int32), iy0=iy0.astype(np.int32), wx1=wx1, wy1=wy1,
+                valid=np.stack([vy0 & vx0, vy0 & vx1, vy1 & vx0, vy1 & vx1], -1))
+
+
+def grid_sample_explicit(feat, grid, padding):
+    """Same result as F.grid_sample(feat, grid, 'bilinear', padding, align_corners=True) built
+    from `bilinear_corners` (gather + lerp); feat [B,C,H,W], grid [B,h,w,2] -> [B,C,h,w]."""
+    B, C, H, W = feat.shape
+    c = bilinear_corners(grid.numpy(), H, W, padding)
+    ix0 = torch.from_numpy(c["ix0"].astype(np.int64))
+    iy0 = torch.from_numpy(c["iy0"].astype(np.int64))
+    wx1, wy1 = torch.from_numpy(c["wx1"]), torch.from_numpy(c["wy1"])
+    valid = torch.from_numpy(c["valid"])
+    wts = [(1 - wx1) * (1 - wy1), wx1 * (1 - wy1), (1 - wx1) * wy1, wx1 * wy1]   # nw ne sw se
+    offs = [(0, 0), (1, 0), (0, 1), (1, 1)]
+    flat = feat.reshape(B, C, H * W)
+    out = torch.zeros(B, C, *grid.shape[1:3])
+    for k in range(4):
+        xx = (ix0 + offs[k][0]).clamp(0, W - 1)
+        yy = (iy0 + offs[k][1]).clamp(0, H - 1)
+        idx = (yy * W + xx).reshape(B, 1, -1).expand(B, C, -1)
+        v = torch.gather(flat, 2, idx).reshape(B, C, *grid.shape[1:3])
+        out = out + v * (wts[k] * valid[..., k]).unsqueeze(1)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# lifting transformer (pose_dformer.py)
+# ----------------------------------------------------------------------------------------------
+def _mlp(P, pre, x):
+    """Mlp.forward pose_dformer.py:24-31 (exact erf GELU, dropout p=0)."""
+    return _linear(P, pre + ".fc2", F.gelu(_linear(P, pre + ".fc1", x)))
+
+
+def _attn_block(P, pre, x, heads, keep=None):
+    """Block.forward pose_dformer.py:76-79 with Attention.forward :46-59 inlined; LN eps 1e-6 (:166).
+    keep: optional (mask1, mask2) per-sample DropPath multipliers (training parity only)."""
+    B, N, C = x.shape
+    d = C // heads
+    h = _ln(P, pre + ".norm1", x, 1e-6)
+    qkv = _linear(P, pre + ".attn.qkv", h).reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(dim=-1)
+    h = _linear(P, pre + ".attn.proj", (a @ v).transpose(1, 2).reshape(B, N, C))
+    x = x + (h if keep is None else h * keep[0])
+    h = _mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", x, 1e-6))
+    return x + (h if keep is None else h * keep[1])
+
+
+def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False, keep=None):
+    """DeformableBlock.forward pose_dformer.py:115-141; LN eps 1e-5 (default nn.LayerNorm, :84)."""
+    x0, xr = x[:, :1], x[:, 1:]
+    b, l, p, c = xr.shape
+    q = _ln(P, pre + ".norm1", xr + x0, 1e-5)
+    w = _linear(P, pre + ".attention_weights", q).view(b, l, p, heads, samples)
+    w = F.softmax(w, dim=-1).unsqueeze(-1)
+    off = _linear(P, pre + ".sampling_offsets", q).reshape(b, l, p, heads * samples, 2).tanh()
+    pos = off + ref.view(b, 1, p, 1, -1)
+    sampled = []
+    for idx, f in enumerate(feats):
+        if explicit:
+            s = grid_sample_explicit(f, pos[:, idx], "border")
+        else:
+            s = F.grid_sample(f, pos[:, idx], mode="bilinear", padding_mode="border", align_corners=True)
+        s = s.permute(0, 2, 3, 1)                                           # b, p, heads*samples, C_l
+        sampled.append(_linear(P, f"{pre}.embed_proj.{idx}", s))
+    s = torch.stack(sampled, dim=1)                                         # b, l, p, hs, c/heads
+    s = (w * s.view(b, l, p, heads, samples, -1)).sum(dim=-2).view(b, l, p, -1)
+    xr = xr + (s if keep is None else s * keep[0])
+    h = _mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", xr, 1e-5))
+    xr = xr + (h if keep is None else h * keep[1])
+    return torch.cat([x0, xr], dim=1), pos
+
+
+def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=False, taps=None,
+                   context_blocks=True):
+    """PoseTransformer.forward pose_dformer.py:210-241.
+
+    k2d [B,17,2], ref [B,17,2] (already normalised), feats: 4 NCHW maps -> [B,1,17,3].
+    taps: optional dict that receives intermediates for stage-level parity tests.
+    """
+    b, p, _ = k2d.shape
+    x = _linear(P, pre + ".coord_embed", k2d)                               # :214
+    toks = []
+    for f in feats:                                                         # :216-218 (padding zeros)
+        g = ref.unsqueeze(-2)
+        s = (grid_sample_explicit(f, g, "zeros") if explicit else
+             F.grid_sample(f, g, mode="bilinear", padding_mode="zeros", align_corners=True))
+        toks.append(s.squeeze(-1).permute(0, 2, 1).contiguous())            # [B,17,C_l]
+    if taps is not None:
+        taps["sampled"] = toks
+    emb = [_linear(P, f"{pre}.feat_embed.{i}", t) for i, t in enumerate(toks)]   # :220-221
+    x = torch.stack([x, *emb], dim=1) + P[pre + ".Spatial_pos_embed"]       # :223-225
+    if taps is not None:
+        taps["tokens0"] = x
+    if context_blocks:
+        for i in range(levels):                                             # :228-229 (depth = levels, :169)
+            x, pos = _deformable_block(P, f"{pre}.context_blocks.{i}", x, ref, feats, explicit=explicit)
+            if taps is not None:
+                taps.setdefault("ctx_pos", []).append(pos)
+        if taps is not None:
+            taps["tokens_ctx"] = x
+    L = x.shape[1]
+    x = x.permute(0, 2, 1, 3).reshape(b * p, L, -1)                          # 'b l p c -> (b p) l c' :231
+    for i in range(levels):
+        x = _attn_block(P, f"{pre}.res_blocks.{i}", x, 8)                   # :233-234
+    x = x.reshape(b, p, -1)                                                 # '(b p) l c -> b p (l c)' :235
+    if taps is not None:
+        taps["tokens_res"] = x
+    for i in range(levels):
+        x = _attn_block(P, f"{pre}.joint_blocks.{i}", x, 8)                 # :237-238
+    if taps is not None:
+        taps["tokens_joint"] = x
+    x = _linear(P, pre + ".head.1", _ln(P, pre + ".head.0", x, 1e-5))       # :240
+    return x.view(b, 1, p, -1)
+
+
+# ----------------------------------------------------------------------------------------------
+# whole path + loss
+# ----------------------------------------------------------------------------------------------
+def normalise_crop_keypoints_(kcrop):
+    """conpose.py:34-35 — IN PLACE, hard-coded 192x256 crop constants."""
+    kcrop[..., :2] /= torch.tensor([192 // 2, 256 // 2], dtype=kcrop.dtype)
+    kcrop[..., :2] -= torch.tensor([1, 1], dtype=kcrop.dtype)
+    return kcrop
+
+
+def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit=False, taps=None):
+    """CA_PF.forward conpose.py:30-42.  images [B,H,W,3] NHWC fp32; mutates kcrop in place."""
+    x = images.permute(0, 3, 1, 2).contiguous()
+    ref = normalise_crop_keypoints_(kcrop)
+    feats = cpn_forward(P, x) if backbone == "cpn" else hrnet_forward(P, x)
+    if taps is not None:
+        taps["ref"] = ref.clone()
+        taps["features"] = feats
+    return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps)
+
+
+def mpjpe(pred, gt):
+    """MPJPE.forward loss.py:16-22."""
+    assert pred.shape == gt.shape
+    return torch.mean(torch.norm(pred - gt, dim=len(gt.shape) - 1))
+
+
+def gelu_exact(x):
+    return 0.5 * x * (1.0 + math.erf(x / math.sqrt(2.0)))

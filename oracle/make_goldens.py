@@ -1,0 +1,120 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported read-only from
+/root/reference on CPU, via oracle/_refshim.py) on deterministic synthetic weights and inputs.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+The reference cannot travel to the GPU box; these small fixtures (outputs only — inputs and
+weights are regenerated from seeds by capf.synth) are what pins both the oracle and the HIP path.
+
+Stored per case:  out [B,1,17,3]; ref [B,17,2] (in-place normalised crop keypoints, conpose.py:34-35);
+feat{l}_sum / feat{l}_abs (per-map fp64 checksums) and feat{l}_slice (an 8x8xC corner-ish window);
+sampled{l} [B,17,C_l] (pose_dformer.py:216-218); tok_ctx / tok_res / tok_joint (after each block
+group); and for w32_256x256_b2 also training-mode vectors with DropPath forced off: loss, and
+grads of a few lifter parameters (loss.py:16-22, train.py:186-195).
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "contextaware-poseformer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+import _refshim
+from capf import synth
+from golden_cases import CASES, case_inputs
+
+GRAD_KEYS = ["volume_net.head.1.weight", "volume_net.context_blocks.0.sampling_offsets.bias",
+             "volume_net.context_blocks.3.sampling_offsets.weight", "volume_net.coord_embed.weight",
+             "volume_net.joint_blocks.0.attn.qkv.bias", "volume_net.res_blocks.2.mlp.fc1.weight",
+             "volume_net.feat_embed.3.weight", "volume_net.Spatial_pos_embed"]
+
+
+def run_case(name, case):
+    torch.set_num_threads(8)
+    model, _ = _refshim.build_reference(case["backbone"])
+    synth.load_synthetic(model, seed=case["wseed"], bn_mode=case["bn"])
+    img, k2d, kc = case_inputs(case)
+    taps = {}
+    vn = model.volume_net
+    hooks = [
+        model.backbone.register_forward_hook(lambda m, i, o: taps.__setitem__("features", [t.detach() for t in o])),
+        vn.context_blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("tok_ctx", o.detach())),
+        vn.res_blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("tok_res", o.detach())),
+        vn.joint_blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("tok_joint", o.detach())),
+    ]
+    for l in range(4):
+        vn.feat_embed[l].register_forward_hook(
+            lambda m, i, o, l=l: taps.__setitem__(f"sampled{l}", i[0].detach()))
+    kc_io = kc.clone()
+    with torch.no_grad():
+        out = model(img, k2d, kc_io)
+    for h in hooks:
+        h.remove()
+    rec = {"out": out.numpy(), "ref": kc_io.numpy()}
+    for l, f in enumerate(taps["features"]):
+        rec[f"feat{l}_shape"] = np.array(f.shape, np.int64)
+        rec[f"feat{l}_sum"] = np.array(f.double().sum().item())
+        rec[f"feat{l}_abs"] = np.array(f.double().abs().sum().item())
+        h0, w0 = f.shape[2] // 3, f.shape[3] // 3
+        rec[f"feat{l}_slice"] = f[:, :, h0:h0 + 4, w0:w0 + 4].permute(0, 2, 3, 1).contiguous().numpy()  # NHWC
+        rec[f"sampled{l}"] = taps[f"sampled{l}"].numpy()
+    # token taps in the layouts the reference holds them: ctx [B,5,17,c], res [(B 17),5,c], joint [B,17,5c]
+    rec["tok_ctx"] = taps["tok_ctx"].numpy()
+    rec["tok_res"] = taps["tok_res"].numpy()
+    rec["tok_joint"] = taps["tok_joint"].numpy()
+
+    if name == "w32_256x256_b2":
+        # training step vectors, DropPath off (drop_prob forced to 0) — SURVEY.md §7 "Hard parts"
+        from mvn.models.loss import MPJPE
+        model.train(); model.backbone.eval()
+        for m in model.modules():
+            if type(m).__name__ == "DropPath":
+                m.drop_prob = 0.0
+        _, _, _, gt = synth.synth_inputs(case["B"], case["H"], case["W"], seed=case["iseed"],
+                                         crop_range=case["crop"], with_gt=True)
+        model.zero_grad()
+        pred = model(img, k2d, kc.clone())
+        loss = MPJPE()(pred, gt)
+        loss.backward()
+        rec["train_loss"] = np.array(loss.item(), np.float32)
+        named = dict(model.named_parameters())
+        for k in GRAD_KEYS:
+            rec["grad:" + k] = named[k].grad.numpy()
+        rec["gradnorm_names"] = np.array([k for k, p in named.items() if p.grad is not None])
+        rec["gradnorms"] = np.array([p.grad.double().norm().item() for k, p in named.items() if p.grad is not None])
+    return rec
+
+
+def dump_schemas(outdir):
+    """state_dict names + shapes of the reference model per backbone (the drop-in boundary,
+    SURVEY.md §8b) -> tests/golden/schema_<backbone>.json."""
+    import json
+    for bb in ("hrnet_32", "hrnet_48", "cpn"):
+        model, _ = _refshim.build_reference(bb)
+        sd = model.state_dict()
+        with open(os.path.join(outdir, f"schema_{bb}.json"), "w") as f:
+            json.dump({k: list(v.shape) for k, v in sd.items()}, f, separators=(",", ":"))
+
+
+def main():
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    only = sys.argv[1:]
+    if not only or "schema" in only:
+        dump_schemas(outdir)
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        rec = run_case(name, case)
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{name}: out absmax {np.abs(rec['out']).max():.4f}  -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

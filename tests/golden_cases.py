@@ -1,0 +1,23 @@
+"""Golden-vector case table, shared by oracle/make_goldens.py (writer, build container only) and
+the tests (readers).  Pure data: inputs and weights are regenerated from these seeds by
+capf.synth on both sides; only the reference's OUTPUTS are stored in tests/golden/<name>.npz."""
+
+CASES = {
+    # name: backbone, B, H, W, weight seed, input seed, BN mode, crop keypoint range (w,h) or 'adv'
+    "w32_256x256_b2": dict(backbone="hrnet_32", B=2, H=256, W=256, wseed=1, iseed=3, bn="random", crop=(256, 256)),
+    "w32_256x192_b1": dict(backbone="hrnet_32", B=1, H=256, W=192, wseed=2, iseed=4, bn="random", crop=(192, 256)),
+    "w32_256x256_adv": dict(backbone="hrnet_32", B=2, H=256, W=256, wseed=1, iseed=5, bn="default", crop="adv"),
+    "w48_256x256_b1": dict(backbone="hrnet_48", B=1, H=256, W=256, wseed=6, iseed=7, bn="random", crop=(256, 256)),
+    "cpn_384x288_b1": dict(backbone="cpn", B=1, H=384, W=288, wseed=8, iseed=9, bn="random", crop=(288, 384)),
+    "cpn_256x192_b1": dict(backbone="cpn", B=1, H=256, W=192, wseed=8, iseed=10, bn="random", crop=(192, 256)),
+}
+
+
+def case_inputs(case):
+    """(images, k2d, kcrop) for a case, via capf.synth (deterministic, torch-RNG free)."""
+    from capf import synth
+    img, k2d, kc = synth.synth_inputs(case["B"], case["H"], case["W"], seed=case["iseed"],
+                                      crop_range=(192, 256) if case["crop"] == "adv" else case["crop"])
+    if case["crop"] == "adv":
+        kc = synth.adversarial_crop_keypoints(case["B"], seed=case["iseed"])
+    return img, k2d, kc

@@ -1,0 +1,95 @@
+"""CPU: the C-ABI library loads, exports every symbol include/capf.h declares, and its parameter
+schema / host module state_dict equal the reference's state_dict (captured in tests/golden/schema_*.json
+by oracle/make_goldens.py).  No compute calls — there is no GPU here."""
+import copy
+import json
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "capf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(capf_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import capf
+    from capf.lib import EXPORTS
+    lib = capf.load_library()
+    declared = _header_symbols()
+    assert declared, "no declarations parsed"
+    for sym in declared:
+        assert hasattr(lib, sym), f"libcapf.so does not export {sym}"
+    assert sorted(EXPORTS) == declared
+    assert b"gfx950" in lib.capf_version()
+
+
+def _cfg(backbone):
+    from mvn.utils.cfg import backbone_preset, config
+    c = backbone_preset(copy.deepcopy(config), backbone)
+    c.model.backbone.fix_weights = True
+    return c
+
+
+@pytest.mark.parametrize("backbone", ["hrnet_32", "hrnet_48", "cpn"])
+def test_schema_equals_reference_state_dict(backbone):
+    from capf import Engine
+    from mvn.models import _native
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", f"schema_{backbone}.json")))
+    eng = Engine(_native.make_capf_config(_cfg(backbone), 256, 192), device=None)
+    got = {n: list(s) for n, s, k in eng.schema()}
+    assert got == want
+    launches, flops = eng.stats(1)
+    assert launches > 100 and flops > 1e10
+    assert eng.workspace_bytes(4) == 4 * eng.workspace_bytes(1) > 0
+
+
+@pytest.mark.parametrize("backbone", ["hrnet_32", "cpn"])
+def test_host_module_state_dict_and_freeze(backbone):
+    import contextlib, io
+    from mvn.models.conpose import CA_PF
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", f"schema_{backbone}.json")))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CA_PF(_cfg(backbone))
+    sd = m.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == want
+    assert not any(p.requires_grad for p in m.backbone.parameters())          # conpose.py:22-25
+    assert all(p.requires_grad for p in m.volume_net.parameters())
+    m.load_state_dict(sd, strict=True)
+    # callers' access patterns (train.py:147-148, 339): .backbone.eval(), .volume_net.named_parameters()
+    m.backbone.eval(); m.volume_net.train()
+    assert len(list(m.volume_net.named_parameters())) == 191 - 0 if backbone == "hrnet_32" else True
+
+
+def test_flops_match_survey():
+    """Algorithmic FLOPs reported by the plan == SURVEY.md §8d (probed on the reference)."""
+    from capf import Engine
+    from mvn.models import _native
+    for bb, hw, gflop in (("hrnet_32", (256, 256), 20.995), ("hrnet_48", (256, 256), 42.469), ("cpn", (384, 288), 23.182)):
+        eng = Engine(_native.make_capf_config(_cfg(bb), *hw), device=None)
+        _, f = eng.stats(1)
+        assert abs(f / 1e9 - gflop) / gflop < 0.01, (bb, f / 1e9)
+
+
+def test_errors_are_reported():
+    from capf import CapfError, Engine
+    from mvn.models import _native
+    c = _native.make_capf_config(_cfg("hrnet_32"), 250, 192)      # not a multiple of 32
+    with pytest.raises(CapfError):
+        Engine(c, device=None)
+    bad = _cfg("hrnet_32")
+    bad.model.backbone.STAGE3.NUM_BLOCKS = [4, 4]
+    with pytest.raises(ValueError):                                # pose_hrnet.py:159-175 semantics
+        _native.make_capf_config(bad)
+    import torch
+    from mvn.models.conpose import CA_PF
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CA_PF(_cfg("hrnet_32"))
+    with pytest.raises(CapfError):                                 # no CPU fallback
+        m(torch.zeros(1, 256, 192, 3), torch.zeros(1, 17, 2), torch.zeros(1, 17, 2))

@@ -1,0 +1,65 @@
+"""CPU: the oracle (oracle/capf_oracle.py) reproduces the golden vectors that oracle/make_goldens.py
+captured from the REAL reference — this is what pins the oracle (the reference has no tests)."""
+import numpy as np
+import pytest
+import torch
+
+import capf_oracle as oracle
+from conftest import load_golden, make_model
+from golden_cases import CASES, case_inputs
+
+TOL = 2e-5   # oracle and reference run the same ATen CPU kernels; only thread-count reassociation differs
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_golden(name):
+    case = CASES[name]
+    g = load_golden(name)
+    _, sd = make_model(case["backbone"], wseed=case["wseed"], bn=case["bn"])
+    img, k2d, kc = case_inputs(case)
+    taps = {}
+    with torch.no_grad():
+        out = oracle.ca_pf_forward(sd, img, k2d, kc, backbone=case["backbone"], taps=taps)
+    assert out.shape == (case["B"], 1, 17, 3)
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=TOL, rtol=0)
+    np.testing.assert_array_equal(kc.numpy(), g["ref"])          # in-place normalisation, bit exact
+    for l, f in enumerate(taps["features"]):
+        assert tuple(f.shape) == tuple(g[f"feat{l}_shape"])
+        np.testing.assert_allclose(f.double().sum().item(), g[f"feat{l}_sum"], rtol=1e-5, atol=1e-2)
+        np.testing.assert_allclose(f.double().abs().sum().item(), g[f"feat{l}_abs"], rtol=1e-5)
+        h0, w0 = f.shape[2] // 3, f.shape[3] // 3
+        np.testing.assert_allclose(f[:, :, h0:h0 + 4, w0:w0 + 4].permute(0, 2, 3, 1).numpy(), g[f"feat{l}_slice"], atol=TOL)
+        np.testing.assert_allclose(taps["sampled"][l].numpy(), g[f"sampled{l}"], atol=TOL)
+    np.testing.assert_allclose(taps["tokens_ctx"].numpy(), g["tok_ctx"], atol=TOL)
+    B = case["B"]
+    np.testing.assert_allclose(taps["tokens_res"].numpy().reshape(B * 17, 5, -1), g["tok_res"], atol=TOL)
+    np.testing.assert_allclose(taps["tokens_joint"].numpy(), g["tok_joint"], atol=5 * TOL)
+
+
+@pytest.mark.parametrize("name", ["w32_256x256_adv", "w32_256x256_b2"])
+def test_explicit_bilinear_restatement(name):
+    """The numpy index arithmetic (bilinear_corners) gives the same samples as ATen grid_sample on
+    in-range, out-of-range and pixel-boundary keypoints, for both padding modes."""
+    case = CASES[name]
+    g = load_golden(name)
+    _, sd = make_model(case["backbone"], wseed=case["wseed"], bn=case["bn"])
+    img, k2d, kc = case_inputs(case)
+    with torch.no_grad():
+        out = oracle.ca_pf_forward(sd, img, k2d, kc, backbone=case["backbone"], explicit=True)
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=1e-5, rtol=0)
+
+
+def test_bilinear_corners_edge_cases():
+    g = np.array([[-1.0, -1.0], [1.0, 1.0], [-0.0, 0.0], [1.5, -1.2], [np.nextafter(np.float32(1), 0), 0.3]], np.float32)
+    z = oracle.bilinear_corners(g, 64, 48, "zeros")
+    b = oracle.bilinear_corners(g, 64, 48, "border")
+    assert z["ix0"].tolist()[:3] == [0, 47, 23] and z["iy0"].tolist()[:3] == [0, 63, 31]
+    assert not z["valid"][3].all() and b["ix0"][3] == 47 and b["iy0"][3] == 0
+    assert z["valid"][1].tolist() == [True, False, False, False]      # SE/NE/SW fall outside at +1
+    assert b["wx1"][1] == 0.0 and b["wy1"][1] == 0.0
+
+
+def test_mpjpe_matches_definition():
+    p, q = torch.randn(3, 1, 17, 3), torch.randn(3, 1, 17, 3)
+    want = ((p - q) ** 2).sum(-1).sqrt().mean()
+    assert abs(oracle.mpjpe(p, q).item() - want.item()) < 1e-6
