@@ -12,6 +12,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
     "capf_set_param", "capf_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_tensor", "capf_forward_stats",
+    "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
 ]
 
 
@@ -36,6 +37,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64/libhsa-runtime64: it must be loaded FIRST so that libcapf.so
+    # binds to the same HIP runtime (two runtimes in one process do not share devices or streams).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CapfError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                         "(or make -C contextaware-poseformer_amd/csrc); there is no fallback path")
@@ -61,6 +65,14 @@ def load_library():
     lib.capf_set_debug.argtypes = [H, c_int]
     lib.capf_tensor.argtypes = [H, c_char_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int)]
     lib.capf_forward_stats.argtypes = [H, c_int, POINTER(c_int64), POINTER(c_double)]
+    lib.capf_num_ops.argtypes = [H]
+    lib.capf_op_info.argtypes = [H, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double)]
+    lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                         POINTER(c_float), c_int]
+    P = c_void_p
+    lib.capf_op_pack_conv.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
+    lib.capf_op_conv.argtypes = [P, P, P, P, P, P] + [c_int] * 8
+    lib.capf_op_linear.argtypes = [P, P, P, P, P, P] + [c_int] * 4
     _lib = lib
     return lib
 
@@ -178,7 +190,80 @@ class Engine:
             flat = flat.view(torch.int32)
         return flat.view(*shp).clone()
 
+    def op_table(self, batch):
+        """[(op name, kernel name, algorithmic flops at `batch`)] in launch order."""
+        name, kern, fl = c_char_p(), c_char_p(), c_double()
+        out = []
+        for i in range(self.lib.capf_num_ops(self.h)):
+            self._check(self.lib.capf_op_info(self.h, i, batch, byref(name), byref(kern), byref(fl)), "op_info")
+            out.append((name.value.decode(), kern.value.decode(), fl.value))
+        return out
+
+    def forward_profile(self, images, k2d, kcrop, out, stream):
+        """One forward with a HIP event pair around every launch (on `stream`); returns ms per op.
+        Synchronises the stream — measurement aid for bench.py, not the product path."""
+        B = images.shape[0]
+        self.ensure_workspace(B)
+        n = self.lib.capf_num_ops(self.h)
+        ms = (c_float * n)()
+        self._check(self.lib.capf_forward_profile(self.h, c_void_p(stream), c_void_p(images.data_ptr()),
+                                                  c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
+                                                  c_void_p(out.data_ptr()), ms, n), "forward_profile")
+        return list(ms)
+
     def stats(self, batch):
         n, f = c_int64(), c_double()
         self._check(self.lib.capf_forward_stats(self.h, batch, byref(n), byref(f)), "forward_stats")
         return n.value, f.value
+
+
+# ---- stateless operators (op-level tests / micro-benchmarks) ---------------------------------------
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream(t):
+    import torch
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def pack_conv(w, bn=None, eps=1e-5):
+    """w [Cout,Cin,k,k] cuda fp32; bn = (gamma, beta, mean, var) or None -> (w_packed [Cout,Kpad], bias [Cout])."""
+    import torch
+    lib = load_library()
+    co, ci, ks, _ = w.shape
+    kpad = (ks * ks * ci + 31) // 32 * 32
+    wp = torch.empty(co, kpad, device=w.device)
+    bias = torch.empty(co, device=w.device)
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    rc = lib.capf_op_pack_conv(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci, ks)
+    if rc:
+        raise CapfError(f"capf_op_pack_conv failed ({rc})")
+    return wp, bias
+
+
+def conv_nhwc(x, wp, bias, ks, stride=1, act=0, residual=None):
+    """x [B,H,W,Cin] cuda fp32 NHWC -> [B,Ho,Wo,Cout]."""
+    import torch
+    lib = load_library()
+    B, H, W, ci = x.shape
+    co = wp.shape[0]
+    pad = ks // 2
+    ho, wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    y = torch.empty(B, ho, wo, co, device=x.device)
+    rc = lib.capf_op_conv(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, ks, stride, act)
+    if rc:
+        raise CapfError(f"capf_op_conv failed ({rc})")
+    return y
+
+
+def linear(x, w, bias=None, act=0, residual=None):
+    import torch
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device)
+    rc = lib.capf_op_linear(_stream(x), _p(x), _p(w), _p(bias), _p(residual), _p(y), M, N, K, act)
+    if rc:
+        raise CapfError(f"capf_op_linear failed ({rc})")
+    return y

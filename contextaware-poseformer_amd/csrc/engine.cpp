@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "engine.h"
 
 namespace capf {
@@ -47,35 +49,41 @@ int Engine::repack(hipStream_t s) {
     return CAPF_OK;
 }
 
-int Engine::run(hipStream_t s, int batch, int first_op, int last_op) {
+GemmArgs Engine::gemm_args(const Op& op, int batch) const {
+    auto ptr = [&](int buf) -> float* { return (buf >= 0 && ws) ? bptr(buf, batch) : nullptr; };
+    const Pack& pk = packs[op.pack];
+    GemmArgs a{};
+    a.A = op.in[0] == -2 ? images : ptr(op.in[0]);
+    if (pk.direct) {
+        a.Wp = params[pk.w[0]].ptr;
+        a.bias = params[pk.b[0]].ptr;
+    } else {
+        a.Wp = pack_arena + pk.w_off;
+        a.bias = pack_arena + pk.b_off;
+    }
+    a.res = op.res_param >= 0 ? params[op.res_param].ptr : ptr(op.aux);
+    a.out = ptr(op.out);
+    a.M = (int)(op.rows_per_frame * batch);
+    a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
+    a.conv = op.conv;
+    a.Cin = op.Cin; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo;
+    a.ks = op.ks; a.stride = op.stride; a.pad = op.pad;
+    a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
+    a.act = op.act;
+    return a;
+}
+
+int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev) {
     auto ptr = [&](int buf) -> float* {
         if (buf >= 0) return bptr(buf, batch);
         return nullptr;
     };
     for (int oi = first_op; oi < last_op; ++oi) {
         const Op& op = ops[oi];
+        if (ev) HIP_TRY(hipEventRecord(ev[oi], s));
         switch (op.kind) {
             case OP_GEMM: {
-                const Pack& pk = packs[op.pack];
-                GemmArgs a{};
-                a.A = op.in[0] == -2 ? images : ptr(op.in[0]);
-                if (pk.direct) {
-                    a.Wp = params[pk.w[0]].ptr;
-                    a.bias = params[pk.b[0]].ptr;
-                } else {
-                    a.Wp = pack_arena + pk.w_off;
-                    a.bias = pack_arena + pk.b_off;
-                }
-                a.res = op.res_param >= 0 ? params[op.res_param].ptr : ptr(op.aux);
-                a.out = ptr(op.out);
-                a.M = (int)(op.rows_per_frame * batch);
-                a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
-                a.conv = op.conv;
-                a.Cin = op.Cin; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo;
-                a.ks = op.ks; a.stride = op.stride; a.pad = op.pad;
-                a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
-                a.act = op.act;
-                HIP_TRY(launch_gemm_f32(a, s));
+                HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
                 break;
             }
             case OP_FUSE: {
@@ -132,6 +140,7 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op) {
                 break;
         }
     }
+    if (ev) HIP_TRY(hipEventRecord(ev[last_op], s));
     return CAPF_OK;
 }
 
@@ -316,6 +325,73 @@ int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, in
     if (ndim) *ndim = t.ndim;
     if (dev_ptr) *dev_ptr = (e.ws && e.last_batch > 0) ? e.bptr(t.buf, e.last_batch) : nullptr;
     return t.is_int ? 1 : 0;
+}
+
+int capf_op_pack_conv(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
+                      const float* var, float eps, float* wp, float* bias, int Cout, int Cin, int ks) {
+    const int Kpad = (ks * ks * Cin + 31) / 32 * 32;
+    return capf::launch_pack_conv(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, ks, Kpad,
+                                  static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv(void* stream, const float* x, const float* wp, const float* bias, const float* residual, float* y,
+                 int B, int H, int W, int Cin, int Cout, int ks, int stride, int act) {
+    capf::GemmArgs a{};
+    const int pad = ks / 2;
+    a.A = x; a.Wp = wp; a.bias = bias; a.res = residual; a.out = y;
+    a.Ho = (H + 2 * pad - ks) / stride + 1;
+    a.Wo = (W + 2 * pad - ks) / stride + 1;
+    a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = ks * ks * Cin; a.Kpad = (a.K + 31) / 32 * 32;
+    a.conv = 1; a.Cin = Cin; a.H = H; a.W = W; a.ks = ks; a.stride = stride; a.pad = pad;
+    a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
+    a.act = act;
+    return capf::launch_gemm_f32(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual, float* y,
+                   int M, int N, int K, int act) {
+    if (K % 32 != 0) return CAPF_ERR_UNSUPPORTED;
+    capf::GemmArgs a{};
+    a.A = x; a.Wp = w; a.bias = bias; a.res = residual; a.out = y;
+    a.M = M; a.N = N; a.K = K; a.Kpad = K;
+    a.amap = capf::row_ld(K); a.omap = capf::row_ld(N); a.rmap = capf::row_ld(N);
+    a.act = act;
+    return capf::launch_gemm_f32(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_num_ops(const capf_handle* h) { return h ? (int)h->e.ops.size() : CAPF_ERR_INVALID; }
+
+int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel, double* flops) {
+    if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0) return CAPF_ERR_INVALID;
+    const capf::Op& op = h->e.ops[index];
+    static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
+                               "layernorm", "deform_sample", "attention", "head"};
+    if (name) *name = op.name.c_str();
+    if (kernel) *kernel = op.kind == capf::OP_GEMM ? capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)) : kn[op.kind];
+    if (flops) *flops = op.flops_per_frame * batch;
+    return CAPF_OK;
+}
+
+int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
+                         int batch, float* out, float* op_ms, int n_ops) {
+    if (!h || !images_nhwc || !k2d || !kcrop_inout || !out || !op_ms) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    const int n = (int)e.ops.size();
+    if (n_ops < n) return CAPF_ERR_INVALID;
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
+    e.last_batch = batch;
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& x : ev)
+        if (hipEventCreate(&x) != hipSuccess) return CAPF_ERR_HIP;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = e.run(s, batch, 0, n, ev.data());
+    if (rc == CAPF_OK && hipStreamSynchronize(s) != hipSuccess) rc = CAPF_ERR_HIP;
+    for (int i = 0; i < n && rc == CAPF_OK; ++i)
+        if (hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = CAPF_ERR_HIP;
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    return rc;
 }
 
 int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops) {

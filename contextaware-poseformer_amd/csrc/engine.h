@@ -131,7 +131,8 @@ struct Engine {
     // ---- execution (engine.cpp)
     float* bptr(int buf, int batch) const { return ws + bufs[buf].offset * (size_t)batch; }
     int repack(hipStream_t s);
-    int run(hipStream_t s, int batch, int first_op, int last_op);
+    int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr);
+    GemmArgs gemm_args(const Op& op, int batch) const;
 };
 
 }  // namespace capf

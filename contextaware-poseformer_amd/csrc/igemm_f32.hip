@@ -239,21 +239,39 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 // Tile selection: N decides the column tile; M decides how many rows a block takes so that the grid
 // still covers the 256 CUs a few times over.
+enum TileCfg { T256x32, T128x32, T128x64, T64x64, T128x128 };
+
+static TileCfg pick_tile(const GemmArgs& a) {
+    if (a.N <= 32) return ((long)a.M >= 256L * 1024) ? T256x32 : T128x32;
+    if (a.N <= 64) return ((long)a.M >= 128L * 512) ? T128x64 : T64x64;
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (tiles128 >= 512) return T128x128;
+    if ((long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 256) return T128x64;
+    return T64x64;
+}
+
+const char* gemm_f32_kernel_name(const GemmArgs& a) {
+    static const char* names[5][3] = {
+        {"igemm_f32<256,32,rows>", "igemm_f32<256,32,conv>", "igemm_f32<256,32,conv_smallc>"},
+        {"igemm_f32<128,32,rows>", "igemm_f32<128,32,conv>", "igemm_f32<128,32,conv_smallc>"},
+        {"igemm_f32<128,64,rows>", "igemm_f32<128,64,conv>", "igemm_f32<128,64,conv_smallc>"},
+        {"igemm_f32<64,64,rows>", "igemm_f32<64,64,conv>", "igemm_f32<64,64,conv_smallc>"},
+        {"igemm_f32<128,128,rows>", "igemm_f32<128,128,conv>", "igemm_f32<128,128,conv_smallc>"}};
+    const int mode = !a.conv ? 0 : (a.Cin % 4 == 0 ? 1 : 2);
+    return names[pick_tile(a)][mode];
+}
+
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (a.Kpad % BK != 0) return hipErrorInvalidValue;
-    if (a.N <= 32) {
-        if ((long)a.M >= 256L * 1024) return launch_cfg<256, 32, 64, 32>(a, s);
-        return launch_cfg<128, 32, 32, 32>(a, s);
+    switch (pick_tile(a)) {
+        case T256x32: return launch_cfg<256, 32, 64, 32>(a, s);
+        case T128x32: return launch_cfg<128, 32, 32, 32>(a, s);
+        case T128x64: return launch_cfg<128, 64, 64, 32>(a, s);
+        case T64x64: return launch_cfg<64, 64, 32, 32>(a, s);
+        case T128x128: return launch_cfg<128, 128, 64, 64>(a, s);
     }
-    if (a.N <= 64) {
-        if ((long)a.M >= 128L * 512) return launch_cfg<128, 64, 64, 32>(a, s);
-        return launch_cfg<64, 64, 32, 32>(a, s);
-    }
-    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tiles128 >= 512) return launch_cfg<128, 128, 64, 64>(a, s);
-    if ((long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 256) return launch_cfg<128, 64, 64, 32>(a, s);
-    return launch_cfg<64, 64, 32, 32>(a, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace capf

@@ -31,6 +31,7 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
+const char* gemm_f32_kernel_name(const GemmArgs& a);   // which template instantiation launch_gemm_f32 picks
 
 // conv weight fold + pack:  Wp[n][(kh*ks+kw)*Cin+ci] = w[n][ci][kh][kw] * gamma[n]/sqrt(var[n]+eps)
 //                            bias[n] = beta[n] - mean[n]*gamma[n]/sqrt(var[n]+eps)

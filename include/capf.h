@@ -137,6 +137,34 @@ int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, in
  * `batch`; used by bench.py for the roofline line. */
 int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops);
 
+/* ---- stateless operator entry points (op-level parity tests and micro-benchmarks) ---------------
+ * capf_op_pack_conv : fold eval-mode BatchNorm into a conv weight and re-lay it out K-major:
+ *     w_packed[Cout][Kpad] (Kpad = ks*ks*Cin rounded up to 32), bias[Cout]; gamma == NULL -> no BN.
+ * capf_op_conv      : y = act(conv2d(x; w_packed) + bias (+ residual)), NHWC, padding = ks/2.
+ *     == nn.Conv2d(bias=False) + nn.BatchNorm2d(eval) (+ residual add) (+ ReLU) of
+ *     pose_hrnet.py:66-136 / networks/resnet.py:58-93 as ONE implicit-GEMM launch.
+ * capf_op_linear    : y[M,N] = act(x[M,K] @ w[N,K]^T + bias (+ residual)); act 0 none, 1 ReLU, 2 GELU(erf)
+ *     == nn.Linear (+GELU) of pose_dformer.py:15-31; K % 32 == 0.                                      */
+int capf_op_pack_conv(void* stream, const float* w_oihw, const float* gamma, const float* beta,
+                      const float* mean, const float* var, float eps, float* w_packed, float* bias,
+                      int Cout, int Cin, int ks);
+int capf_op_conv(void* stream, const float* x_nhwc, const float* w_packed, const float* bias,
+                 const float* residual, float* y_nhwc, int B, int H, int W, int Cin, int Cout, int ks,
+                 int stride, int act);
+int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual,
+                   float* y, int M, int N, int K, int act);
+
+/* ---- measurement aids (bench.py roofline line; no reference counterpart) -------------------------
+ * capf_op_info: op `index` in launch order: its plan name, the kernel (template instantiation) it
+ *   launches at `batch`, and its algorithmic FLOPs at `batch`.
+ * capf_forward_profile: capf_forward with a hipEvent pair recorded on `stream` around every launch;
+ *   synchronises the stream and writes the elapsed milliseconds per op into op_ms[0..n_ops).        */
+int capf_num_ops(const capf_handle* h);
+int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel,
+                 double* flops);
+int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
+                         float* kcrop_inout, int batch, float* out, float* op_ms, int n_ops);
+
 #ifdef __cplusplus
 }
 #endif
