@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--lanes", type=int, default=1, help="1: independent backbone branches on side streams (default); 0: one stream")
     return ap.parse_args()
 
 
@@ -116,6 +117,7 @@ def main():
     img, k2d, kc0 = img.to(dev), k2d.to(dev), kc.to(dev)
     kc_work = kc0.clone()
     stream = torch.cuda.current_stream(dev)
+    model.engine_for(img).set_lanes(a.lanes)
 
     def step():
         kc_work.copy_(kc0)             # the forward normalises its 3rd argument in place (conpose.py:34-35)

@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
     "capf_set_param", "capf_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
-    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_tensor", "capf_forward_stats",
+    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
 ]
 
@@ -63,6 +63,7 @@ def load_library():
     lib.capf_backbone_forward.argtypes = [H, c_void_p, c_void_p, c_int]
     lib.capf_lifter_forward.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
     lib.capf_set_debug.argtypes = [H, c_int]
+    lib.capf_set_lanes.argtypes = [H, c_int]
     lib.capf_tensor.argtypes = [H, c_char_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int)]
     lib.capf_forward_stats.argtypes = [H, c_int, POINTER(c_int64), POINTER(c_double)]
     lib.capf_num_ops.argtypes = [H]
@@ -171,6 +172,9 @@ class Engine:
         self._check(self.lib.capf_lifter_forward(self.h, c_void_p(stream), c_void_p(k2d.data_ptr()),
                                                  c_void_p(kcrop.data_ptr()), B, c_void_p(out.data_ptr())),
                     "lifter_forward")
+
+    def set_lanes(self, on):
+        self._check(self.lib.capf_set_lanes(self.h, int(on)), "set_lanes")
 
     def set_debug(self, on):
         self._check(self.lib.capf_set_debug(self.h, int(on)), "set_debug")

@@ -78,10 +78,27 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
         if (buf >= 0) return bptr(buf, batch);
         return nullptr;
     };
+    hipStream_t main_stream = s;
+    const bool par = lanes && !ev && side[0];        // profiling runs everything in order on one stream
     for (int oi = first_op; oi < last_op; ++oi) {
         const Op& op = ops[oi];
+        s = (par && op.lane > 0) ? side[op.lane - 1] : main_stream;
         if (ev) HIP_TRY(hipEventRecord(ev[oi], s));
         switch (op.kind) {
+            case OP_FORK:
+                if (par) {
+                    HIP_TRY(hipEventRecord(events[op.i1], main_stream));
+                    for (int l = 1; l < op.i0; ++l) HIP_TRY(hipStreamWaitEvent(side[l - 1], events[op.i1], 0));
+                }
+                break;
+            case OP_JOIN:
+                if (par) {
+                    for (int l = 1; l < op.i0; ++l) {
+                        HIP_TRY(hipEventRecord(events[op.i1 + l], side[l - 1]));
+                        HIP_TRY(hipStreamWaitEvent(main_stream, events[op.i1 + l], 0));
+                    }
+                }
+                break;
             case OP_GEMM: {
                 HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
                 break;
@@ -140,7 +157,7 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 break;
         }
     }
-    if (ev) HIP_TRY(hipEventRecord(ev[last_op], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[last_op], main_stream));
     return CAPF_OK;
 }
 
@@ -186,6 +203,10 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
     if (device >= 0) {
         hipError_t r = hipSetDevice(device);
         if (r == hipSuccess && e.pack_elems) r = hipMalloc(reinterpret_cast<void**>(&e.pack_arena), e.pack_elems * sizeof(float));
+        for (int i = 0; i < 3 && r == hipSuccess; ++i) r = hipStreamCreateWithFlags(&e.side[i], hipStreamNonBlocking);
+        e.events.resize(e.n_events);
+        for (auto& x : e.events)
+            if (r == hipSuccess) r = hipEventCreateWithFlags(&x, hipEventDisableTiming);
         if (r != hipSuccess) {
             g_create_error = std::string("hip: ") + hipGetErrorString(r);
             delete h;
@@ -199,6 +220,10 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
 void capf_destroy(capf_handle* h) {
     if (!h) return;
     if (h->e.pack_arena) (void)hipFree(h->e.pack_arena);
+    for (auto& x : h->e.events)
+        if (x) (void)hipEventDestroy(x);
+    for (auto& st : h->e.side)
+        if (st) (void)hipStreamDestroy(st);
     delete h;
 }
 
@@ -252,6 +277,12 @@ int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes) {
     if (!h) return CAPF_ERR_INVALID;
     h->e.ws = static_cast<float*>(dev_ptr);
     h->e.ws_bytes = bytes;
+    return CAPF_OK;
+}
+
+int capf_set_lanes(capf_handle* h, int on) {
+    if (!h) return CAPF_ERR_INVALID;
+    h->e.lanes = on != 0;
     return CAPF_OK;
 }
 
@@ -365,7 +396,7 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0) return CAPF_ERR_INVALID;
     const capf::Op& op = h->e.ops[index];
     static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
-                               "layernorm", "deform_sample", "attention", "head"};
+                               "layernorm", "deform_sample", "attention", "head", "", ""};
     if (name) *name = op.name.c_str();
     if (kernel) *kernel = op.kind == capf::OP_GEMM ? capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)) : kn[op.kind];
     if (flops) *flops = op.flops_per_frame * batch;
@@ -400,6 +431,7 @@ int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, doubl
     double f = 0.0;
     for (const capf::Op& op : h->e.ops) {
         if (op.kind == capf::OP_FUSE && op.i0 == 1) continue;
+        if (op.kind == capf::OP_FORK || op.kind == capf::OP_JOIN) continue;
         ++n;
         f += op.flops_per_frame * batch;
     }

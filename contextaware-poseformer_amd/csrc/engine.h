@@ -54,7 +54,7 @@ struct Pack {
 
 enum OpKind {
     OP_GEMM = 0, OP_FUSE, OP_MAXPOOL, OP_RESIZE, OP_PREP_EMBED, OP_SAMPLE_REF, OP_LAYERNORM, OP_DEFORM,
-    OP_ATTENTION, OP_HEAD
+    OP_ATTENTION, OP_HEAD, OP_FORK, OP_JOIN
 };
 
 struct Op {
@@ -81,6 +81,8 @@ struct Op {
     int lvlH[4] = {0, 0, 0, 0}, lvlW[4] = {0, 0, 0, 0}, lvlC[4] = {0, 0, 0, 0};
     int outs[4] = {-1, -1, -1, -1};
     double flops_per_frame = 0.0;
+    int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
+    int region = -1;              // index of the enclosing fork/join region, -1 outside
 };
 
 struct NamedTensor {
@@ -101,6 +103,8 @@ struct Engine {
     std::vector<Pack> packs;
     std::vector<Op> ops;
     int n_backbone_ops = 0;
+    int cur_lane = 0, cur_region = -1, n_regions = 0, n_events = 0;
+    std::vector<std::pair<int, int>> regions;   // [fork op, join op]
     std::map<std::string, NamedTensor> named;
     size_t ws_elems_per_frame = 0;
     size_t pack_elems = 0;
@@ -110,6 +114,9 @@ struct Engine {
     size_t ws_bytes = 0;
     bool packed = false;
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
+    bool lanes = true;             // run fork/join regions on side streams (capf_set_lanes)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> events;
     int last_batch = 0;
     const float* images = nullptr;
     const float* k2d = nullptr;
@@ -127,6 +134,10 @@ struct Engine {
     bool build();
     void assign_offsets();
     void use(int buf);   // mark buffer as read by the op being appended
+    void push(Op op);    // append an op, tagging it with the current lane / region
+    void fork(int n);    // open a region of n independent lanes (independent branches run on side streams)
+    void set_lane(int l) { cur_lane = l; }
+    void join();
 
     // ---- execution (engine.cpp)
     float* bptr(int buf, int batch) const { return ws + bufs[buf].offset * (size_t)batch; }

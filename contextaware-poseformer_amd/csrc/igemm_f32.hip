@@ -8,16 +8,27 @@
 //
 // Design (MI355X-first, not a translation of a warp-32 tiling):
 //   * activations are NHWC, weights are pre-packed [N][Kpad] with k = (kh, kw, ci): both MFMA operands
-//     are "row-major with K contiguous", so both are staged with 16-byte global loads / ds_write_b128
-//     and read back with ds_read_b128.  One b128 read feeds FOUR 32x32x2 MFMAs: lanes 0-31 hold
+//     are "row-major with K contiguous".  One ds_read_b128 feeds FOUR 32x32x2 MFMAs: lanes 0-31 hold
 //     k = kk+j, lanes 32-63 hold k = kk+4+j (the K order inside an MFMA is free as long as A and B agree).
-//   * LDS row pitch 36 floats (= 4*odd): ds_read_b128 / ds_write_b128 are conflict-free without a swizzle.
-//   * 256 threads = 4 wave64, one per SIMD; register-staged software pipeline (global loads of chunk
-//     c+1 are in flight while chunk c is multiplied), one LDS buffer -> several blocks per CU.
-//   * blockIdx is remapped so that consecutive tiles (which share halo rows / the same weights) land
-//     on the same XCD and hit its private L2.
+//   * tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  The LDS
+//     image of such a load is lane-linear (8 rows x 128 B per wave instruction), so the bank-conflict
+//     fix is an XOR swizzle applied to the SOURCE k-quad and to the ds_read_b128 address.
+//   * every tap's validity (zero padding, ragged M) is one bit of a per-row mask computed ONCE before
+//     the K loop; a staged element's address is row_offset + tap_offset or a 16-byte zero page: the K
+//     loop has no branch and ~10 VALU instructions per staged KiB.
+//   * S-stage LDS ring, counted s_waitcnt vmcnt, at most ONE raw s_barrier per 32-deep K chunk; the DMA
+//     instructions of chunk c+S-1 are issued in the 64-cycle shadows of the MFMAs of chunk c.
+//   * two block shapes: 4 wave64 sharing A/B tiles (small M, wide N: fewer L2->LDS bytes per FLOP) and
+//     single-wave blocks with a private ring and NO barrier at all (huge M, N <= 64: the 32- and
+//     64-channel high-resolution branches of HRNet) — waves then drift freely and keep the MFMA pipe
+//     fed instead of convoying through per-chunk barriers.
+//   * blockIdx is remapped so that consecutive tiles (which share halo rows / the same weights) land on
+//     the same XCD and hit its private L2.
 //   * f32 MFMA is an exact fmaf chain (1/16 of the bf16 rate): results match an fp32 reference to
 //     accumulation-order roundoff, which is what the 1e-3 parity bar of BASELINE.json needs.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace capf {
@@ -25,10 +36,9 @@ namespace capf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int BK = 32;      // K chunk (floats)
-static constexpr int PITCH = 36;   // LDS row pitch (floats): 16-byte aligned and 4*odd
+static constexpr int BK = 32;      // K chunk (floats) = 128 B per tile row
 
-enum { AMODE_ROWS = 0, AMODE_CONV = 1, AMODE_CONV_SMALLC = 2 };
+enum { AMODE_ROWS = 0, AMODE_CONV = 1 };
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -40,23 +50,45 @@ __device__ __forceinline__ long rowmap(const RowMap& r, int m) {
     return (long)q * r.S1 + (long)(m - q * r.G) * r.S2 + r.off;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs p) {
+// n / d for n < 2^31 with a host-computed (mul, shift): q = (umulhi(n, mul) + n) >> shift
+__device__ __forceinline__ int fast_div(int n, FastDiv d) {
+    return (int)((__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
+}
+
+__device__ __attribute__((aligned(16))) float capf_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NW waves per block (1 or 4), block tile BM x BN, wave tile WM x WN, S LDS stages.
+// PLAIN: out / res rows are addressed with a plain leading dimension (every conv, most linears);
+// otherwise the (G, S1, S2) row maps of the lifter's strided token views are evaluated per row.
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN>
+__global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
+    constexpr int NT = 64 * NW;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;     // float4 rows staged per thread
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int RPR = NT / 8;                           // tile rows covered by one DMA round of the block
+    constexpr int RA = BM / RPR, RB = BN / RPR;           // DMA instructions per thread per chunk
+    constexpr int NLOAD = RA + RB;
+    constexpr int STAGE = (BM + BN) * BK;                 // floats per stage
+    constexpr int KEYSH = (NW == 4) ? 1 : 0;              // swizzle key = (row >> KEYSH) & 7 (see below)
+    static_assert((BM / WM) * (BN / WN) == NW, "wave grid");
+    static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows per DMA round");
 
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PITCH];
-    float* As = lds;
-    float* Bs = lds + BM * PITCH;
+    __shared__ __attribute__((aligned(16))) float lds[S * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- XCD-aware tile order: physical block b runs on XCD b % 8; give each XCD a contiguous
-    //      range of logical tiles (bijective for any grid size).
+    // XCD-aware tile order: physical block b runs on XCD b % 8; give each XCD a contiguous range of
+    // logical tiles (bijective for any grid size).
     const int nblk = gridDim.x;
     int bid;
     {
@@ -67,94 +99,91 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs p) {
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread staging assignment: row = tid/8 + 32*i, k-quad = tid%8
+    // Staging assignment: DMA round i, thread tid -> tile row i*RPR + tid/8, physical 16-byte quad tid%8.
+    // The quad holds logical k-quad (tid%8) ^ key(row); key must not depend on i so that a thread walks
+    // ONE k sequence: with 32 rows per round key = (row>>1)&7 (conflict-free ds_read_b128), with 8 rows
+    // per round key = row&7 (2-way conflict: 8 instead of 4 LDS cycles per read, irrelevant next to
+    // 4 x 64-cycle MFMAs per read).
     const int srow = tid >> 3;
-    const int kq = (tid & 7) * 4;
+    const int kq = (((tid & 7) ^ ((srow >> KEYSH) & 7))) * 4;
 
-    long a_base[RA];
-    int a_h0[RA], a_w0[RA];
+    const float* zero = capf_zero_page;
+    const int nchunks = p.Kpad / BK;
+    long a_off[RA];                    // element offset of (row, tap 0, channel 0); rows mode: row base
+    unsigned long long a_mask[RA];     // bit t set <=> tap t of this row reads real data
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + srow + 32 * i;
-        if (AMODE == AMODE_ROWS) {
-            a_base[i] = (m < p.M) ? rowmap(p.amap, m) : -1;
-            a_h0[i] = a_w0[i] = 0;
-        } else {
-            if (m < p.M) {
-                const int hw = p.Ho * p.Wo;
-                const int b = m / hw, rem = m - b * hw;
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                a_base[i] = (long)b * p.H * p.W * p.Cin;
-                a_h0[i] = ho * p.stride - p.pad;
-                a_w0[i] = wo * p.stride - p.pad;
+        const int m = m0 + srow + RPR * i;
+        a_off[i] = 0;
+        a_mask[i] = 0ull;
+        if (m < p.M) {
+            if (AMODE == AMODE_ROWS) {
+                a_off[i] = rowmap(p.amap, m);
+                a_mask[i] = 1ull;
             } else {
-                a_base[i] = 0;
-                a_h0[i] = -(1 << 20);
-                a_w0[i] = 0;
+                const int b = fast_div(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
+                const int ho = fast_div(rem, p.fd_wo), wo = rem - ho * p.Wo;
+                const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+                a_off[i] = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+                // valid taps: kw in [max(0,-w0), min(ks, W-w0)), kh likewise; mask = wbits * spread(hbits)
+                // (bit kh*ks+kw; no carries because wbits < 2^ks and spread has its bits ks apart)
+                const int kw_lo = max(0, -w0), kw_hi = min(p.ks, p.W - w0);
+                const int kh_lo = max(0, -h0), kh_hi = min(p.ks, p.H - h0);
+                unsigned long long mk = 0ull;
+                if (kw_hi > kw_lo && kh_hi > kh_lo) {
+                    const unsigned long long wbits = ((1ull << kw_hi) - 1) & ~((1ull << kw_lo) - 1);
+                    const unsigned long long below_hi = kh_hi * p.ks >= 64 ? ~0ull : ((1ull << (kh_hi * p.ks)) - 1);
+                    const unsigned long long below_lo = (1ull << (kh_lo * p.ks)) - 1;
+                    mk = (wbits * p.spread) & below_hi & ~below_lo;      // rows [kh_lo, kh_hi) only
+                }
+                a_mask[i] = mk;
             }
         }
     }
-    const float* b_ptr[RB];
+    const float* b_src[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = n0 + srow + 32 * i;
-        b_ptr[i] = (n < p.N) ? p.Wp + (long)n * p.Kpad + kq : nullptr;
+        const int n = n0 + srow + RPR * i;
+        b_src[i] = (n < p.N) ? p.Wp + (long)n * p.Kpad + kq : nullptr;
     }
 
-    // running (tap, ci) of this thread's k-quad for the vectorised conv loader
-    int tap = 0, ci = kq;
+    // running decomposition of this thread's k = c*32 + kq into (tap, ci)
+    int tap = 0, ci = kq, kh = 0, kw = 0;
     if (AMODE == AMODE_CONV) {
         tap = kq / p.Cin;
         ci = kq - tap * p.Cin;
+        kh = tap / p.ks;
+        kw = tap - kh * p.ks;
     }
-    const int ntaps = p.ks * p.ks;
 
-    f32x4 a_reg[RA], b_reg[RB];
-
-    auto load_chunk = [&](int c) {
-        const int k = c * BK + kq;
+    // source pointers of the chunk being staged (computed once per chunk, fired between MFMAs)
+    const float* src[NLOAD];
+    auto prepare = [&](int c) {
         if (AMODE == AMODE_ROWS) {
+            const int k = c * BK + kq;
+            const bool k_ok = k < p.K;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_base[i] >= 0 && k < p.K) v = *reinterpret_cast<const f32x4*>(p.A + a_base[i] + k);
-                a_reg[i] = v;
-            }
-        } else if (AMODE == AMODE_CONV) {
-            const int kh = tap / p.ks, kw = tap - kh * p.ks;
-            const bool tap_ok = tap < ntaps;
+            for (int i = 0; i < RA; ++i) src[i] = (k_ok && a_mask[i]) ? p.A + a_off[i] + k : zero;
+        } else {
+            const long toff = ((long)kh * p.W + kw) * p.Cin + ci;
+            const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(p.A + a_base[i] + ((long)hi * p.W + wi) * p.Cin + ci);
-                a_reg[i] = v;
-            }
+            for (int i = 0; i < RA; ++i) src[i] = (a_mask[i] & bit) ? p.A + a_off[i] + toff : zero;
             ci += BK;
-            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
-        } else {  // small Cin (stem, Cin = 3): element-wise gather, k = (kh*ks + kw)*Cin + ci
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ke = k + e;
-                    const int t = ke / p.Cin, c1 = ke - t * p.Cin;
-                    const int kh = t / p.ks, kw = t - kh * p.ks;
-                    const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-                    if (ke < p.K && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                        v[e] = p.A[a_base[i] + ((long)hi * p.W + wi) * p.Cin + c1];
-                }
-                a_reg[i] = v;
+            while (ci >= p.Cin) {
+                ci -= p.Cin;
+                ++tap;
+                if (++kw == p.ks) { kw = 0; ++kh; }
             }
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ptr[i]) v = *reinterpret_cast<const f32x4*>(b_ptr[i] + c * BK);
-            b_reg[i] = v;
-        }
+        for (int i = 0; i < RB; ++i) src[RA + i] = (b_src[i] && c < nchunks) ? b_src[i] + c * BK : zero;
+    };
+    // fire load #idx of the prepared chunk into `stage` (LDS image: 8 rows x 128 B per wave instruction)
+    auto fire = [&](int idx, int stage) {
+        float* As = lds + stage * STAGE;
+        float* dst = idx < RA ? As + (idx * RPR + wave * 8) * BK : As + BM * BK + ((idx - RA) * RPR + wave * 8) * BK;
+        __builtin_amdgcn_global_load_lds((gptr_t)src[idx], (lptr_t)dst, 16, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -167,20 +196,204 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs p) {
 
     const int wm0 = (wave / WAVES_N) * WM;
     const int wn0 = (wave % WAVES_N) * WN;
-    const int frow = lane & 31;         // fragment row (m for A, n for B)
-    const int fk = (lane >> 5) * 4;     // k offset of this half-wave inside an 8-wide k step
+    const int frow = lane & 31;
+    const int fsw = (frow >> KEYSH) & 7;      // swizzle key of this lane's fragment row (tile offsets are multiples of 32)
+    const int fhalf = lane >> 5;              // which 4-wide k half of an 8-wide step this lane feeds
 
+    // Pipeline.  Chunks c+1 .. c+S-2 are in flight at the top of iteration c; chunk c+S-1 is fired into
+    // the stage that iteration c-1 read, AFTER this iteration's barrier (every wave of the block has then
+    // finished reading it), between the MFMAs of the first two k-steps.  Single-wave blocks need no
+    // barrier: the wave's own counted vmcnt orders its DMA against its ds_reads.
+    constexpr int PER_STEP = (NLOAD + 1) / 2;
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) {
+        prepare(s);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) fire(i, s);
+    }
+    int st_read = 0, st_fill = S - 1;
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vmcnt<(S - 2) * NLOAD>();
+        if (NW > 1) __builtin_amdgcn_s_barrier();
+        const float* As = lds + st_read * STAGE;
+        const float* Bs = As + BM * BK;
+        prepare(c + S - 1);      // past the last chunk every source is the zero page: branch-free, harmless
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int q = ((step * 2) + fhalf) ^ fsw;          // physical quad of logical quad 2*step + half
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BK + q * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BK + q * 4]);
+            int fired = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                        if (step < 2 && fired < PER_STEP) {
+                            const int idx = step * PER_STEP + fired;
+                            if (idx < NLOAD) fire(idx, st_fill);
+                            ++fired;
+                        }
+                    }
+            if (step < 2) {   // tiles with fewer MFMAs per step than loads: fire the rest here
+#pragma unroll
+                for (int f = TM * TN * 4; f < PER_STEP; ++f) {
+                    const int idx = step * PER_STEP + f;
+                    if (idx < NLOAD) fire(idx, st_fill);
+                }
+            }
+        }
+        st_read = (st_read + 1 == S) ? 0 : st_read + 1;
+        st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
+    }
+    wait_vmcnt<0>();
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col(n) = lane & 31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Residuals are loaded for a whole 32x32 tile before anything is stored (an in-place residual may
+    // alias `out`; interleaving load/store would serialise 16 memory round trips per tile).
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const bool n_ok = full || n < p.N;
+        const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm0 + i * 32 + 4 * (lane >> 5);
+            float rv[16];
+            if (PLAIN) {
+                // 32-bit element offsets from uniform bases (tensors are < 2^31 elements per launch)
+                const unsigned oo = (unsigned)mb * (unsigned)p.omap.S1 + (unsigned)n;
+                const unsigned ro = (unsigned)mb * (unsigned)p.rmap.S1 + (unsigned)n;
+                float* ob = p.out + p.omap.off;
+                const float* rb = p.res ? p.res + p.rmap.off : nullptr;
+                const unsigned lo = (unsigned)p.omap.S1, lr = (unsigned)p.rmap.S1;
+                if (rb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        rv[r] = (full || (n_ok && mb + dm < p.M)) ? rb[ro + dm * lr] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bv + rv[r];
+                    if (GELU) { if (p.act == ACT_GELU) v = gelu_erf(v); }
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    if (full || (n_ok && mb + dm < p.M)) ob[oo + dm * lo] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    rv[r] = (p.res && n_ok && m < p.M) ? p.res[rowmap(p.rmap, m) + n] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bv + rv[r];
+                    if (GELU) { if (p.act == ACT_GELU) v = gelu_erf(v); }
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    if (n_ok && m < p.M) p.out[rowmap(p.omap, m) + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// Small-Cin (stem: Cin = 3, k = 3 or 7) variant: K is gathered element-wise into registers, staged with
+// ds_write_b128 into a padded LDS tile (pitch 36 floats: conflict-free b128 without a swizzle).  0.3 % of
+// the FLOPs of the path; kept simple.
+// =====================================================================================================
+static constexpr int PITCH = 36;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_f32_smallc_kernel(GemmArgs p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PITCH];
+    float* As = lds;
+    float* Bs = lds + BM * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / nbn, tile_n = blockIdx.x - tile_m * nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int srow = tid >> 3, kq = (tid & 7) * 4;
+
+    long a_base[RA];
+    int a_h0[RA], a_w0[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + srow + 32 * i;
+        if (m < p.M) {
+            const int b = fast_div(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
+            const int ho = fast_div(rem, p.fd_wo), wo = rem - ho * p.Wo;
+            a_base[i] = (long)b * p.H * p.W * p.Cin;
+            a_h0[i] = ho * p.stride - p.pad;
+            a_w0[i] = wo * p.stride - p.pad;
+        } else {
+            a_base[i] = 0;
+            a_h0[i] = -(1 << 20);
+            a_w0[i] = 0;
+        }
+    }
+    f32x4 a_reg[RA], b_reg[RB];
+    auto load_chunk = [&](int c) {
+        const int k = c * BK + kq;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = k + e;
+                const int t = ke / p.Cin, c1 = ke - t * p.Cin;
+                const int kh = t / p.ks, kw = t - kh * p.ks;
+                const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                if (ke < p.K && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    v[e] = p.A[a_base[i] + ((long)hi * p.W + wi) * p.Cin + c1];
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + srow + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) v = *reinterpret_cast<const f32x4*>(p.Wp + (long)n * p.Kpad + c * BK + kq);
+            b_reg[i] = v;
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
     const int nchunks = p.Kpad / BK;
     load_chunk(0);
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * PITCH + kq]) = a_reg[i];
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * PITCH + kq]) = a_reg[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * PITCH + kq]) = b_reg[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * PITCH + kq]) = b_reg[i];
         __syncthreads();
-        if (c + 1 < nchunks) load_chunk(c + 1);   // in flight during the MFMAs below
+        if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
             f32x4 af[TM], bf[TN];
@@ -200,8 +413,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col(n) = lane & 31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + j * 32 + (lane & 31);
@@ -216,7 +427,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs p) {
                     float v = acc[i][j][r] + bv;
                     if (p.res) v += p.res[rowmap(p.rmap, m) + n];
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_GELU) v = gelu_erf(v);
                     p.out[rowmap(p.omap, m) + n] = v;
                 }
             }
@@ -224,54 +434,99 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    dim3 grid(nbm * nbn), block(256);
-    if (!a.conv)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE_ROWS>), grid, block, 0, s, a);
-    else if (a.Cin % 4 == 0)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE_CONV>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE_CONV_SMALLC>), grid, block, 0, s, a);
-    return hipGetLastError();
+// =====================================================================================================
+// host side: tile selection + launch
+// =====================================================================================================
+FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+    return f;
 }
 
-// Tile selection: N decides the column tile; M decides how many rows a block takes so that the grid
-// still covers the 256 CUs a few times over.
-enum TileCfg { T256x32, T128x32, T128x64, T64x64, T128x128 };
+enum TileCfg { W1_64x32 = 0, W1_64x64, W4_128x64, W4_64x64, W4_128x128, W4_256x32, N_TILES };
+static const char* kTileNames[N_TILES] = {"w1,64x32", "w1,64x64", "w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32"};
 
+// N decides the column tile; M decides whether single-wave blocks (private LDS ring, no barrier) still
+// give every SIMD several waves, or whether the tile must be shared by 4 waves to keep L2->LDS traffic
+// per FLOP down (small M, wide N).  CAPF_TILE=<index> forces a tile (micro-benchmark tuning only).
 static TileCfg pick_tile(const GemmArgs& a) {
-    if (a.N <= 32) return ((long)a.M >= 256L * 1024) ? T256x32 : T128x32;
-    if (a.N <= 64) return ((long)a.M >= 128L * 512) ? T128x64 : T64x64;
+    static const int forced = [] { const char* e = getenv("CAPF_TILE"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && forced < N_TILES) return (TileCfg)forced;
+    // measured on MI355X (tools/bench_conv.py, batch 64): N <= 32 -> 256x32 (69 TF on 32->32@64^2 vs 45-55 for
+    // the others); N <= 64 -> 128x64 for big M (95 TF on 64->64@64^2), 64x64 otherwise; the single-wave
+    // blocks (w1,*) lose 15-25 % to their extra L2->LDS traffic and are kept for experiments only.
+    if (a.N <= 32) return ((long)a.M >= 256L * 512) ? W4_256x32 : W4_64x64;
+    if (a.N <= 64) return ((long)a.M >= 128L * 512) ? W4_128x64 : W4_64x64;
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tiles128 >= 512) return T128x128;
-    if ((long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 256) return T128x64;
-    return T64x64;
+    if (tiles128 >= 512) return W4_128x128;
+    if ((long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 256) return W4_128x64;
+    return W4_64x64;
 }
 
 const char* gemm_f32_kernel_name(const GemmArgs& a) {
-    static const char* names[5][3] = {
-        {"igemm_f32<256,32,rows>", "igemm_f32<256,32,conv>", "igemm_f32<256,32,conv_smallc>"},
-        {"igemm_f32<128,32,rows>", "igemm_f32<128,32,conv>", "igemm_f32<128,32,conv_smallc>"},
-        {"igemm_f32<128,64,rows>", "igemm_f32<128,64,conv>", "igemm_f32<128,64,conv_smallc>"},
-        {"igemm_f32<64,64,rows>", "igemm_f32<64,64,conv>", "igemm_f32<64,64,conv_smallc>"},
-        {"igemm_f32<128,128,rows>", "igemm_f32<128,128,conv>", "igemm_f32<128,128,conv_smallc>"}};
-    const int mode = !a.conv ? 0 : (a.Cin % 4 == 0 ? 1 : 2);
-    return names[pick_tile(a)][mode];
+    static char buf[N_TILES][2][48];
+    static bool init = false;
+    if (!init) {
+        const char* modes[2] = {"rows", "conv"};
+        for (int t = 0; t < N_TILES; ++t)
+            for (int m = 0; m < 2; ++m) snprintf(buf[t][m], sizeof(buf[t][m]), "igemm_f32<%s,%s>", kTileNames[t], modes[m]);
+        init = true;
+    }
+    if (a.conv && a.Cin % 4 != 0) return "igemm_f32_smallc<w4,128x64>";
+    return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
 
-hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    if (a.Kpad % BK != 0) return hipErrorInvalidValue;
-    switch (pick_tile(a)) {
-        case T256x32: return launch_cfg<256, 32, 64, 32>(a, s);
-        case T128x32: return launch_cfg<128, 32, 32, 32>(a, s);
-        case T128x64: return launch_cfg<128, 64, 64, 32>(a, s);
-        case T64x64: return launch_cfg<64, 64, 32, 32>(a, s);
-        case T128x128: return launch_cfg<128, 128, 64, 64>(a, s);
+template <int NW, int BM, int BN, int WM, int WN, int S>
+static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    dim3 grid(nbm * nbn), block(64 * NW);
+    const bool plain = a.omap.G == 1 && (!a.res || a.rmap.G == 1);
+    if (a.conv) {
+        if (!plain) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true>), grid, block, 0, s, a);
+    } else if (a.act == ACT_GELU) {
+        if (!plain) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_ROWS, true, true>), grid, block, 0, s, a);
+    } else if (plain) {
+        hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_ROWS, false, true>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_ROWS, false, false>), grid, block, 0, s, a);
     }
-    return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
+    if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
+    if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
+    GemmArgs a = a_in;
+    // the epilogue's fast path addresses out / res with 32-bit element offsets from their bases
+    if (a.omap.G == 1 && (double)a.M * (double)a.omap.S1 >= 4.0e9) return hipErrorInvalidValue;
+    if (a.res && a.rmap.G == 1 && (double)a.M * (double)a.rmap.S1 >= 4.0e9) return hipErrorInvalidValue;
+    if (a.conv) {
+        a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
+        a.fd_wo = make_fastdiv((unsigned)a.Wo);
+        a.spread = 0ull;
+        for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+        if (a.act == ACT_GELU) return hipErrorInvalidValue;
+        if (a.Cin % 4 != 0) {
+            dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64)), block(256);
+            hipLaunchKernelGGL((igemm_f32_smallc_kernel<128, 64, 64, 32>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+    }
+    switch (pick_tile(a)) {
+        case W1_64x32: return launch_cfg<1, 64, 32, 64, 32, 3>(a, s);
+        case W1_64x64: return launch_cfg<1, 64, 64, 64, 64, 3>(a, s);
+        case W4_128x64: return launch_cfg<4, 128, 64, 64, 32, 2>(a, s);
+        case W4_64x64: return launch_cfg<4, 64, 64, 32, 32, 3>(a, s);
+        case W4_128x128: return launch_cfg<4, 128, 128, 64, 64, 2>(a, s);
+        case W4_256x32: return launch_cfg<4, 256, 32, 64, 32, 2>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace capf

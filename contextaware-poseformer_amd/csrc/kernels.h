@@ -14,6 +14,12 @@ inline RowMap row_ld(long ld, long off = 0) { return RowMap{1, ld, 0, off}; }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
+// n / d for 0 <= n < 2^31:  q = (umulhi(n, mul) + n) >> shift   (host: make_fastdiv)
+struct FastDiv {
+    unsigned mul, shift;
+};
+FastDiv make_fastdiv(unsigned d);
+
 // One implicit-GEMM problem:  out[m, n] = act( sum_k A[m, k] * Wp[n, k] + bias[n] + res[m, n] )
 //   conv mode: A[m, k] gathered from an NHWC tensor, m = (b, ho, wo), k = (kh, kw, ci)
 //   rows mode: A[m, k] = A[amap(m) + k]
@@ -28,6 +34,8 @@ struct GemmArgs {
     int Cin, H, W, Ho, Wo, ks, stride, pad;
     RowMap amap, omap, rmap;
     int act;
+    FastDiv fd_hw, fd_wo;   // filled by launch_gemm_f32 (conv mode): division by Ho*Wo and by Wo
+    unsigned long long spread;   // conv mode: bits kh*ks set for kh < ks (tap-mask construction)
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);

@@ -47,6 +47,38 @@ void Engine::use(int buf) {
     if (buf >= 0) bufs[buf].last_op = std::max(bufs[buf].last_op, (int)ops.size());
 }
 
+void Engine::push(Op op) {
+    op.lane = cur_lane;
+    op.region = cur_region;
+    ops.push_back(op);
+}
+
+void Engine::fork(int n) {
+    Op op;
+    op.kind = OP_FORK;
+    op.name = "fork";
+    op.i0 = n;
+    op.i1 = n_events;          // first event id of this region: 1 for the fork + (n-1) for the join
+    n_events += n;
+    cur_region = n_regions++;
+    cur_lane = 0;
+    regions.push_back({(int)ops.size(), -1});
+    push(op);
+}
+
+void Engine::join() {
+    Op op;
+    op.kind = OP_JOIN;
+    op.name = "join";
+    const Op& f = ops[regions[cur_region].first];
+    op.i0 = f.i0;
+    op.i1 = f.i1;
+    cur_lane = 0;
+    regions[cur_region].second = (int)ops.size();
+    push(op);
+    cur_region = -1;
+}
+
 static void keep(Engine& e, int buf) { e.bufs[buf].last_op = INT_MAX; }
 
 static void name_tensor(Engine& e, const std::string& name, int buf, std::initializer_list<int64_t> shape,
@@ -105,7 +137,7 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     }
     y.buf = new_buffer((size_t)y.H * y.W * Cout, conv);
     op.out = y.buf;
-    ops.push_back(op);
+    push(op);
     return y;
 }
 
@@ -124,7 +156,7 @@ static Tensor fuse_sum(Engine& e, const std::string& name, const Tensor* terms, 
     Tensor y = like;
     y.buf = e.new_buffer((size_t)like.H * like.W * like.C, name);
     op.out = y.buf;
-    e.ops.push_back(op);
+    e.push(op);
     return y;
 }
 
@@ -149,15 +181,20 @@ static void hr_module(Engine& e, const std::string& p, std::vector<Tensor>& xs, 
                       std::vector<Tensor>* branch_out) {
     const int nb = (int)xs.size();
     std::vector<Tensor> br(nb);
+    e.fork(nb);                      // the branches are independent until the fuse: one stream lane each
     for (int i = 0; i < nb; ++i) {
+        e.set_lane(i);
         Tensor y = xs[i];
         for (int k = 0; k < blocks; ++k)
             y = hr_basic_block(e, p + ".branches." + std::to_string(i) + "." + std::to_string(k), y);
         br[i] = y;
     }
+    e.join();
     if (branch_out) *branch_out = br;
     std::vector<Tensor> outs(n_out);
+    if (n_out > 1) e.fork(n_out);    // each fused output only reads the branch outputs: independent lanes again
     for (int i = 0; i < n_out; ++i) {
+        if (n_out > 1) e.set_lane(i);
         Tensor terms[4];
         int shifts[4] = {0, 0, 0, 0};
         for (int j = 0; j < nb; ++j) {
@@ -180,6 +217,7 @@ static void hr_module(Engine& e, const std::string& p, std::vector<Tensor>& xs, 
         }
         outs[i] = fuse_sum(e, p + ".fuse" + std::to_string(i), terms, shifts, nb, br[i], 1);
     }
+    if (n_out > 1) e.join();
     xs = outs;
 }
 
@@ -246,7 +284,7 @@ static Tensor pool_or_resize(Engine& e, OpKind kind, const std::string& name, co
     Tensor y{-1, Ho, Wo, x.C};
     y.buf = e.new_buffer((size_t)Ho * Wo * x.C, name);
     op.out = y.buf;
-    e.ops.push_back(op);
+    e.push(op);
     return y;
 }
 
@@ -301,7 +339,9 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
     // refineNet.forward (refineNet.py:72-88)
     const std::string F = "backbone.refine_net";
     const int oh = 64, ow = 48;   // cpn/test_config.py:24 output_shape
+    fork(4);                      // the four cascades are independent
     for (int i = 0; i < 4; ++i) {
+        set_lane(i);
         Tensor y = fms[i];
         for (int k = 0; k < 3 - i; ++k) {
             const std::string p = F + ".cascade." + std::to_string(i) + "." + std::to_string(k);
@@ -312,6 +352,7 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
         }
         feats[i] = pool_or_resize(*this, OP_RESIZE, F + ".cascade." + std::to_string(i) + ".resize", y, oh, ow);
     }
+    join();
     // final_predict is never called (:76-88): parameters only
     const std::string fp = F + ".final_predict";
     register_unused_conv_bn(*this, fp + ".0.conv1", fp + ".0.bn1", 128, 1024, 1);
@@ -385,7 +426,7 @@ static void gemm_rows(Engine& e, const std::string& name, int pack, int a_buf, R
     e.use(a_buf);
     e.use(res_buf);
     e.use(out_buf);
-    e.ops.push_back(op);
+    e.push(op);
 }
 
 static void layernorm(Engine& e, const std::string& name, const std::string& ln, float eps, int in_buf, RowMap imap,
@@ -406,7 +447,7 @@ static void layernorm(Engine& e, const std::string& name, const std::string& ln,
     e.use(in_buf);
     e.use(add_buf);
     e.use(out_buf);
-    e.ops.push_back(op);
+    e.push(op);
 }
 
 static void debug_copy(Engine& e, const std::string& name, int src, size_t elems, std::initializer_list<int64_t> shape) {
@@ -419,7 +460,7 @@ static void debug_copy(Engine& e, const std::string& name, int src, size_t elems
     op.i0 = 1;               // debug-only op
     e.use(src);
     op.out = e.new_buffer(elems, name);
-    e.ops.push_back(op);
+    e.push(op);
     name_tensor(e, name, op.out, shape);
 }
 
@@ -478,7 +519,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
         op.p2 = pos;
         op.i0 = J; op.i1 = L1; op.C = C;
         use(X);
-        ops.push_back(op);
+        push(op);
     }
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
@@ -492,7 +533,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
         const int I = new_buffer((size_t)J * 2, "idx" + ls);
         op.out = S;
         op.aux2 = I;
-        ops.push_back(op);
+        push(op);
         name_tensor(*this, "sampled" + ls, S, {-1, J, Cl[l]});
         name_tensor(*this, "idx" + ls, I, {-1, J, 2}, 1);
         const int pk = make_linear_pack(*this, {V + ".feat_embed." + ls});
@@ -533,7 +574,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
                     use(U[l]);
                 }
                 op.i0 = J; op.i1 = L; op.i2 = NH; op.i3 = NS;
-                ops.push_back(op);
+                push(op);
             }
             for (int l = 0; l < L; ++l) {
                 const int pk = make_linear_pack(*this, {p + ".embed_proj." + std::to_string(l)});
@@ -568,7 +609,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 op.i0 = groups_pf; op.i1 = tokens; op.i2 = cfg.num_heads; op.i3 = dim / cfg.num_heads;
                 op.flops_per_frame = 4.0 * groups_pf * tokens * tokens * dim;
                 use(QKV); use(O);
-                ops.push_back(op);
+                push(op);
             }
             gemm_rows(*this, n + ".proj", make_linear_pack(*this, {p + ".attn.proj"}), O, row_ld(dim), rows_pf, X,
                       row_ld(dim), ACT_NONE, X, row_ld(dim));
@@ -599,7 +640,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
         op.i0 = 3;
         op.flops_per_frame = 2.0 * J * D * 3;
         use(X);
-        ops.push_back(op);
+        push(op);
     }
 }
 
@@ -608,6 +649,15 @@ void Engine::assign_offsets() {
     struct Live { size_t off, size; int last; };
     std::vector<int> order(bufs.size());
     for (size_t i = 0; i < bufs.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bufs[a].def_op < bufs[b].def_op; });
+    // Ops of different lanes of a fork/join region run concurrently: a buffer whose life touches a region
+    // stays allocated for the whole region (no reuse across lanes while they may overlap).
+    for (Buffer& b : bufs)
+        for (const auto& rg : regions) {
+            const bool touches = b.def_op <= rg.second && b.last_op >= rg.first;
+            if (touches && b.last_op < rg.second) b.last_op = rg.second;
+            if (touches && b.def_op > rg.first) b.def_op = rg.first;
+        }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bufs[a].def_op < bufs[b].def_op; });
     std::vector<Live> live;
     size_t top = 0;

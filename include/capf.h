@@ -120,6 +120,11 @@ int capf_backbone_forward(capf_handle* h, void* stream, const float* images_nhwc
 int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* kcrop_inout, int batch,
                         float* out);
 
+/* Independent branches of the backbone (the 2-4 resolution branches of an HRNet module, the fused
+ * outputs, the CPN refine cascades) are enqueued on library-owned side streams, forked from / joined
+ * to the caller's stream with events (default on).  0 = everything in order on the caller's stream. */
+int capf_set_lanes(capf_handle* h, int on);
+
 /* When on, forward also snapshots the token buffer after each block group (tok_ctx/tok_res/tok_joint). */
 int capf_set_debug(capf_handle* h, int on);
 

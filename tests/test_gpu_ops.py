@@ -1,0 +1,73 @@
+"""GPU, operator level: the stateless C-ABI operators (capf_op_conv / capf_op_linear: the fp32-MFMA
+implicit GEMM behind every conv and nn.Linear of the path) against plain PyTorch fp32 (CPU) on the
+same inputs.  Covers every shape class of SURVEY.md Appendix A plus ragged tiles, stride 2, 1x1, 7x7,
+Cin=3 stem, channel counts that are not multiples of 32, residual / ReLU / GELU epilogues."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (Cin, Cout, ks, stride, H, W, B, act, residual, bn)
+CONV_CASES = [
+    (32, 32, 3, 1, 64, 64, 2, 1, True, True),      # branch-0 BasicBlock conv2
+    (64, 64, 3, 1, 32, 32, 3, 1, False, True),
+    (128, 128, 3, 1, 16, 16, 2, 0, True, False),
+    (256, 256, 3, 1, 8, 8, 5, 1, True, True),
+    (3, 64, 3, 2, 64, 48, 2, 1, False, True),      # stem (small-Cin loader)
+    (3, 64, 7, 2, 96, 72, 1, 1, False, True),      # CPN stem 7x7
+    (64, 256, 1, 1, 16, 12, 2, 1, True, True),     # bottleneck expand
+    (256, 64, 1, 1, 16, 12, 2, 1, False, True),
+    (32, 64, 3, 2, 16, 12, 3, 0, False, True),     # fuse down path
+    (48, 48, 3, 1, 24, 20, 1, 1, True, True),      # W48: K = 432 is not a multiple of 32
+    (96, 48, 1, 1, 10, 6, 2, 0, False, True),
+    (48, 96, 3, 2, 12, 10, 2, 1, False, True),
+    (2048, 256, 1, 1, 4, 3, 1, 1, False, True),    # CPN lateral
+    (512, 512, 3, 2, 12, 10, 1, 1, False, False),
+    (256, 17, 3, 1, 9, 7, 1, 0, False, False),     # ragged N = 17
+    (32, 32, 3, 1, 5, 3, 7, 1, True, False),       # tiny ragged image, M = 105
+]
+
+
+@pytest.mark.parametrize("ci,co,ks,st,H,W,B,act,res,bn", CONV_CASES)
+def test_conv_bn_act_matches_torch(ci, co, ks, st, H, W, B, act, res, bn):
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(ci * 131 + co * 7 + ks + st + H)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, ks, ks, generator=g) / (ci * ks * ks) ** 0.5
+    bnp = None
+    if bn:
+        bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1,
+               torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) * 0.4 + 0.8)
+    want = F.conv2d(x, w, None, st, ks // 2)
+    if bn:
+        want = F.batch_norm(want, bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    r = torch.randn_like(want) if res else None
+    if res:
+        want = want + r
+    if act == 1:
+        want = F.relu(want)
+    wp, bias = capf.pack_conv(w.cuda(), tuple(t.cuda() for t in bnp) if bn else None)
+    got = capf.conv_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, ks, st, act,
+                         r.permute(0, 2, 3, 1).contiguous().cuda() if res else None)
+    got = got.cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(1088, 1920, 640, 0, False), (1088, 640, 1280, 0, True), (85, 384, 128, 0, False),
+                                           (4352, 256, 128, 2, False), (272, 32, 32, 0, True), (17, 16, 128, 0, False),
+                                           (300, 48, 128, 0, False), (1, 640, 640, 2, True), (129, 33, 64, 0, False)])
+def test_linear_matches_torch(M, N, K, act, res):
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    want = F.linear(x, w, b)
+    r = torch.randn(M, N, generator=g) if res else None
+    if res:
+        want = want + r
+    if act == 2:
+        want = F.gelu(want)
+    got = capf.linear(x.cuda(), w.cuda(), b.cuda(), act, r.cuda() if res else None).cpu()
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())

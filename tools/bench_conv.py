@@ -12,7 +12,7 @@ import torch
 from capf import lib as capf
 
 # (Cin, Cout, ks, stride, H, W)  — the HRNet-W32 @256x256 shape classes
-SHAPES = [(32, 32, 3, 1, 64, 64), (64, 64, 3, 1, 32, 32), (128, 128, 3, 1, 16, 16), (256, 256, 3, 1, 8, 8),
+SHAPES = [(32, 32, 1, 1, 64, 64), (32, 32, 3, 1, 64, 64), (64, 64, 3, 1, 32, 32), (128, 128, 3, 1, 16, 16), (256, 256, 3, 1, 8, 8),
           (64, 64, 3, 1, 64, 64), (64, 256, 1, 1, 64, 64), (256, 64, 1, 1, 64, 64), (256, 32, 3, 1, 64, 64),
           (64, 64, 3, 2, 128, 128), (3, 64, 3, 2, 256, 256), (32, 64, 3, 2, 64, 64), (64, 32, 1, 1, 32, 32)]
 
