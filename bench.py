@@ -94,12 +94,8 @@ def main():
     from mvn.models.conpose import CA_PF
     from mvn.utils.cfg import backbone_preset, config
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+    from capf import dist as cdist
+    rank, world, local = cdist.init_from_env("nccl")       # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -139,10 +135,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     assert torch.isfinite(out).all()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = cdist.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / a.steps * 1e3
     fps = B * world * a.steps / elapsed
 
@@ -169,8 +162,16 @@ def main():
         gemm_ms = sum(e[0] for k, e in acc.items() if k.startswith("igemm"))
         gemm_fl = sum(e[1] for k, e in acc.items() if k.startswith("igemm"))
         peak = PEAK_TFLOPS["f32"]
+        # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE in separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tfile) and (a.backbone, B, H, W) == ("hrnet_32", 64, 256, 256):
+            traffic = json.load(open(tfile)).get(dname, {}).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
+                    "algorithmic_flops_per_launch": round(dflops / dn, 1),
                     "launches_per_step": dn // max(1, a.profile_steps),
                     "avg_launch_us": round(dms / dn * 1e3, 2),
                     "share_of_step": round(dms / total_ms, 4),
