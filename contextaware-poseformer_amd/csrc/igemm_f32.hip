@@ -68,7 +68,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NW waves per block (1 or 4), block tile BM x BN, wave tile WM x WN, S LDS stages.
 // PLAIN: out / res rows are addressed with a plain leading dimension (every conv, most linears);
 // otherwise the (G, S1, S2) row maps of the lifter's strided token views are evaluated per row.
-template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN>
+// ABL: ablation for diagnosis only (0 = product kernel; 1 = no DMA inside the K loop; 2 = no MFMA)
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = BN / WN;
@@ -212,14 +213,18 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
         for (int i = 0; i < NLOAD; ++i) fire(i, s);
     }
     int st_read = 0, st_fill = S - 1;
+    prepare(S - 1);              // sources of the chunk fired in iteration 0
     for (int c = 0; c < nchunks; ++c) {
         wait_vmcnt<(S - 2) * NLOAD>();
         if (NW > 1) __builtin_amdgcn_s_barrier();
         const float* As = lds + st_read * STAGE;
         const float* Bs = As + BM * BK;
-        prepare(c + S - 1);      // past the last chunk every source is the zero page: branch-free, harmless
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
+            // the address arithmetic of the NEXT iteration's loads runs in the MFMA shadows of k-step 2
+            // (this iteration's loads were all fired in steps 0-1); past the last chunk every source is
+            // the zero page: branch-free, harmless
+            if (step == 2) prepare(c + S);
             const int q = ((step * 2) + fhalf) ^ fsw;          // physical quad of logical quad 2*step + half
             f32x4 af[TM], bf[TN];
 #pragma unroll
@@ -235,10 +240,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                        if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+                        else { acc[i][j][e] += af[i][e] * bf[j][e]; }   // (ablation only)
                         if (step < 2 && fired < PER_STEP) {
                             const int idx = step * PER_STEP + fired;
-                            if (idx < NLOAD) fire(idx, st_fill);
+                            if (idx < NLOAD && ABL != 1) fire(idx, st_fill);
                             ++fired;
                         }
                     }
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
 #pragma unroll
                 for (int f = TM * TN * 4; f < PER_STEP; ++f) {
                     const int idx = step * PER_STEP + f;
-                    if (idx < NLOAD) fire(idx, st_fill);
+                    if (idx < NLOAD && ABL != 1) fire(idx, st_fill);
                 }
             }
         }
@@ -255,57 +261,64 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     }
     wait_vmcnt<0>();
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col(n) = lane & 31, row(m) = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Residuals are loaded for a whole 32x32 tile before anything is stored (an in-place residual may
-    // alias `out`; interleaving load/store would serialise 16 memory round trips per tile).
+    // ---- epilogue.  The MFMAs were issued with the WEIGHTS as the A operand, so the accumulator holds the
+    // transposed tile: C/D map of the 32x32 MFMA gives this lane ONE output row m = lane & 31 and, per
+    // register group g = r >> 2, FOUR CONSECUTIVE channels n = 8g + 4*(lane>>5) + (r & 3).  NHWC output
+    // therefore goes out as 16-byte stores (4 per 32x32 tile instead of 16 dword stores: the store tail of
+    // a short-K tile is issue-bound), bias and residual come in as 16-byte loads, and a row's address is
+    // computed once per lane.  Residuals are loaded for the whole tile before anything is stored (an
+    // in-place residual aliases `out`).
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + (lane & 31);
-        const bool n_ok = full || n < p.N;
-        const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + (lane & 31);
+        const bool m_ok = full || m < p.M;
+        long o_row = 0, r_row = 0;
+        if (m_ok) {
+            o_row = PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m);
+            if (p.res) r_row = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : rowmap(p.rmap, m);
+        }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm0 + i * 32 + 4 * (lane >> 5);
-            float rv[16];
-            if (PLAIN) {
-                // 32-bit element offsets from uniform bases (tensors are < 2^31 elements per launch)
-                const unsigned oo = (unsigned)mb * (unsigned)p.omap.S1 + (unsigned)n;
-                const unsigned ro = (unsigned)mb * (unsigned)p.rmap.S1 + (unsigned)n;
-                float* ob = p.out + p.omap.off;
-                const float* rb = p.res ? p.res + p.rmap.off : nullptr;
-                const unsigned lo = (unsigned)p.omap.S1, lr = (unsigned)p.rmap.S1;
-                if (rb) {
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + wn0 + j * 32 + 4 * (lane >> 5);
+            f32x4 rv[4], bv[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dm = (r & 3) + 8 * (r >> 2);
-                        rv[r] = (full || (n_ok && mb + dm < p.M)) ? rb[ro + dm * lr] : 0.f;
-                    }
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 8 * g;
+                const bool ok = m_ok && (full || n < p.N);
+                rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (vec_ok) {
+                    if (ok && p.bias) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (ok && p.res) rv[g] = *reinterpret_cast<const f32x4*>(p.res + r_row + n);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        if (m_ok && n + e < p.N) {
+                            if (p.bias) bv[g][e] = p.bias[n + e];
+                            if (p.res) rv[g][e] = p.res[r_row + n + e];
+                        }
+                    }
                 }
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dm = (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bv + rv[r];
-                    if (GELU) { if (p.act == ACT_GELU) v = gelu_erf(v); }
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    if (full || (n_ok && mb + dm < p.M)) ob[oo + dm * lo] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 8 * g;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * g + e] + bv[g][e] + rv[g][e];
+                    if (GELU) { if (p.act == ACT_GELU) t = gelu_erf(t); }
+                    if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = t;
                 }
-            } else {
+                if (vec_ok) {
+                    if (m_ok && (full || n < p.N)) *reinterpret_cast<f32x4*>(p.out + o_row + n) = v;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    rv[r] = (p.res && n_ok && m < p.M) ? p.res[rowmap(p.rmap, m) + n] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bv + rv[r];
-                    if (GELU) { if (p.act == ACT_GELU) v = gelu_erf(v); }
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    if (n_ok && m < p.M) p.out[rowmap(p.omap, m) + n] = v;
+                    for (int e = 0; e < 4; ++e)
+                        if (m_ok && n + e < p.N) p.out[o_row + n + e] = v[e];
                 }
             }
         }
@@ -487,6 +500,12 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     const bool plain = a.omap.G == 1 && (!a.res || a.rmap.G == 1);
     if (a.conv) {
         if (!plain) return hipErrorInvalidValue;
+        static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
+        if (abl == 1)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 1>), grid, block, 0, s, a);
+        else if (abl == 2)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 2>), grid, block, 0, s, a);
+        else
         hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true>), grid, block, 0, s, a);
     } else if (a.act == ACT_GELU) {
         if (!plain) return hipErrorInvalidValue;
