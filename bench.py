@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
     ap.add_argument("--lanes", type=int, default=1, help="1: independent backbone branches on side streams (default); 0: one stream")
     return ap.parse_args()
 
@@ -95,8 +96,10 @@ def main():
     from mvn.utils.cfg import backbone_preset, config
 
     from capf import dist as cdist
-    rank, world, local = cdist.init_from_env("nccl")       # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
+    rank, world, local = cdist.init_from_env(a.backend)    # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("CAPF_BENCH_SINGLE_DEVICE"):         # smoke-testing the N>1 flow on a 1-GPU box (gloo only)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

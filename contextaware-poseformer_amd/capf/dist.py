@@ -77,6 +77,8 @@ def broadcast_state_(module, src=0):
 def max_over_ranks(seconds, device):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return seconds
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
