@@ -13,6 +13,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_set_param", "capf_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
+    "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
 ]
 
 
@@ -26,6 +27,7 @@ class CapfConfig(ctypes.Structure):
         ("base_dim", c_int32), ("embed_dim_ratio", c_int32), ("levels", c_int32), ("num_joints", c_int32),
         ("num_heads", c_int32), ("deform_heads", c_int32), ("deform_samples", c_int32), ("context_blocks", c_int32),
         ("compute_dtype", c_int32), ("max_batch", c_int32), ("height", c_int32), ("width", c_int32),
+        ("training", c_int32),
     ]
 
 
@@ -71,6 +73,13 @@ def load_library():
     lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          POINTER(c_float), c_int]
     P = c_void_p
+    lib.capf_forward_train.argtypes = [H, P, P, P, P, c_int, P, P]
+    lib.capf_backward.argtypes = [H, P, P, c_int, P, P]
+    lib.capf_grad_elems.argtypes = [H]
+    lib.capf_grad_elems.restype = c_int64
+    lib.capf_grad_info.argtypes = [H, c_int, POINTER(c_int64)]
+    lib.capf_mpjpe.argtypes = [P, P, P, c_int, P, P, c_float]
+    lib.capf_adamw_step.argtypes = [P, P, P, P, P, c_int64] + [c_float] * 5 + [c_int]
     lib.capf_op_pack_conv.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     lib.capf_op_linear.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -159,6 +168,39 @@ class Engine:
         self._check(self.lib.capf_forward(self.h, c_void_p(stream), c_void_p(images.data_ptr()),
                                           c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
                                           c_void_p(out.data_ptr())), "forward")
+
+    # ---- training step
+    def grad_layout(self):
+        """{parameter name: (offset, numel)} inside the flat lifter gradient; total element count."""
+        out, off = {}, c_int64()
+        for i, (name, shape, kind) in enumerate(self.schema()):
+            self._check(self.lib.capf_grad_info(self.h, i, byref(off)), "grad_info")
+            if off.value >= 0:
+                n = 1
+                for d in shape:
+                    n *= d
+                out[name] = (off.value, n)
+        return out, self.lib.capf_grad_elems(self.h)
+
+    def grad_layout_cached(self):
+        if not hasattr(self, "_grad_layout"):
+            self._grad_layout = self.grad_layout()
+        return self._grad_layout
+
+    def forward_train(self, images, k2d, kcrop, out, stream, masks=None):
+        B = images.shape[0]
+        self.ensure_workspace(B)
+        self._check(self.lib.capf_forward_train(self.h, c_void_p(stream), c_void_p(images.data_ptr()),
+                                                c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
+                                                c_void_p(out.data_ptr()),
+                                                c_void_p(masks.data_ptr()) if masks is not None else c_void_p(0)),
+                    "forward_train")
+
+    def backward(self, grad_out, flat_grad, stream, masks=None):
+        B = grad_out.shape[0]
+        self._check(self.lib.capf_backward(self.h, c_void_p(stream), c_void_p(grad_out.data_ptr()), B,
+                                           c_void_p(flat_grad.data_ptr()),
+                                           c_void_p(masks.data_ptr()) if masks is not None else c_void_p(0)), "backward")
 
     def backbone_forward(self, images, stream):
         B = images.shape[0]

@@ -270,7 +270,9 @@ int capf_params_changed(capf_handle* h, void* stream) {
 
 size_t capf_workspace_bytes(const capf_handle* h, int batch) {
     if (!h || batch <= 0) return 0;
-    return h->e.ws_elems_per_frame * (size_t)batch * sizeof(float);
+    size_t n = h->e.ws_elems_per_frame * (size_t)batch;
+    if (h->e.cfg.training) n += h->e.train_elems(batch);
+    return n * sizeof(float);
 }
 
 int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes) {
@@ -292,6 +294,12 @@ int capf_set_debug(capf_handle* h, int on) {
     return CAPF_OK;
 }
 
+static size_t capf_workspace_bytes_impl(const Engine& e, int batch) {
+    size_t n = e.ws_elems_per_frame * (size_t)batch;
+    if (e.cfg.training) n += e.train_elems(batch);
+    return n * sizeof(float);
+}
+
 static int check_run(Engine& e, int batch) {
     if (e.device < 0) {
         e.err = "plan-only handle (device < 0)";
@@ -305,7 +313,7 @@ static int check_run(Engine& e, int batch) {
         e.err = "capf_params_changed has not been called since the last capf_set_param";
         return CAPF_ERR_STATE;
     }
-    if (!e.ws || e.ws_bytes < e.ws_elems_per_frame * (size_t)batch * sizeof(float)) {
+    if (!e.ws || e.ws_bytes < capf_workspace_bytes_impl(e, batch)) {
         e.err = "workspace missing or too small";
         return CAPF_ERR_STATE;
     }
@@ -331,6 +339,50 @@ int capf_backbone_forward(capf_handle* h, void* stream, const float* images_nhwc
     e.images = images_nhwc;
     e.last_batch = batch;
     return e.run(static_cast<hipStream_t>(stream), batch, 0, e.n_backbone_ops);
+}
+
+int capf_forward_train(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
+                       int batch, float* out, const float* drop_masks) {
+    if (!h || !images_nhwc || !k2d || !kcrop_inout || !out) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    if (!e.cfg.training) {
+        e.err = "handle was created with training = 0";
+        return CAPF_ERR_STATE;
+    }
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
+    e.last_batch = batch;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = e.run(s, batch, 0, e.n_backbone_ops);
+    if (rc) return rc;
+    return e.forward_train(s, batch, drop_masks);
+}
+
+int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch, float* flat_grad, const float* drop_masks) {
+    if (!h || !grad_out || !flat_grad) return CAPF_ERR_INVALID;
+    return h->e.backward(static_cast<hipStream_t>(stream), batch, grad_out, flat_grad, drop_masks);
+}
+
+int64_t capf_grad_elems(const capf_handle* h) { return h ? h->e.grad_elems : -1; }
+
+int capf_grad_info(const capf_handle* h, int index, int64_t* offset) {
+    if (!h || index < 0 || index >= (int)h->e.params.size() || !offset) return CAPF_ERR_INVALID;
+    *offset = h->e.grad_off[index];
+    return CAPF_OK;
+}
+
+int capf_mpjpe(void* stream, const float* pred, const float* gt, int rows, float* loss, float* dpred, float grad_scale) {
+    if (!pred || !gt || !loss || rows <= 0) return CAPF_ERR_INVALID;
+    return capf::launch_mpjpe(pred, gt, rows, loss, dpred, grad_scale, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_adamw_step(void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return CAPF_ERR_INVALID;
+    return capf::launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
+                              static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
 int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* kcrop_inout, int batch, float* out) {

@@ -92,6 +92,18 @@ struct NamedTensor {
     int is_int;
 };
 
+// float offsets inside the training region of the workspace (train.cpp :: Engine::train_layout)
+struct TrainLayout {
+    struct Ctx { size_t xh1, rs1, y1, ao, U[4], xh2, rs2, y2, hp, hg; };
+    struct Att { size_t xh1, rs1, y1, qkv, o, xh2, rs2, y2, hp, hg; };
+    size_t X, S[4];
+    Ctx ctx[4];
+    Att res[4], joint[4];
+    size_t xhh, rsh, yh;
+    size_t dX, gA, gB, gC, cat, dU[4], tA, tB, wT, slabs, red;
+    size_t total;
+};
+
 struct Engine {
     capf_config cfg{};
     int device = -1;
@@ -138,6 +150,21 @@ struct Engine {
     void fork(int n);    // open a region of n independent lanes (independent branches run on side streams)
     void set_lane(int l) { cur_lane = l; }
     void join();
+
+    // ---- training step (train.cpp)
+    int feat_buf[4] = {-1, -1, -1, -1}, feat_H[4] = {0, 0, 0, 0}, feat_W[4] = {0, 0, 0, 0}, feat_C[4] = {0, 0, 0, 0};
+    std::vector<int> ctx_ao_pack;        // pack index of [attention_weights | sampling_offsets] per context block
+    std::vector<long> grad_off;          // per parameter: offset in the flat lifter gradient, -1 for the backbone
+    long grad_elems = 0;
+    int train_batch = 0;
+    void train_layout(int B, TrainLayout& L) const;
+    size_t train_elems(int B) const;
+    int forward_train(hipStream_t s, int B, const float* masks);
+    int backward(hipStream_t s, int B, const float* dOut, float* flat_grad, const float* masks);
+    int t_gemm(hipStream_t s, const float* A, RowMap amap, int M, int N, int K, const float* W, int Kpad, const float* bias,
+               float* out, RowMap omap, const float* res, RowMap rmap, int act, const float* rscale, int rs_div);
+    int t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const float* dY, RowMap dymap, int rows, int N, int K,
+                     const float* Xin, RowMap xmap, const float* W, float* dX, RowMap dxmap, bool acc_dx, float* gW, float* gb);
 
     // ---- execution (engine.cpp)
     float* bptr(int buf, int batch) const { return ws + bufs[buf].offset * (size_t)batch; }

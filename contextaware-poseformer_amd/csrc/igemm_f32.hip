@@ -110,6 +110,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
 
     const float* zero = capf_zero_page;
     const int nchunks = p.Kpad / BK;
+    // split-K (rows mode, weight gradients): grid.y slices the chunk range, each slice writes its own slab
+    const int c_begin = blockIdx.y * p.cps;
+    const int c_end = min(nchunks, c_begin + p.cps);
     long a_off[RA];                    // element offset of (row, tap 0, channel 0); rows mode: row base
     unsigned long long a_mask[RA];     // bit t set <=> tap t of this row reads real data
 #pragma unroll
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     auto prepare = [&](int c) {
         if (AMODE == AMODE_ROWS) {
             const int k = c * BK + kq;
-            const bool k_ok = k < p.K;
+            const bool k_ok = k < p.K && c < c_end;
 #pragma unroll
             for (int i = 0; i < RA; ++i) src[i] = (k_ok && a_mask[i]) ? p.A + a_off[i] + k : zero;
         } else {
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) src[RA + i] = (b_src[i] && c < nchunks) ? b_src[i] + c * BK : zero;
+        for (int i = 0; i < RB; ++i) src[RA + i] = (b_src[i] && c < c_end) ? b_src[i] + c * BK : zero;
     };
     // fire load #idx of the prepared chunk into `stage` (LDS image: 8 rows x 128 B per wave instruction)
     auto fire = [&](int idx, int stage) {
@@ -208,13 +211,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     constexpr int PER_STEP = (NLOAD + 1) / 2;
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) {
-        prepare(s);
+        prepare(c_begin + s);
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) fire(i, s);
     }
     int st_read = 0, st_fill = S - 1;
-    prepare(S - 1);              // sources of the chunk fired in iteration 0
-    for (int c = 0; c < nchunks; ++c) {
+    prepare(c_begin + S - 1);    // sources of the chunk fired in iteration 0
+    for (int c = c_begin; c < c_end; ++c) {
         wait_vmcnt<(S - 2) * NLOAD>();
         if (NW > 1) __builtin_amdgcn_s_barrier();
         const float* As = lds + st_read * STAGE;
@@ -275,8 +278,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
         const int m = m0 + wm0 + i * 32 + (lane & 31);
         const bool m_ok = full || m < p.M;
         long o_row = 0, r_row = 0;
+        float rs = 1.0f;            // per-row scale of the branch output (DropPath keep mask / keep_prob)
         if (m_ok) {
-            o_row = PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m);
+            if (p.rscale) rs = p.rscale[m / p.rs_div];
+            o_row = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (long)blockIdx.y * p.split_stride;
             if (p.res) r_row = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : rowmap(p.rmap, m);
         }
 #pragma unroll
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] + bv[g][e] + rv[g][e];
+                    float t = (acc[i][j][4 * g + e] + bv[g][e]) * rs + rv[g][e];
                     if (GELU) { if (p.act == ACT_GELU) t = gelu_erf(t); }
                     if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
                     v[e] = t;
@@ -496,7 +501,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
 template <int NW, int BM, int BN, int WM, int WN, int S>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    dim3 grid(nbm * nbn), block(64 * NW);
+    dim3 grid(nbm * nbn, a.splits > 1 ? a.splits : 1), block(64 * NW);
     const bool plain = a.omap.G == 1 && (!a.res || a.rmap.G == 1);
     if (a.conv) {
         if (!plain) return hipErrorInvalidValue;
@@ -522,6 +527,9 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
     GemmArgs a = a_in;
+    if (a.splits <= 1) { a.splits = 1; a.cps = a.Kpad / BK; a.split_stride = 0; }
+    else if (a.conv || a.bias || a.res) return hipErrorInvalidValue;     // split-K slabs are raw partial sums
+    if (a.rs_div <= 0) a.rs_div = 1;
     // the epilogue's fast path addresses out / res with 32-bit element offsets from their bases
     if (a.omap.G == 1 && (double)a.M * (double)a.omap.S1 >= 4.0e9) return hipErrorInvalidValue;
     if (a.res && a.rmap.G == 1 && (double)a.M * (double)a.rmap.S1 >= 4.0e9) return hipErrorInvalidValue;

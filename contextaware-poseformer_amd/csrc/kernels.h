@@ -36,6 +36,10 @@ struct GemmArgs {
     int act;
     FastDiv fd_hw, fd_wo;   // filled by launch_gemm_f32 (conv mode): division by Ho*Wo and by Wo
     unsigned long long spread;   // conv mode: bits kh*ks set for kh < ks (tap-mask construction)
+    const float* rscale;    // optional per-row scale of (acc + bias): rscale[m / rs_div] (DropPath), or nullptr
+    int rs_div;
+    int splits, cps;        // split-K (rows mode): grid.y slices of `cps` chunks, slab s at out + s*split_stride
+    long split_stride;
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
@@ -86,6 +90,8 @@ struct DeformArgs {
     const float* AO;
     const float* ref;
     int B, J, L, NH, NS;
+    int ld_ao;               // row pitch of AO (0 = 3*NH*NS, the inference layout; 64 in training)
+    const float* dU[4];      // backward only: gradient w.r.t. U[l]
 };
 hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s);
 // tiny multi-head attention: QKV [G*N, 3*heads*d] -> O [G*N, heads*d]; N tokens per group
@@ -93,5 +99,33 @@ hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int
 // head (pose_dformer.py:240): out[r, 0..2] = Linear(LN(X[r,:]))
 hipError_t launch_head(const float* X, const float* g, const float* b, float eps, const float* w,
                        const float* wb, float* out, int rows, int C, int NO, hipStream_t s);
+
+// ---- training step (train_kernels.hip) ----------------------------------------------------------------
+hipError_t launch_layernorm_train(const float* in, RowMap imap, const float* add, RowMap amap, const float* g,
+                                  const float* b, float eps, float* out, float* xhat, float* rstd, int rows, int C,
+                                  hipStream_t s);
+hipError_t launch_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dX,
+                                RowMap omap, float* second, RowMap smap, int rows, int GRP, int C, hipStream_t s);
+// dst[c*dst_stride] (+)= sum_r A[amap(r)+c] * B(r,c); bmode 0 none, 1 B[bmap(r)+c], 2 B[bmap(r)]; scratch >= 64*C floats
+hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
+                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s);
+hipError_t launch_slab_sum(const float* slabs, int nslab, long n, float* dst, hipStream_t s);
+hipError_t launch_gelu_fwd(const float* x, float* y, long n, hipStream_t s);
+hipError_t launch_gelu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t s);
+hipError_t launch_transpose_pad(const float* in, RowMap imap, int M, int C, float* out, int Mp, hipStream_t s);
+hipError_t launch_attention_bwd(const float* qkv, const float* dO, float* dqkv, int groups, int N, int heads, int d,
+                                hipStream_t s);
+hipError_t launch_deform_bwd(const DeformArgs& a, float* dAO, int ldd, hipStream_t s);
+hipError_t launch_mpjpe(const float* pred, const float* gt, int rows, float* loss, float* dpred, float gscale,
+                        hipStream_t s);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        float wd, int step, hipStream_t s);
+// dst[r, :] = src[smap(r), :] * scale[r / div]   (DropPath mask on a gradient), width C
+hipError_t launch_scale_rows(const float* src, RowMap smap, const float* scale, int div, float* dst, int rows, int C,
+                             hipStream_t s);
+// head backward pieces: dY[r, c] = sum_o dOut[r, o] * W[o, c]  (NO <= 4)
+hipError_t launch_head_dgrad(const float* dOut, const float* W, float* dY, int rows, int C, int NO, hipStream_t s);
+// dpos[l, p, c] = sum_b dX[b, p, l, c]
+hipError_t launch_pos_grad(const float* dX, float* dpos, int B, int J, int L1, int C, hipStream_t s);
 
 }  // namespace capf

@@ -176,7 +176,7 @@ __global__ void deform_sample_kernel(DeformArgs a) {
     const int H = a.H[l], W = a.W[l], C = a.C[l];
     const float* feat = a.feat[l] + (long)b * H * W * C;
     const int nk = a.NH * NS;
-    const float* ao = a.AO + ((long)bp * a.L + l) * (3 * nk);
+    const float* ao = a.AO + ((long)bp * a.L + l) * (a.ld_ao ? a.ld_ao : 3 * nk);
     const float rx = a.ref[bp * 2 + 0], ry = a.ref[bp * 2 + 1];
     float* U = a.U[l] + (long)bp * a.NH * C;
     for (int h = 0; h < a.NH; ++h) {

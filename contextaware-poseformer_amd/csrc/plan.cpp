@@ -558,6 +558,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
             const std::string n = "ctx" + std::to_string(i);
             layernorm(*this, n + ".norm1", p + ".norm1", 1e-5f, X, tok, X, tok0, Q, (long)J * L, C);
             const int pk_ao = make_linear_pack(*this, {p + ".attention_weights", p + ".sampling_offsets"});
+            ctx_ao_pack.push_back(pk_ao);
             gemm_rows(*this, n + ".attn_off", pk_ao, Q, row_ld(C), (long)J * L, AO, row_ld(3 * NH * NS), ACT_NONE, -1,
                       row_ld(0));
             {
@@ -711,7 +712,18 @@ bool Engine::build() {
         }
     }
     n_backbone_ops = (int)ops.size();
+    for (int l = 0; l < 4; ++l) {
+        feat_buf[l] = feats[l].buf; feat_H[l] = feats[l].H; feat_W[l] = feats[l].W; feat_C[l] = feats[l].C;
+    }
     build_lifter(feats);
+    // flat gradient layout: the volume_net.* parameters in schema (= registration) order
+    grad_off.assign(params.size(), -1);
+    grad_elems = 0;
+    for (size_t i = 0; i < params.size(); ++i)
+        if (params[i].name.rfind("volume_net.", 0) == 0) {
+            grad_off[i] = grad_elems;
+            grad_elems += params[i].numel();
+        }
     assign_offsets();
     // pack arena layout
     size_t off = 0;

@@ -1,0 +1,403 @@
+// Training step of the lifter: forward that keeps what the backward needs, and the
+// backward itself.  The backbone is frozen (conpose.py:22-25) and runs through the inference plan; its four
+// context maps are constants here, so gradients flow only into the 191 `volume_net.*` parameters
+// (pose_dformer.py:144-208) — exactly the tensors DDP all-reduces in the reference (train.py:361-362).
+//
+// Every product is an igemm_f32 launch: with dY [M,N], X [M,K], W [N,K] (all row-major),
+//   dX = dY . W        -> A = dY (K' = N),            Wp = W^T  [K][Npad]   (transpose_pad of the weight)
+//   dW = dY^T . X      -> A = dY^T [N][Mpad] (K' = M), Wp = X^T  [K][Mpad]   (split-K over M, slabs summed in order)
+//   db = column sums of dY (two-stage deterministic reduction)
+// Gradients are written ONCE each (no accumulation, no atomics) into one flat fp32 buffer laid out in
+// state_dict order, so a single RCCL all-reduce covers what DDP sends in three buckets.
+#include <string.h>
+
+#include <algorithm>
+
+#include "engine.h"
+
+namespace capf {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return CAPF_ERR_HIP;                                                           \
+        }                                                                                  \
+    } while (0)
+
+static size_t r64(size_t n) { return (n + 63) / 64 * 64; }
+static int r32(int n) { return (n + 31) / 32 * 32; }
+
+// ---------------------------------------------------------------------------------------------------
+// layout of the training region (after the inference workspace): offset = cursor; cursor += pf*B + fixed
+// ---------------------------------------------------------------------------------------------------
+void Engine::train_layout(int B, TrainLayout& L) const {
+    const int J = cfg.num_joints, Lv = cfg.levels, L1 = Lv + 1, C = cfg.embed_dim_ratio, D = C * L1;
+    const int NH = cfg.deform_heads;
+    size_t cur = 0;
+    auto take = [&](size_t pf, size_t fixed = 0) {
+        const size_t o = cur;
+        cur += r64(pf * (size_t)B + fixed);
+        return o;
+    };
+    L.X = take((size_t)J * D);
+    for (int l = 0; l < Lv; ++l) L.S[l] = take((size_t)J * feat_C[l]);
+    for (int i = 0; i < Lv; ++i) {
+        TrainLayout::Ctx& c = L.ctx[i];
+        const size_t R = (size_t)J * Lv;
+        c.xh1 = take(R * C); c.rs1 = take(R); c.y1 = take(R * C); c.ao = take(R * 64);
+        for (int l = 0; l < Lv; ++l) c.U[l] = take((size_t)J * NH * feat_C[l]);
+        c.xh2 = take(R * C); c.rs2 = take(R); c.y2 = take(R * C); c.hp = take(R * 2 * C); c.hg = take(R * 2 * C);
+    }
+    for (int g = 0; g < 2; ++g)
+        for (int i = 0; i < Lv; ++i) {
+            TrainLayout::Att& a = g == 0 ? L.res[i] : L.joint[i];
+            const size_t E = (size_t)J * D;       // rows * dim is J*D elements per frame for both groups
+            const size_t R = g == 0 ? (size_t)J * L1 : (size_t)J;
+            a.xh1 = take(E); a.rs1 = take(R); a.y1 = take(E); a.qkv = take(3 * E); a.o = take(E);
+            a.xh2 = take(E); a.rs2 = take(R); a.y2 = take(E); a.hp = take(2 * E); a.hg = take(2 * E);
+        }
+    L.xhh = take((size_t)J * D); L.rsh = take(J); L.yh = take((size_t)J * D);
+    // backward scratch
+    L.dX = take((size_t)J * D);
+    L.gA = take((size_t)J * 3 * D);
+    L.gB = take((size_t)J * 3 * D);
+    L.gC = take((size_t)J * 3 * D);
+    L.cat = take(0, (size_t)64 * (C + 1));
+    for (int l = 0; l < Lv; ++l) L.dU[l] = take((size_t)J * NH * feat_C[l]);
+    const size_t maxNR = (size_t)J * 3 * D;                    // max over linears of (N or K) * rows per frame
+    L.tA = take(maxNR, (size_t)3 * D * 32);
+    L.tB = take(maxNR, (size_t)3 * D * 32);
+    L.wT = take(0, (size_t)3 * D * D + 64 * 2 * D);            // largest transposed weight [K][Npad]
+    L.slabs = take(0, (size_t)16 * 3 * D * D);                 // split-K slabs of the largest weight gradient
+    L.red = take(0, (size_t)64 * 3 * D);
+    L.total = cur;
+}
+
+size_t Engine::train_elems(int B) const {
+    TrainLayout L;
+    train_layout(B, L);
+    return L.total;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------
+int Engine::t_gemm(hipStream_t s, const float* A, RowMap amap, int M, int N, int K, const float* W, int Kpad,
+                   const float* bias, float* out, RowMap omap, const float* res, RowMap rmap, int act,
+                   const float* rscale, int rs_div) {
+    GemmArgs a{};
+    a.A = A; a.Wp = W; a.bias = bias; a.res = res; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.Kpad = Kpad;
+    a.amap = amap; a.omap = omap; a.rmap = rmap; a.act = act;
+    a.rscale = rscale; a.rs_div = rs_div;
+    HIP_TRY(launch_gemm_f32(a, s));
+    return CAPF_OK;
+}
+
+// gradients of y = x W^T + b :  gW [N][K], gb [N], and (optionally) dX (+)= dY W
+int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const float* dY, RowMap dymap, int rows, int N,
+                         int K, const float* Xin, RowMap xmap, const float* W, float* dX, RowMap dxmap, bool acc_dx,
+                         float* gW, float* gb) {
+    float* red = tw + L.red;
+    if (gb) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s));
+    if (gW) {
+        const int Mp = r32(rows);
+        float* tA = tw + L.tA;
+        float* tB = tw + L.tB;
+        HIP_TRY(launch_transpose_pad(dY, dymap, rows, N, tA, Mp, s));
+        HIP_TRY(launch_transpose_pad(Xin, xmap, rows, K, tB, Mp, s));
+        GemmArgs a{};
+        a.A = tA; a.Wp = tB; a.out = gW;
+        a.M = N; a.N = K; a.K = Mp; a.Kpad = Mp;
+        a.amap = row_ld(Mp); a.omap = row_ld(K); a.rmap = row_ld(K);
+        const int tiles = ((N + 63) / 64) * ((K + 63) / 64), chunks = Mp / 32;
+        int splits = std::min(16, std::max(1, 512 / std::max(1, tiles)));
+        splits = std::min(splits, chunks);
+        if (splits > 1) {
+            a.out = tw + L.slabs;
+            a.splits = splits;
+            a.cps = (chunks + splits - 1) / splits;
+            a.splits = (chunks + a.cps - 1) / a.cps;
+            a.split_stride = (long)N * K;
+        }
+        HIP_TRY(launch_gemm_f32(a, s));
+        if (a.splits > 1) HIP_TRY(launch_slab_sum(tw + L.slabs, a.splits, (long)N * K, gW, s));
+    }
+    if (dX) {
+        const int Np = r32(N);
+        float* wT = tw + L.wT;
+        HIP_TRY(launch_transpose_pad(W, row_ld(K), N, K, wT, Np, s));
+        int rc = t_gemm(s, dY, dymap, rows, K, N, wT, Np, nullptr, dX, dxmap, acc_dx ? dX : nullptr, dxmap, ACT_NONE,
+                        nullptr, 1);
+        if (rc) return rc;
+    }
+    return CAPF_OK;
+}
+
+static const float* P(const Engine& e, const std::string& n) { return e.params[e.param_index.at(n)].ptr; }
+
+// ---------------------------------------------------------------------------------------------------
+// forward (training): same math as the inference plan, every intermediate kept
+// masks: DropPath multipliers (0 or 1/keep_prob), or nullptr for "no drop":
+//   ctx[i]: m1[B], m2[B]  |  res[i]: m1[B*J], m2[B*J]  |  joint[i]: m1[B], m2[B]      (i = 0..levels-1)
+// ---------------------------------------------------------------------------------------------------
+int Engine::forward_train(hipStream_t s, int B, const float* masks) {
+    const std::string V = "volume_net";
+    const int J = cfg.num_joints, Lv = cfg.levels, L1 = Lv + 1, C = cfg.embed_dim_ratio, D = C * L1;
+    const int NH = cfg.deform_heads, NS = cfg.deform_samples, HD = C / NH;
+    TrainLayout L;
+    train_layout(B, L);
+    float* tw = ws + ws_elems_per_frame * (size_t)B;
+    float* X = tw + L.X;
+    const float* m_ctx = masks;
+    const float* m_res = masks ? masks + (size_t)2 * Lv * B : nullptr;
+    const float* m_joint = masks ? m_res + (size_t)2 * Lv * B * J : nullptr;
+
+    HIP_TRY(launch_prep_embed(kcrop, k2d, P(*this, V + ".coord_embed.weight"), P(*this, V + ".coord_embed.bias"),
+                              P(*this, V + ".Spatial_pos_embed"), X, B, J, L1, C, s));
+    const float* pos = P(*this, V + ".Spatial_pos_embed");
+    for (int l = 0; l < Lv; ++l) {
+        const std::string fe = V + ".feat_embed." + std::to_string(l);
+        float* S = tw + L.S[l];
+        HIP_TRY(launch_sample_ref(bptr(feat_buf[l], B), kcrop, S, nullptr, B, J, feat_H[l], feat_W[l], feat_C[l], s));
+        int rc = t_gemm(s, S, row_ld(feat_C[l]), B * J, C, feat_C[l], P(*this, fe + ".weight"), feat_C[l],
+                        P(*this, fe + ".bias"), X, row_ld(D, (long)(1 + l) * C), pos, RowMap{J, 0, C, (long)(1 + l) * J * C},
+                        ACT_NONE, nullptr, 1);
+        if (rc) return rc;
+    }
+    const RowMap tok{Lv, D, C, C}, tok0{Lv, D, 0, 0};
+    for (int i = 0; i < Lv && cfg.context_blocks; ++i) {
+        const std::string p = V + ".context_blocks." + std::to_string(i);
+        const TrainLayout::Ctx& c = L.ctx[i];
+        const int R = B * J * Lv;
+        const float* m1 = m_ctx ? m_ctx + (size_t)(2 * i) * B : nullptr;
+        const float* m2 = m_ctx ? m_ctx + (size_t)(2 * i + 1) * B : nullptr;
+        HIP_TRY(launch_layernorm_train(X, tok, X, tok0, P(*this, p + ".norm1.weight"), P(*this, p + ".norm1.bias"), 1e-5f,
+                                       tw + c.y1, tw + c.xh1, tw + c.rs1, R, C, s));
+        const Pack& pk = packs[ctx_ao_pack[i]];
+        int rc = t_gemm(s, tw + c.y1, row_ld(C), R, 3 * NH * NS, C, pack_arena + pk.w_off, pk.Kpad, pack_arena + pk.b_off,
+                        tw + c.ao, row_ld(64), nullptr, row_ld(64), ACT_NONE, nullptr, 1);
+        if (rc) return rc;
+        DeformArgs da{};
+        for (int l = 0; l < Lv; ++l) {
+            da.feat[l] = bptr(feat_buf[l], B);
+            da.H[l] = feat_H[l]; da.W[l] = feat_W[l]; da.C[l] = feat_C[l];
+            da.U[l] = tw + c.U[l];
+        }
+        da.AO = tw + c.ao; da.ref = kcrop; da.B = B; da.J = J; da.L = Lv; da.NH = NH; da.NS = NS; da.ld_ao = 64;
+        HIP_TRY(launch_deform_sample(da, s));
+        for (int l = 0; l < Lv; ++l) {
+            const std::string ep = p + ".embed_proj." + std::to_string(l);
+            const RowMap dst{NH, D, HD, (long)(1 + l) * C};
+            rc = t_gemm(s, tw + c.U[l], row_ld(feat_C[l]), B * J * NH, HD, feat_C[l], P(*this, ep + ".weight"), feat_C[l],
+                        P(*this, ep + ".bias"), X, dst, X, dst, ACT_NONE, m1, J * NH);
+            if (rc) return rc;
+        }
+        HIP_TRY(launch_layernorm_train(X, tok, nullptr, row_ld(0), P(*this, p + ".norm2.weight"), P(*this, p + ".norm2.bias"),
+                                       1e-5f, tw + c.y2, tw + c.xh2, tw + c.rs2, R, C, s));
+        rc = t_gemm(s, tw + c.y2, row_ld(C), R, 2 * C, C, P(*this, p + ".mlp.fc1.weight"), C, P(*this, p + ".mlp.fc1.bias"),
+                    tw + c.hp, row_ld(2 * C), nullptr, row_ld(0), ACT_NONE, nullptr, 1);
+        if (rc) return rc;
+        HIP_TRY(launch_gelu_fwd(tw + c.hp, tw + c.hg, (long)R * 2 * C, s));
+        rc = t_gemm(s, tw + c.hg, row_ld(2 * C), R, C, 2 * C, P(*this, p + ".mlp.fc2.weight"), 2 * C,
+                    P(*this, p + ".mlp.fc2.bias"), X, tok, X, tok, ACT_NONE, m2, J * Lv);
+        if (rc) return rc;
+    }
+    for (int g = 0; g < 2; ++g) {
+        const int dim = g == 0 ? C : D, R = g == 0 ? B * J * L1 : B * J;
+        const int tokens = g == 0 ? L1 : J, groups = g == 0 ? B * J : B, per = g == 0 ? L1 : J;
+        for (int i = 0; i < Lv; ++i) {
+            const std::string p = V + (g == 0 ? ".res_blocks." : ".joint_blocks.") + std::to_string(i);
+            const TrainLayout::Att& a = g == 0 ? L.res[i] : L.joint[i];
+            const float* mb = g == 0 ? m_res : m_joint;
+            const size_t ms = g == 0 ? (size_t)B * J : (size_t)B;
+            const float* m1 = mb ? mb + (size_t)(2 * i) * ms : nullptr;
+            const float* m2 = mb ? mb + (size_t)(2 * i + 1) * ms : nullptr;
+            HIP_TRY(launch_layernorm_train(X, row_ld(dim), nullptr, row_ld(0), P(*this, p + ".norm1.weight"),
+                                           P(*this, p + ".norm1.bias"), 1e-6f, tw + a.y1, tw + a.xh1, tw + a.rs1, R, dim, s));
+            int rc = t_gemm(s, tw + a.y1, row_ld(dim), R, 3 * dim, dim, P(*this, p + ".attn.qkv.weight"), dim,
+                            P(*this, p + ".attn.qkv.bias"), tw + a.qkv, row_ld(3 * dim), nullptr, row_ld(0), ACT_NONE, nullptr, 1);
+            if (rc) return rc;
+            HIP_TRY(launch_attention(tw + a.qkv, tw + a.o, groups, tokens, cfg.num_heads, dim / cfg.num_heads, s));
+            rc = t_gemm(s, tw + a.o, row_ld(dim), R, dim, dim, P(*this, p + ".attn.proj.weight"), dim,
+                        P(*this, p + ".attn.proj.bias"), X, row_ld(dim), X, row_ld(dim), ACT_NONE, m1, per);
+            if (rc) return rc;
+            HIP_TRY(launch_layernorm_train(X, row_ld(dim), nullptr, row_ld(0), P(*this, p + ".norm2.weight"),
+                                           P(*this, p + ".norm2.bias"), 1e-6f, tw + a.y2, tw + a.xh2, tw + a.rs2, R, dim, s));
+            rc = t_gemm(s, tw + a.y2, row_ld(dim), R, 2 * dim, dim, P(*this, p + ".mlp.fc1.weight"), dim,
+                        P(*this, p + ".mlp.fc1.bias"), tw + a.hp, row_ld(2 * dim), nullptr, row_ld(0), ACT_NONE, nullptr, 1);
+            if (rc) return rc;
+            HIP_TRY(launch_gelu_fwd(tw + a.hp, tw + a.hg, (long)R * 2 * dim, s));
+            rc = t_gemm(s, tw + a.hg, row_ld(2 * dim), R, dim, 2 * dim, P(*this, p + ".mlp.fc2.weight"), 2 * dim,
+                        P(*this, p + ".mlp.fc2.bias"), X, row_ld(dim), X, row_ld(dim), ACT_NONE, m2, per);
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(launch_layernorm_train(X, row_ld(D), nullptr, row_ld(0), P(*this, V + ".head.0.weight"), P(*this, V + ".head.0.bias"),
+                                   1e-5f, tw + L.yh, tw + L.xhh, tw + L.rsh, B * J, D, s));
+    HIP_TRY(launch_head(X, P(*this, V + ".head.0.weight"), P(*this, V + ".head.0.bias"), 1e-5f, P(*this, V + ".head.1.weight"),
+                        P(*this, V + ".head.1.bias"), out, B * J, D, 3, s));
+    train_batch = B;
+    return CAPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward: dOut [B,1,17,3] -> flat_grad (state_dict order of volume_net.*)
+// ---------------------------------------------------------------------------------------------------
+int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const float* masks) {
+    if (B != train_batch) {
+        err = "capf_backward: no matching capf_forward_train for this batch";
+        return CAPF_ERR_STATE;
+    }
+    const std::string V = "volume_net";
+    const int J = cfg.num_joints, Lv = cfg.levels, L1 = Lv + 1, C = cfg.embed_dim_ratio, D = C * L1;
+    const int NH = cfg.deform_heads, NS = cfg.deform_samples, HD = C / NH;
+    TrainLayout L;
+    train_layout(B, L);
+    float* tw = ws + ws_elems_per_frame * (size_t)B;
+    float* dX = tw + L.dX;
+    float* gA = tw + L.gA;
+    float* gB = tw + L.gB;
+    float* red = tw + L.red;
+    auto G = [&](const std::string& n) { return flat + grad_off[param_index.at(n)]; };
+    const float* m_ctx = masks;
+    const float* m_res = masks ? masks + (size_t)2 * Lv * B : nullptr;
+    const float* m_joint = masks ? m_res + (size_t)2 * Lv * B * J : nullptr;
+
+    HIP_TRY(hipMemsetAsync(dX, 0, sizeof(float) * (size_t)B * J * D, s));
+
+    // ---- head: out = LN(X) W^T + b
+    {
+        const int R = B * J;
+        HIP_TRY(launch_colreduce(dOut, row_ld(3), nullptr, row_ld(0), 0, R, 3, G(V + ".head.1.bias"), 1, 0, red, s));
+        for (int o = 0; o < 3; ++o)
+            HIP_TRY(launch_colreduce(tw + L.yh, row_ld(D), dOut + o, row_ld(3), 2, R, D, G(V + ".head.1.weight") + (size_t)o * D, 1, 0, red, s));
+        HIP_TRY(launch_head_dgrad(dOut, P(*this, V + ".head.1.weight"), gA, R, D, 3, s));
+        HIP_TRY(launch_colreduce(gA, row_ld(D), tw + L.xhh, row_ld(D), 1, R, D, G(V + ".head.0.weight"), 1, 0, red, s));
+        HIP_TRY(launch_colreduce(gA, row_ld(D), nullptr, row_ld(0), 0, R, D, G(V + ".head.0.bias"), 1, 0, red, s));
+        HIP_TRY(launch_layernorm_bwd(gA, tw + L.xhh, tw + L.rsh, P(*this, V + ".head.0.weight"), dX, row_ld(D), nullptr, row_ld(0), R, 1, D, s));
+    }
+
+    // ---- the MLP half of any block: x_out = x + m2 * fc2(gelu(fc1(LN2(x))))
+    auto mlp_bwd = [&](const std::string& p, RowMap xm, int R, int dim, float eps_unused, size_t xh2, size_t rs2, size_t y2,
+                       size_t hp, size_t hg, const float* m2, int div) -> int {
+        (void)eps_unused;
+        const float* dBr = dX;
+        RowMap dm = xm;
+        if (m2) {      // gradient of the branch output = dX * mask
+            HIP_TRY(launch_scale_rows(dX, xm, m2, div, gB, R, dim, s));
+            dBr = gB;
+            dm = row_ld(dim);
+        }
+        int rc = t_linear_bwd(s, L, tw, dBr, dm, R, dim, 2 * dim, tw + hg, row_ld(2 * dim), P(*this, p + ".mlp.fc2.weight"), gA,
+                              row_ld(2 * dim), false, G(p + ".mlp.fc2.weight"), G(p + ".mlp.fc2.bias"));
+        if (rc) return rc;
+        HIP_TRY(launch_gelu_bwd(tw + hp, gA, gA, (long)R * 2 * dim, s));
+        rc = t_linear_bwd(s, L, tw, gA, row_ld(2 * dim), R, 2 * dim, dim, tw + y2, row_ld(dim), P(*this, p + ".mlp.fc1.weight"), gB,
+                          row_ld(dim), false, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"));
+        if (rc) return rc;
+        HIP_TRY(launch_colreduce(gB, row_ld(dim), tw + xh2, row_ld(dim), 1, R, dim, G(p + ".norm2.weight"), 1, 0, red, s));
+        HIP_TRY(launch_colreduce(gB, row_ld(dim), nullptr, row_ld(0), 0, R, dim, G(p + ".norm2.bias"), 1, 0, red, s));
+        HIP_TRY(launch_layernorm_bwd(gB, tw + xh2, tw + rs2, P(*this, p + ".norm2.weight"), dX, xm, nullptr, row_ld(0), R, 1, dim, s));
+        return CAPF_OK;
+    };
+
+    // ---- attention blocks, joint group first (reverse of the forward)
+    for (int g = 1; g >= 0; --g) {
+        const int dim = g == 0 ? C : D, R = g == 0 ? B * J * L1 : B * J;
+        const int tokens = g == 0 ? L1 : J, groups = g == 0 ? B * J : B, per = g == 0 ? L1 : J;
+        for (int i = Lv - 1; i >= 0; --i) {
+            const std::string p = V + (g == 0 ? ".res_blocks." : ".joint_blocks.") + std::to_string(i);
+            const TrainLayout::Att& a = g == 0 ? L.res[i] : L.joint[i];
+            const float* mb = g == 0 ? m_res : m_joint;
+            const size_t ms = g == 0 ? (size_t)B * J : (size_t)B;
+            const float* m1 = mb ? mb + (size_t)(2 * i) * ms : nullptr;
+            const float* m2 = mb ? mb + (size_t)(2 * i + 1) * ms : nullptr;
+            int rc = mlp_bwd(p, row_ld(dim), R, dim, 0.f, a.xh2, a.rs2, a.y2, a.hp, a.hg, m2, per);
+            if (rc) return rc;
+            const float* dBr = dX;
+            if (m1) {
+                HIP_TRY(launch_scale_rows(dX, row_ld(dim), m1, per, gB, R, dim, s));
+                dBr = gB;
+            }
+            rc = t_linear_bwd(s, L, tw, dBr, row_ld(dim), R, dim, dim, tw + a.o, row_ld(dim), P(*this, p + ".attn.proj.weight"), gA,
+                              row_ld(dim), false, G(p + ".attn.proj.weight"), G(p + ".attn.proj.bias"));
+            if (rc) return rc;
+            HIP_TRY(launch_attention_bwd(tw + a.qkv, gA, gB, groups, tokens, cfg.num_heads, dim / cfg.num_heads, s));
+            rc = t_linear_bwd(s, L, tw, gB, row_ld(3 * dim), R, 3 * dim, dim, tw + a.y1, row_ld(dim), P(*this, p + ".attn.qkv.weight"),
+                              gA, row_ld(dim), false, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"));
+            if (rc) return rc;
+            HIP_TRY(launch_colreduce(gA, row_ld(dim), tw + a.xh1, row_ld(dim), 1, R, dim, G(p + ".norm1.weight"), 1, 0, red, s));
+            HIP_TRY(launch_colreduce(gA, row_ld(dim), nullptr, row_ld(0), 0, R, dim, G(p + ".norm1.bias"), 1, 0, red, s));
+            HIP_TRY(launch_layernorm_bwd(gA, tw + a.xh1, tw + a.rs1, P(*this, p + ".norm1.weight"), dX, row_ld(dim), nullptr, row_ld(0), R, 1, dim, s));
+        }
+    }
+
+    // ---- deformable context blocks
+    const RowMap tok{Lv, D, C, C}, tok0{Lv, D, 0, 0};
+    for (int i = Lv - 1; i >= 0 && cfg.context_blocks; --i) {
+        const std::string p = V + ".context_blocks." + std::to_string(i);
+        const TrainLayout::Ctx& c = L.ctx[i];
+        const int R = B * J * Lv;
+        const float* m1 = m_ctx ? m_ctx + (size_t)(2 * i) * B : nullptr;
+        const float* m2 = m_ctx ? m_ctx + (size_t)(2 * i + 1) * B : nullptr;
+        int rc = mlp_bwd(p, tok, R, C, 0.f, c.xh2, c.rs2, c.y2, c.hp, c.hg, m2, J * Lv);
+        if (rc) return rc;
+        DeformArgs da{};
+        for (int l = 0; l < Lv; ++l) {
+            const std::string ep = p + ".embed_proj." + std::to_string(l);
+            const RowMap src{NH, D, HD, (long)(1 + l) * C};      // row (b,p,h) -> dX[b,p,1+l,h*HD:]
+            const float* dBr = dX;
+            RowMap dm = src;
+            if (m1) {
+                HIP_TRY(launch_scale_rows(dX, src, m1, J * NH, gB, B * J * NH, HD, s));
+                dBr = gB;
+                dm = row_ld(HD);
+            }
+            rc = t_linear_bwd(s, L, tw, dBr, dm, B * J * NH, HD, feat_C[l], tw + c.U[l], row_ld(feat_C[l]), P(*this, ep + ".weight"),
+                              tw + L.dU[l], row_ld(feat_C[l]), false, G(ep + ".weight"), G(ep + ".bias"));
+            if (rc) return rc;
+            da.feat[l] = bptr(feat_buf[l], B);
+            da.H[l] = feat_H[l]; da.W[l] = feat_W[l]; da.C[l] = feat_C[l];
+            da.dU[l] = tw + L.dU[l];
+        }
+        da.AO = tw + c.ao; da.ref = kcrop; da.B = B; da.J = J; da.L = Lv; da.NH = NH; da.NS = NS; da.ld_ao = 64;
+        HIP_TRY(launch_deform_bwd(da, gA, 64, s));                                  // gA = dAO [R, 64]
+        // [attention_weights | sampling_offsets] were one GEMM with N = 48: gradients land in a [48, C] temp
+        const Pack& pk = packs[ctx_ao_pack[i]];
+        const int NA = NH * NS, NO = 2 * NH * NS;
+        float* gWcat = tw + L.cat;                      // [48][C]
+        float* gbcat = tw + L.cat + (size_t)64 * C;     // [48]
+        float* dq = tw + L.gC;                          // [R, C]
+        rc = t_linear_bwd(s, L, tw, gA, row_ld(64), R, NA + NO, C, tw + c.y1, row_ld(C), pack_arena + pk.w_off, dq,
+                          row_ld(C), false, gWcat, gbcat);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(G(p + ".attention_weights.weight"), gWcat, sizeof(float) * NA * C, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(G(p + ".sampling_offsets.weight"), gWcat + (size_t)NA * C, sizeof(float) * NO * C, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(G(p + ".attention_weights.bias"), gbcat, sizeof(float) * NA, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(G(p + ".sampling_offsets.bias"), gbcat + NA, sizeof(float) * NO, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(launch_colreduce(dq, row_ld(C), tw + c.xh1, row_ld(C), 1, R, C, G(p + ".norm1.weight"), 1, 0, red, s));
+        HIP_TRY(launch_colreduce(dq, row_ld(C), nullptr, row_ld(0), 0, R, C, G(p + ".norm1.bias"), 1, 0, red, s));
+        HIP_TRY(launch_layernorm_bwd(dq, tw + c.xh1, tw + c.rs1, P(*this, p + ".norm1.weight"), dX, tok, dX, tok0, R, Lv, C, s));
+    }
+
+    // ---- embeddings: X[b,p,0] = coord_embed(k2d) + pos[0,p];  X[b,p,1+l] = feat_embed_l(S_l) + pos[1+l,p]
+    {
+        const int R = B * J;
+        for (int l = 0; l < Lv; ++l) {
+            const std::string fe = V + ".feat_embed." + std::to_string(l);
+            int rc = t_linear_bwd(s, L, tw, dX, row_ld(D, (long)(1 + l) * C), R, C, feat_C[l], tw + L.S[l], row_ld(feat_C[l]),
+                                  P(*this, fe + ".weight"), nullptr, row_ld(0), false, G(fe + ".weight"), G(fe + ".bias"));
+            if (rc) return rc;
+        }
+        HIP_TRY(launch_colreduce(dX, row_ld(D), nullptr, row_ld(0), 0, R, C, G(V + ".coord_embed.bias"), 1, 0, red, s));
+        for (int j = 0; j < 2; ++j)
+            HIP_TRY(launch_colreduce(dX, row_ld(D), k2d + j, row_ld(2), 2, R, C, G(V + ".coord_embed.weight") + j, 2, 0, red, s));
+        HIP_TRY(launch_pos_grad(dX, G(V + ".Spatial_pos_embed"), B, J, L1, C, s));
+    }
+    return CAPF_OK;
+}
+
+}  // namespace capf

@@ -1,0 +1,570 @@
+// Kernels of the lifter's TRAINING step: LayerNorm with saved statistics
+// and its backward, deterministic column reductions (bias / LayerNorm-affine / pos-embed gradients),
+// GELU forward/backward on saved pre-activations, zero-padded transposes that turn the weight- and
+// input-gradient products into the K-contiguous GEMMs of igemm_f32.hip, backward of the tiny attention
+// and of the deformable sampler (gradient w.r.t. sampling positions and attention logits only — the
+// feature maps come from the frozen backbone, conpose.py:22-25), MPJPE loss + gradient (loss.py:16-22)
+// and a fused AdamW update (train.py:345).  No atomics: every reduction has a fixed order.
+#include "kernels.h"
+
+namespace capf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ long rowmap_t(const RowMap& r, int m) {
+    if (r.G == 1) return (long)m * r.S1 + r.off;
+    const int q = m / r.G;
+    return (long)q * r.S1 + (long)(m - q * r.G) * r.S2 + r.off;
+}
+
+// ---- LayerNorm forward that keeps xhat = (x - mean) * rstd and rstd for the backward --------------
+template <int MAXV>
+__global__ void layernorm_train_kernel(const float* __restrict__ in, RowMap imap, const float* __restrict__ add,
+                                       RowMap amap, const float* __restrict__ g, const float* __restrict__ b,
+                                       float eps, float* __restrict__ out, float* __restrict__ xhat,
+                                       float* __restrict__ rstd_out, int rows, int C) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = in + rowmap_t(imap, r);
+    const float* a = add ? add + rowmap_t(amap, r) : nullptr;
+    float v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        float t = 0.f;
+        if (c < C) {
+            t = x[c];
+            if (a) t += a[c];
+        }
+        v[i] = t;
+        s += t;
+    }
+    const float mean = wave_sum_t(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_t(q) / (float)C + eps);
+    if (lane == 0) rstd_out[r] = rstd;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            const float h = (v[i] - mean) * rstd;
+            xhat[(long)r * C + c] = h;
+            out[(long)r * C + c] = h * g[c] + b[c];
+        }
+    }
+}
+
+hipError_t launch_layernorm_train(const float* in, RowMap imap, const float* add, RowMap amap, const float* g,
+                                  const float* b, float eps, float* out, float* xhat, float* rstd, int rows, int C,
+                                  hipStream_t s) {
+    dim3 grid((rows + 3) / 4), block(256);
+    if (C <= 128)
+        hipLaunchKernelGGL(layernorm_train_kernel<2>, grid, block, 0, s, in, imap, add, amap, g, b, eps, out, xhat, rstd, rows, C);
+    else if (C <= 640)
+        hipLaunchKernelGGL(layernorm_train_kernel<10>, grid, block, 0, s, in, imap, add, amap, g, b, eps, out, xhat, rstd, rows, C);
+    else if (C <= 1536)
+        hipLaunchKernelGGL(layernorm_train_kernel<24>, grid, block, 0, s, in, imap, add, amap, g, b, eps, out, xhat, rstd, rows, C);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- LayerNorm backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma --------
+// One wave handles GRP consecutive rows; dx is ACCUMULATED into dX at omap(row) and, when `second` is
+// given, the sum over the group is accumulated at smap(first row of the group) (the query of a
+// DeformableBlock is LN(x_l + x_0): token 0 receives the sum over the 4 level rows, pose_dformer.py:120).
+template <int MAXV>
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                     float* __restrict__ dX, RowMap omap, float* __restrict__ second, RowMap smap,
+                                     int groups, int GRP, int C) {
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= groups) return;
+    const int lane = threadIdx.x & 63;
+    float acc2[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc2[i] = 0.f;
+    for (int t = 0; t < GRP; ++t) {
+        const int r = w * GRP + t;
+        float gv[MAXV], hv[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            gv[i] = hv[i] = 0.f;
+            if (c < C) {
+                gv[i] = dy[(long)r * C + c] * gamma[c];
+                hv[i] = xhat[(long)r * C + c];
+            }
+            s1 += gv[i];
+            s2 += gv[i] * hv[i];
+        }
+        const float m1 = wave_sum_t(s1) / (float)C, m2 = wave_sum_t(s2) / (float)C;
+        const float rs = rstd[r];
+        float* dst = dX + rowmap_t(omap, r);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float dx = rs * (gv[i] - m1 - hv[i] * m2);
+                dst[c] += dx;
+                acc2[i] += dx;
+            }
+        }
+    }
+    if (second) {
+        float* dst = second + rowmap_t(smap, w * GRP);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) dst[c] += acc2[i];
+        }
+    }
+}
+
+hipError_t launch_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dX,
+                                RowMap omap, float* second, RowMap smap, int rows, int GRP, int C, hipStream_t s) {
+    const int groups = rows / GRP;
+    dim3 grid((groups + 3) / 4), block(256);
+    if (C <= 128)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, dy, xhat, rstd, gamma, dX, omap, second, smap, groups, GRP, C);
+    else if (C <= 640)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<10>, grid, block, 0, s, dy, xhat, rstd, gamma, dX, omap, second, smap, groups, GRP, C);
+    else if (C <= 1536)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<24>, grid, block, 0, s, dy, xhat, rstd, gamma, dX, omap, second, smap, groups, GRP, C);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- deterministic column reduction:  dst[c] = sum_r A[amap(r) + c] * B(r, c) -----------------------
+// B absent -> 1; bmode 1: B[bmap(r) + c]; bmode 2: B[bmap(r)] (one scalar per row).
+// Stage 1: grid (C/64, chunks), 256 threads = 4 row lanes x 64 columns, fixed row order per lane and a
+// fixed 4-way LDS reduce; stage 2 sums the chunk partials in order.  No atomics.
+__global__ void colreduce_kernel(const float* __restrict__ A, RowMap amap, const float* __restrict__ Bm, RowMap bmap,
+                                 int bmode, float* __restrict__ partial, int rows, int C, int rows_per_chunk) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(rows, r0 + rows_per_chunk);
+    float acc = 0.f;
+    if (col < C) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            float v = A[rowmap_t(amap, r) + col];
+            if (bmode == 1) v *= Bm[rowmap_t(bmap, r) + col];
+            else if (bmode == 2) v *= Bm[rowmap_t(bmap, r)];
+            acc += v;
+        }
+    }
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < C)
+        partial[(long)blockIdx.y * C + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void colreduce_final_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dst,
+                                       long dst_stride, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(long)k * C + c];
+    float* d = dst + (long)c * dst_stride;
+    *d = accumulate ? *d + s : s;
+}
+
+hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
+                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s) {
+    int chunks = (rows + 511) / 512;
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    const int rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, A, amap, Bm, bmap, bmode, scratch,
+                       rows, C, rpc);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, chunks, C, dst, dst_stride,
+                       accumulate);
+    return hipGetLastError();
+}
+
+// dst[i] (+)= sum_k slabs[k][i]  (split-K partial slabs of the weight-gradient GEMMs)
+__global__ void slab_sum_kernel(const float* __restrict__ slabs, int nslab, long n, float* __restrict__ dst) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[(long)k * n + i];
+        dst[i] = s;
+    }
+}
+
+hipError_t launch_slab_sum(const float* slabs, int nslab, long n, float* dst, hipStream_t s) {
+    const long want = (n + 255) / 256;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, slabs, nslab, n, dst);
+    return hipGetLastError();
+}
+
+// ---- exact (erf) GELU on a saved pre-activation, and its derivative --------------------------------
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+}
+
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float cdf = 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * v[e] * v[e]);
+            o[e] = g[e] * (cdf + v[e] * pdf);
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+hipError_t launch_gelu_fwd(const float* x, float* y, long n, hipStream_t s) {
+    const long n4 = n / 4, want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, y, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_gelu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t s) {
+    const long n4 = n / 4, want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, x, dy, dx, n4);
+    return hipGetLastError();
+}
+
+// ---- out[c][m] = in[imap(m) + c] for m < M, 0 for M <= m < Mp  (32x32 LDS tiles) -------------------
+__global__ void transpose_pad_kernel(const float* __restrict__ in, RowMap imap, int M, int C, float* __restrict__ out,
+                                     int Mp) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows of 32
+    for (int k = ty; k < 32; k += 8) {
+        const int m = m0 + k, c = c0 + tx;
+        tile[k][tx] = (m < M && c < C) ? in[rowmap_t(imap, m) + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, m = m0 + tx;
+        if (c < C && m < Mp) out[(long)c * Mp + m] = tile[tx][k];
+    }
+}
+
+hipError_t launch_transpose_pad(const float* in, RowMap imap, int M, int C, float* out, int Mp, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Mp + 31) / 32, (C + 31) / 32), dim3(256), 0, s, in, imap, M, C, out, Mp);
+    return hipGetLastError();
+}
+
+// ---- backward of the tiny attention (Attention.forward pose_dformer.py:46-59) -----------------------
+// One thread per (group, head, token t): as QUERY t it produces dq_t, as KEY t it produces dk_t and dv_t
+// (probabilities are recomputed from the saved qkv; N <= 17 so the N^2 recompute is a few hundred FMAs).
+template <int NMAX>
+__global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                     float* __restrict__ dqkv, int groups, int N, int heads, int d, float scale) {
+    const long tt = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long total = (long)groups * heads * N;
+    if (tt >= total) return;
+    const int t = (int)(tt % N);
+    const int h = (int)((tt / N) % heads);
+    const long g = tt / ((long)N * heads);
+    const int Cq = 3 * heads * d, Co = heads * d;
+    const float* qb = qkv + (g * N) * Cq + h * d;
+    const float* kb = qb + heads * d;
+    const float* vb = qb + 2 * heads * d;
+    const float* dob = dO + (g * N) * Co + h * d;
+
+    auto dot = [&](const float* a, const float* b) {
+        float s = 0.f;
+        for (int c = 0; c < d; c += 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a + c), y = *reinterpret_cast<const f32x4*>(b + c);
+            s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+        return s;
+    };
+    // probabilities / score gradients of row i: p[j], ds[j]
+    auto row = [&](int i, float* p, float* ds) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            p[j] = (j < N) ? dot(qb + (long)i * Cq, kb + (long)j * Cq) * scale : -INFINITY;
+            mx = fmaxf(mx, p[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) { p[j] = (j < N) ? expf(p[j] - mx) : 0.f; den += p[j]; }
+        float D = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            p[j] /= den;
+            ds[j] = (j < N) ? dot(dob + (long)i * Co, vb + (long)j * Cq) : 0.f;    // dp_ij
+            D += p[j] * ds[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) ds[j] = p[j] * (ds[j] - D);
+    };
+
+    float p[NMAX], ds[NMAX];
+    // query role
+    row(t, p, ds);
+    float* dq = dqkv + (g * N + t) * Cq + h * d;
+    for (int c = 0; c < d; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < N) s += ds[j] * kb[(long)j * Cq + c];
+        dq[c] = s * scale;
+    }
+    // key role: column t of P and dS
+    float pk[NMAX], dsk[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        pk[i] = dsk[i] = 0.f;
+        if (i < N) {
+            row(i, p, ds);
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j == t) { pk[i] = p[j]; dsk[i] = ds[j]; }
+        }
+    }
+    float* dk = dq + heads * d;
+    float* dv = dq + 2 * heads * d;
+    for (int c = 0; c < d; ++c) {
+        float sk = 0.f, sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if (i < N) {
+                sk += dsk[i] * qb[(long)i * Cq + c];
+                sv += pk[i] * dob[(long)i * Co + c];
+            }
+        dk[c] = sk * scale;
+        dv[c] = sv;
+    }
+}
+
+hipError_t launch_attention_bwd(const float* qkv, const float* dO, float* dqkv, int groups, int N, int heads, int d,
+                                hipStream_t s) {
+    if (d % 4 != 0) return hipErrorInvalidValue;
+    const long total = (long)groups * heads * N;
+    const float scale = 1.0f / sqrtf((float)d);
+    dim3 grid((unsigned)((total + 63) / 64)), block(64);
+    if (N <= 5)
+        hipLaunchKernelGGL(attention_bwd_kernel<5>, grid, block, 0, s, qkv, dO, dqkv, groups, N, heads, d, scale);
+    else if (N <= 17)
+        hipLaunchKernelGGL(attention_bwd_kernel<17>, grid, block, 0, s, qkv, dO, dqkv, groups, N, heads, d, scale);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- backward of the deformable sampler w.r.t. attention logits and offset pre-activations ----------
+// forward (lifter.hip): U[c] = sum_s w_s v_s[c],  w = softmax(logit),  v_s = bilinear_border(feat, tanh(o_s) + ref)
+//   dw_s   = sum_c dU[c] v_s[c]
+//   dpos_s = w_s * sum_c dU[c] dv_s[c]/dpos  * (size-1)/2 * [coordinate not clipped]   (ATen grid_sampler
+//            backward: clip_coordinates_set_grad zeroes the gradient where the unnormalised coordinate is
+//            <= 0 or >= size-1)
+//   dlogit = softmax backward, do = dpos * (1 - tanh^2)
+// One block per (b, p); wave = level; lanes stride over channels; wave-level reductions.
+template <int NS>
+__global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd) {
+    const int bp = blockIdx.x;
+    const int l = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    if (l >= a.L) return;
+    const int b = bp / a.J;
+    const int H = a.H[l], W = a.W[l], C = a.C[l];
+    const float* feat = a.feat[l] + (long)b * H * W * C;
+    const int nk = a.NH * NS;
+    const long row = (long)bp * a.L + l;
+    const float* ao = a.AO + row * ldd;
+    float* dao = dAO + row * ldd;
+    const float rx = a.ref[bp * 2 + 0], ry = a.ref[bp * 2 + 1];
+    const float* dU = a.dU[l] + (long)bp * a.NH * C;
+    for (int h = 0; h < a.NH; ++h) {
+        float ws[NS], th[NS][2], mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ws[s] = ao[h * NS + s]; mx = fmaxf(mx, ws[s]); }
+        float den = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ws[s] = expf(ws[s] - mx); den += ws[s]; }
+        float dw[NS], gx[NS], gy[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ws[s] /= den;
+            const int k = h * NS + s;
+            th[s][0] = tanhf(ao[nk + 2 * k + 0]);
+            th[s][1] = tanhf(ao[nk + 2 * k + 1]);
+            const float ux = ((th[s][0] + rx + 1.0f) / 2.0f) * (float)(W - 1);
+            const float uy = ((th[s][1] + ry + 1.0f) / 2.0f) * (float)(H - 1);
+            const float mxk = (ux <= 0.f || ux >= (float)(W - 1)) ? 0.f : 1.f;
+            const float myk = (uy <= 0.f || uy >= (float)(H - 1)) ? 0.f : 1.f;
+            const float x = fminf((float)(W - 1), fmaxf(ux, 0.f)), y = fminf((float)(H - 1), fmaxf(uy, 0.f));
+            const float xf = floorf(x), yf = floorf(y);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            const bool vx = x0 + 1 <= W - 1, vy = y0 + 1 <= H - 1;       // +1 corner inside the map
+            const int xb = vx ? x0 + 1 : x0, yb = vy ? y0 + 1 : y0;
+            const float* p00 = feat + ((long)y0 * W + x0) * C;
+            const float* p01 = feat + ((long)y0 * W + xb) * C;
+            const float* p10 = feat + ((long)yb * W + x0) * C;
+            const float* p11 = feat + ((long)yb * W + xb) * C;
+            float a_dw = 0.f, a_gx = 0.f, a_gy = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float g = dU[(long)h * C + c];
+                const float f00 = p00[c], f01 = vx ? p01[c] : 0.f, f10 = vy ? p10[c] : 0.f, f11 = (vx && vy) ? p11[c] : 0.f;
+                a_dw += g * (((f00 * (wx0 * wy0) + f01 * (wx1 * wy0)) + f10 * (wx0 * wy1)) + f11 * (wx1 * wy1));
+                a_gx += g * ((f01 - f00) * wy0 + (f11 - f10) * wy1);
+                a_gy += g * ((f10 - f00) * wx0 + (f11 - f01) * wx1);
+            }
+            dw[s] = wave_sum_t(a_dw);
+            gx[s] = wave_sum_t(a_gx) * ws[s] * 0.5f * (float)(W - 1) * mxk;
+            gy[s] = wave_sum_t(a_gy) * ws[s] * 0.5f * (float)(H - 1) * myk;
+        }
+        float dotw = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dotw += ws[s] * dw[s];
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k = h * NS + s;
+                dao[k] = ws[s] * (dw[s] - dotw);
+                dao[nk + 2 * k + 0] = gx[s] * (1.f - th[s][0] * th[s][0]);
+                dao[nk + 2 * k + 1] = gy[s] * (1.f - th[s][1] * th[s][1]);
+            }
+        }
+    }
+    if (lane == 0)
+        for (int k = 3 * nk; k < ldd; ++k) dao[k] = 0.f;      // padding columns of the 64-wide row
+}
+
+hipError_t launch_deform_bwd(const DeformArgs& a, float* dAO, int ldd, hipStream_t s) {
+    if (a.NS != 4 || a.L > 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(deform_bwd_kernel<4>, dim3(a.B * a.J), dim3(64 * a.L), 0, s, a, dAO, ldd);
+    return hipGetLastError();
+}
+
+// ---- MPJPE (loss.py:16-22): loss = mean_r ||pred_r - gt_r||_2 ; dpred = (pred - gt) / (||.|| * rows) ---
+__global__ void mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int rows,
+                             float* __restrict__ loss, float* __restrict__ dpred, float gscale) {
+    __shared__ float red[1024];
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float dx = pred[r * 3 + 0] - gt[r * 3 + 0], dy = pred[r * 3 + 1] - gt[r * 3 + 1],
+                    dz = pred[r * 3 + 2] - gt[r * 3 + 2];
+        const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+        acc += n;
+        if (dpred) {
+            const float inv = n > 0.f ? gscale / (n * (float)rows) : 0.f;
+            dpred[r * 3 + 0] = dx * inv; dpred[r * 3 + 1] = dy * inv; dpred[r * 3 + 2] = dz * inv;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)rows;
+}
+
+hipError_t launch_mpjpe(const float* pred, const float* gt, int rows, float* loss, float* dpred, float gscale,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(mpjpe_kernel, dim3(1), dim3(1024), 0, s, pred, gt, rows, loss, dpred, gscale);
+    return hipGetLastError();
+}
+
+// ---- fused AdamW over one flat parameter buffer (torch.optim.AdamW semantics, train.py:345) -----------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi;
+    }
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        float wd, int step, hipStream_t s) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    const long want = (n + 255) / 256;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2,
+                       eps, wd, bc1, bc2s);
+    return hipGetLastError();
+}
+
+// dst[r, :] = src[smap(r), :] * scale[r / div]
+__global__ void scale_rows_kernel(const float* __restrict__ src, RowMap smap, const float* __restrict__ scale, int div,
+                                  float* __restrict__ dst, int rows, int C) {
+    const long total = (long)rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i - (long)r * C);
+        dst[i] = src[rowmap_t(smap, r) + c] * (scale ? scale[r / div] : 1.0f);
+    }
+}
+
+hipError_t launch_scale_rows(const float* src, RowMap smap, const float* scale, int div, float* dst, int rows, int C,
+                             hipStream_t s) {
+    const long want = ((long)rows * C + 255) / 256;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, src, smap, scale, div,
+                       dst, rows, C);
+    return hipGetLastError();
+}
+
+__global__ void head_dgrad_kernel(const float* __restrict__ dOut, const float* __restrict__ W, float* __restrict__ dY,
+                                  int rows, int C, int NO) {
+    const long total = (long)rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i - (long)r * C);
+        float s = 0.f;
+        for (int o = 0; o < NO; ++o) s += dOut[r * NO + o] * W[(long)o * C + c];
+        dY[i] = s;
+    }
+}
+
+hipError_t launch_head_dgrad(const float* dOut, const float* W, float* dY, int rows, int C, int NO, hipStream_t s) {
+    const long want = ((long)rows * C + 255) / 256;
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, dOut, W, dY, rows, C, NO);
+    return hipGetLastError();
+}
+
+__global__ void pos_grad_kernel(const float* __restrict__ dX, float* __restrict__ dpos, int B, int J, int L1, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over (l, p, c)
+    if (i >= L1 * J * C) return;
+    const int c = i % C, p = (i / C) % J, l = i / (C * J);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dX[(((long)b * J + p) * L1 + l) * C + c];
+    dpos[i] = s;
+}
+
+hipError_t launch_pos_grad(const float* dX, float* dpos, int B, int J, int L1, int C, hipStream_t s) {
+    const int n = L1 * J * C;
+    hipLaunchKernelGGL(pos_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dX, dpos, B, J, L1, C);
+    return hipGetLastError();
+}
+
+}  // namespace capf

@@ -58,6 +58,7 @@ def make_capf_config(config, height=256, width=192, context_blocks=True):
     c.compute_dtype = 0
     c.max_batch = MAX_BATCH
     c.height, c.width = height, width
+    c.training = 1                  # workspace also holds what capf_backward needs (6.4 MB/frame)
     return c
 
 

@@ -17,6 +17,33 @@ from capf.lib import CapfError, Engine
 from . import _native
 
 
+class _LifterStep(torch.autograd.Function):
+    """Autograd boundary of the native training step: forward = capf_forward_train, backward =
+    capf_backward into one flat gradient buffer whose slices are returned as the parameter gradients
+    (so torch optimizers, DDP hooks and `capf.dist.allreduce_mean_` all see ordinary .grad tensors)."""
+
+    @staticmethod
+    def forward(ctx, owner, eng, images, k2d, kcrop, masks, names, *params):
+        out = torch.empty(images.shape[0], 1, owner.num_joints, 3, dtype=torch.float32, device=images.device)
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        eng.forward_train(images, k2d, kcrop, out, stream, masks)
+        ctx.eng, ctx.masks, ctx.names, ctx.owner = eng, masks, names, owner
+        ctx.keep = (k2d, kcrop)     # capf_backward re-reads the keypoints / normalised ref: keep them alive
+        ctx.shapes = [p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.eng
+        layout, total = eng.grad_layout_cached()
+        flat = torch.empty(total, dtype=torch.float32, device=grad_out.device)
+        stream = torch.cuda.current_stream(grad_out.device).cuda_stream
+        eng.backward(grad_out.contiguous(), flat, stream, ctx.masks)
+        ctx.owner.last_flat_grad = flat
+        grads = tuple(flat[layout[n][0]: layout[n][0] + layout[n][1]].view(shp) for n, shp in zip(ctx.names, ctx.shapes))
+        return (None,) * 7 + grads
+
+
 class CA_PF(nn.Module):
     def __init__(self, config, device="cuda:0"):
         super().__init__()
@@ -38,6 +65,8 @@ class CA_PF(nn.Module):
             for p in self.backbone.parameters():
                 p.requires_grad = False
 
+        self.drop_path_rate = 0.2   # PoseTransformer(drop_path_rate=0.2), dpr = linspace(0, rate, levels) (pose_dformer.py:147,187)
+        self.last_flat_grad = None  # flat fp32 gradient of volume_net.* written by the last backward
         self._engines = {}          # (device index, H, W) -> Engine
         self._dirty = True          # parameters (re)loaded / moved since the last pack
         self._lifter_versions = None
@@ -99,9 +128,33 @@ class CA_PF(nn.Module):
         out = torch.empty(B, 1, self.num_joints, 3, dtype=torch.float32, device=images.device)
         stream = torch.cuda.current_stream(images.device).cuda_stream
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.volume_net.parameters()):
-            raise NotImplementedError("lifter backward is not built yet: wrap inference in torch.no_grad()")
+            named = [(n, p) for n, p in self.volume_net.named_parameters()]
+            if not all(p.requires_grad for _, p in named):
+                raise NotImplementedError("partially frozen volume_net is not supported by the native backward")
+            names = tuple("volume_net." + n for n, _ in named)
+            return _LifterStep.apply(self, eng, images, k2d, keypoints_2d_cpn_crop, self._drop_masks(B, images.device),
+                                     names, *[p for _, p in named])
         eng.forward(images, k2d, keypoints_2d_cpn_crop, out, stream)
         return out
+
+    def _drop_masks(self, B, device):
+        """DropPath multipliers for one training step (timm semantics: keep-mask / keep_prob per sample;
+        a 'sample' is one batch element for context / joint blocks and one (frame, joint) row group for the
+        level blocks, whose batch axis is (b p) — pose_dformer.py:231-234).  None when nothing is dropped."""
+        levels = self._config.model.poseformer.levels
+        if not self.training or self.drop_path_rate <= 0.0:
+            return None
+        rates = torch.linspace(0, self.drop_path_rate, levels).tolist()
+        parts = []
+        for per in (B, B * self.num_joints, B):
+            for r in rates:
+                for _ in range(2):
+                    if r == 0.0:
+                        parts.append(torch.ones(per, device=device))
+                    else:
+                        keep = 1.0 - r
+                        parts.append(torch.empty(per, device=device).bernoulli_(keep).div_(keep))
+        return torch.cat(parts).contiguous()
 
     def engine_for(self, images):
         """The native engine serving inputs of this shape/device (tests, bench)."""

@@ -69,6 +69,7 @@ typedef struct capf_config {
     int32_t compute_dtype;     /* capf_dtype: MFMA operand type of the backbone convs / lifter GEMMs */
     int32_t max_batch;         /* workspace is sized for this many frames */
     int32_t height, width;     /* input image size (256x256, 256x192, 384x288, ...) */
+    int32_t training;          /* 1: size the workspace for capf_forward_train / capf_backward as well */
 } capf_config;
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -113,6 +114,27 @@ int capf_forward(capf_handle* h, void* stream, const float* images_nhwc, const f
 /* Backbone only: writes nothing to `out`; the four context maps stay in the workspace (NHWC) and
  * can be read through capf_tensor("feat0".."feat3").  Replaces self.backbone(images) conpose.py:38. */
 int capf_backbone_forward(capf_handle* h, void* stream, const float* images_nhwc, int batch);
+
+/* ---- training step of the lifter (the backbone is frozen, conpose.py:22-25) --
+ * capf_forward_train: capf_forward that keeps the lifter's intermediates for capf_backward.
+ *     Replaces model(images, k2d, kcrop) under model.train() (train.py:183).  drop_masks: the DropPath
+ *     multipliers (0 or 1/keep_prob; timm DropPath, pose_dformer.py:71,101) laid out as
+ *     ctx[i]{m1[B],m2[B]} | res[i]{m1[B*17],m2[B*17]} | joint[i]{m1[B],m2[B]}, i = 0..levels-1; NULL = no drop.
+ * capf_backward: replaces loss.backward() through the lifter (train.py:195): grad_out [B,1,17,3] ->
+ *     flat_grad, one fp32 buffer holding the gradient of every volume_net.* parameter in schema order
+ *     (capf_grad_info), each written exactly once (no atomics) — so ONE all-reduce covers DDP's traffic.
+ * capf_mpjpe: MPJPE.forward (loss.py:16-22) + its gradient w.r.t. pred (scaled by grad_scale).
+ * capf_adamw_step: torch.optim.AdamW update (train.py:345) of one flat parameter buffer.            */
+int capf_forward_train(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
+                       float* kcrop_inout, int batch, float* out, const float* drop_masks);
+int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch, float* flat_grad,
+                  const float* drop_masks);
+int64_t capf_grad_elems(const capf_handle* h);
+int capf_grad_info(const capf_handle* h, int param_index, int64_t* offset);   /* -1: not a lifter parameter */
+int capf_mpjpe(void* stream, const float* pred, const float* gt, int rows, float* loss, float* dpred,
+               float grad_scale);
+int capf_adamw_step(void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
 
 /* Lifter only, on the context maps left in the workspace by the last capf_backbone_forward /
  * capf_forward of the same batch.  Replaces self.volume_net(...) conpose.py:40

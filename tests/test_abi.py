@@ -41,12 +41,19 @@ def test_schema_equals_reference_state_dict(backbone):
     from capf import Engine
     from mvn.models import _native
     want = json.load(open(os.path.join(ROOT, "tests", "golden", f"schema_{backbone}.json")))
-    eng = Engine(_native.make_capf_config(_cfg(backbone), 256, 192), device=None)
+    c = _native.make_capf_config(_cfg(backbone), 256, 192)
+    eng = Engine(c, device=None)
     got = {n: list(s) for n, s, k in eng.schema()}
     assert got == want
     launches, flops = eng.stats(1)
     assert launches > 100 and flops > 1e10
-    assert eng.workspace_bytes(4) == 4 * eng.workspace_bytes(1) > 0
+    assert eng.workspace_bytes(4) > eng.workspace_bytes(1) > 0          # inference + training regions
+    layout, total = eng.grad_layout()
+    lifter = {n: s for n, s in want.items() if n.startswith("volume_net.")}
+    assert set(layout) == set(lifter) and total == sum(int(__import__("math").prod(s)) for s in lifter.values())
+    c.training = 0
+    inf = Engine(c, device=None)
+    assert inf.workspace_bytes(4) == 4 * inf.workspace_bytes(1) > 0      # activations scale with the batch
 
 
 @pytest.mark.parametrize("backbone", ["hrnet_32", "cpn"])

@@ -1,0 +1,88 @@
+"""GPU: the native training step of the lifter (SURVEY.md §8a rows A12 + T) against gradients captured
+from the REAL reference (oracle/make_goldens.py: model.train(), backbone.eval(), DropPath forced off,
+MPJPE loss, loss.backward()) on the same synthetic checkpoint and inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, make_model
+from golden_cases import CASES, case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _train_step(name, drop_path=0.0):
+    from capf import synth
+    from mvn.models.loss import MPJPE
+    case = CASES[name]
+    model, sd = make_model(case["backbone"], device="cuda", wseed=case["wseed"], bn=case["bn"])
+    model.train(); model.backbone.eval(); model.volume_net.train()
+    model.drop_path_rate = drop_path
+    img, k2d, kc = case_inputs(case)
+    _, _, _, gt = synth.synth_inputs(case["B"], case["H"], case["W"], seed=case["iseed"], crop_range=case["crop"], with_gt=True)
+    pred = model(img.cuda(), k2d.cuda(), kc.cuda())
+    loss = MPJPE()(pred, gt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return model, pred, loss
+
+
+def test_loss_and_gradients_match_reference():
+    g = load_golden("w32_256x256_b2")
+    model, pred, loss = _train_step("w32_256x256_b2")
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["out"], atol=1e-3)
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-5
+    named = dict(model.named_parameters())
+    assert not any(p.grad is not None for p in model.backbone.parameters())
+    # a few full gradients
+    for key in [k for k in g.files if k.startswith("grad:")]:
+        want = g[key]
+        got = named[key[5:]].grad.cpu().numpy()
+        scale = max(1e-6, np.abs(want).max())
+        err = np.abs(got - want).max() / scale
+        print(f"{key[5:]:60s} max|grad| {scale:.3e} rel err {err:.2e}")
+        assert err < 2e-3, key
+    # and the norm of EVERY lifter gradient
+    names = [str(n) for n in g["gradnorm_names"]]
+    norms = g["gradnorms"]
+    worst = 0.0
+    for n, want in zip(names, norms):
+        got = named[n].grad.double().norm().item()
+        rel = abs(got - want) / max(1e-7, want)
+        worst = max(worst, rel)
+        assert rel < 2e-3, (n, got, want)
+    print("worst relative gradient-norm error", worst)
+    assert len(names) == 191
+
+
+def test_flat_gradient_and_fused_adamw_match_torch():
+    """The flat buffer capf_backward writes is what .grad views alias; one fused AdamW step on the flattened
+    parameters equals torch.optim.AdamW on a copy."""
+    from capf.optim import FusedAdamW, flatten_
+    model, pred, loss = _train_step("w32_256x256_b2")
+    vn = model.volume_net
+    ref_params = [p.detach().clone().requires_grad_(True) for p in vn.parameters()]
+    for rp, p in zip(ref_params, vn.parameters()):
+        rp.grad = p.grad.detach().clone()
+    opt = torch.optim.AdamW(ref_params, lr=6.4e-4, weight_decay=0.1)
+    opt.step()
+    flat_g = torch.cat([p.grad.reshape(-1) for p in vn.parameters()])
+    flat_p = flatten_(vn)
+    FusedAdamW(flat_p, lr=6.4e-4, weight_decay=0.1).step(flat_g)
+    torch.cuda.synchronize()
+    for rp, p in zip(ref_params, vn.parameters()):
+        assert (rp.detach() - p.detach()).abs().max().item() < 2e-6
+    # parameters changed in place -> the next forward must repack and give a different prediction
+    img, k2d, kc = case_inputs(CASES["w32_256x256_b2"])
+    with torch.no_grad():
+        pred2 = model(img.cuda(), k2d.cuda(), kc.cuda())
+    assert (pred2 - pred.detach()).abs().max().item() > 1e-5
+
+
+def test_droppath_masks_scale_branches():
+    """With DropPath on, the step still runs, stays finite, and differs from the no-drop prediction."""
+    torch.manual_seed(0)
+    _, pred_drop, loss = _train_step("w32_256x256_b2", drop_path=0.5)
+    _, pred_nodrop, _ = _train_step("w32_256x256_b2", drop_path=0.0)
+    assert torch.isfinite(pred_drop).all() and torch.isfinite(loss)
+    assert (pred_drop - pred_nodrop).abs().max().item() > 1e-4
