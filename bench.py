@@ -33,7 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 64; 512 with --train)")
+    ap.add_argument("--train", action="store_true", help="BASELINE.json configs[3]: training step (frozen backbone forward, "
+                    "lifter forward+backward, MPJPE, gradient all-reduce, fused AdamW) instead of inference")
     ap.add_argument("--backbone", default="hrnet_32", choices=["hrnet_32", "hrnet_48", "cpn"])
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=256)
@@ -111,16 +113,37 @@ def main():
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
 
-    B, H, W = a.batch, a.height, a.width
-    img, k2d, kc = synth.synth_inputs(B, H, W, seed=1000 + rank, crop_range=(192, 256))
-    img, k2d, kc0 = img.to(dev), k2d.to(dev), kc.to(dev)
+    B, H, W = a.batch or (512 if a.train else 64), a.height, a.width
+    img, k2d, kc, gt = synth.synth_inputs(B, H, W, seed=1000 + rank, crop_range=(192, 256), with_gt=True)
+    img, k2d, kc0, gt = img.to(dev), k2d.to(dev), kc.to(dev), gt.to(dev)
     kc_work = kc0.clone()
     stream = torch.cuda.current_stream(dev)
     model.engine_for(img).set_lanes(a.lanes)
 
-    def step():
-        kc_work.copy_(kc0)             # the forward normalises its 3rd argument in place (conpose.py:34-35)
-        return model(img, k2d, kc_work)
+    if a.train:
+        from capf.optim import FusedAdamW, flatten_
+        from mvn.models.loss import MPJPE
+        model.train(); model.backbone.eval(); model.volume_net.train()      # train.py:144-148
+        cdist.broadcast_state_(model.volume_net)                             # DDP ctor broadcast (C1)
+        flat_p = flatten_(model.volume_net)
+        opt = FusedAdamW(flat_p, lr=6.4e-4, weight_decay=0.1)                # train.py:345, human36m.yaml:58
+        crit = MPJPE()
+
+        def step():
+            kc_work.copy_(kc0)
+            pred = model(img, k2d, kc_work)                                  # DropPath active (dpr 0..0.2)
+            loss = crit(pred, gt)
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            flat_g = model.last_flat_grad
+            cdist.allreduce_mean_(flat_g)                                    # ONE RCCL all-reduce of 56.4 MB (C3)
+            opt.step(flat_g)
+            model.lifter_params_changed()
+            return pred.detach()
+    else:
+        def step():
+            kc_work.copy_(kc0)         # the forward normalises its 3rd argument in place (conpose.py:34-35)
+            return model(img, k2d, kc_work)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -128,7 +151,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.no_grad():
+    with (torch.enable_grad() if a.train else torch.no_grad()):
         for _ in range(a.warmup):
             out = step()
         fence()
@@ -169,7 +192,7 @@ def main():
         # WRITE_SIZE in separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tfile) and (a.backbone, B, H, W) == ("hrnet_32", 64, 256, 256):
+        if os.path.exists(tfile) and (a.backbone, B, H, W, a.train) == ("hrnet_32", 64, 256, 256, False):
             traffic = json.load(open(tfile)).get(dname, {}).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -192,8 +215,10 @@ def main():
             "metric": "frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch {B}/GPU {a.backbone} {H}x{W} image + 17 kpts -> 17x3, "
-                                   f"PoseFormer lifter embed 128 levels 4, fp32 inference",
+            "config": {"workload": (f"configs[3]: TRAINING step, batch {B}/GPU {a.backbone} {H}x{W} (frozen backbone forward, lifter "
+                                    f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), fp32" if a.train else
+                                    f"configs[1]: batch {B}/GPU {a.backbone} {H}x{W} image + 17 kpts -> 17x3, "
+                                    f"PoseFormer lifter embed 128 levels 4, fp32 inference"),
                        "frames_per_step": B * world, "parallelism": f"dp{world} (independent frames, no collective)",
                        "launches_per_step": launches, "gflop_per_frame": round(flops / B / 1e9, 3)},
             "end_to_end_tflops": round(fps * flops / B / 1e12, 2),

@@ -10,7 +10,7 @@ F32, BF16 = 0, 1
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
-    "capf_set_param", "capf_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
+    "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
@@ -58,6 +58,7 @@ def load_library():
     lib.capf_param_info.argtypes = [H, c_int, POINTER(c_char_p), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
     lib.capf_set_param.argtypes = [H, c_char_p, c_void_p, POINTER(c_int64), c_int]
     lib.capf_params_changed.argtypes = [H, c_void_p]
+    lib.capf_lifter_params_changed.argtypes = [H, c_void_p]
     lib.capf_workspace_bytes.argtypes = [H, c_int]
     lib.capf_workspace_bytes.restype = c_size_t
     lib.capf_set_workspace.argtypes = [H, c_void_p, c_size_t]
@@ -148,6 +149,9 @@ class Engine:
 
     def params_changed(self, stream=0):
         self._check(self.lib.capf_params_changed(self.h, c_void_p(stream)), "params_changed")
+
+    def lifter_params_changed(self, stream=0):
+        self._check(self.lib.capf_lifter_params_changed(self.h, c_void_p(stream)), "lifter_params_changed")
 
     # ---- workspace
     def workspace_bytes(self, batch):

@@ -19,7 +19,7 @@ namespace capf {
     } while (0)
 
 // Rebuild the private packed copies from the borrowed parameters.
-int Engine::repack(hipStream_t s) {
+int Engine::repack(hipStream_t s, bool lifter_only) {
     for (const Param& p : params) {
         if (p.kind == CAPF_P_BN_NBT) continue;
         if (!p.ptr) {
@@ -29,6 +29,7 @@ int Engine::repack(hipStream_t s) {
     }
     for (const Pack& pk : packs) {
         if (pk.direct) continue;
+        if (lifter_only && pk.kind == 0) continue;      // conv+BN packs belong to the frozen backbone
         float* W = pack_arena + pk.w_off;
         float* B = pack_arena + pk.b_off;
         if (pk.kind == 0) {
@@ -257,6 +258,15 @@ int capf_set_param(capf_handle* h, const char* name, const void* dev_ptr, const 
     p.ptr = static_cast<const float*>(dev_ptr);
     e.packed = false;
     return CAPF_OK;
+}
+
+int capf_lifter_params_changed(capf_handle* h, void* stream) {
+    if (!h) return CAPF_ERR_INVALID;
+    if (h->e.device < 0 || !h->e.packed) {
+        h->e.err = "capf_params_changed must have run once before capf_lifter_params_changed";
+        return CAPF_ERR_STATE;
+    }
+    return h->e.repack(static_cast<hipStream_t>(stream), true);
 }
 
 int capf_params_changed(capf_handle* h, void* stream) {

@@ -168,7 +168,7 @@ struct Engine {
 
     // ---- execution (engine.cpp)
     float* bptr(int buf, int batch) const { return ws + bufs[buf].offset * (size_t)batch; }
-    int repack(hipStream_t s);
+    int repack(hipStream_t s, bool lifter_only = false);
     int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr);
     GemmArgs gemm_args(const Op& op, int batch) const;
 };

@@ -85,6 +85,14 @@ class CA_PF(nn.Module):
         weights, manual .data edits).  volume_net parameters are tracked automatically."""
         self._dirty = True
 
+    def lifter_params_changed(self):
+        """Call after an update of volume_net parameters that torch cannot see (capf.optim.FusedAdamW writes
+        them from its own kernel); torch optimizers bump tensor versions and are picked up automatically."""
+        stream = torch.cuda.current_stream().cuda_stream
+        for eng in self._engines.values():
+            if eng._bound:
+                eng.lifter_params_changed(stream)
+
     def _engine(self, images):
         dev = images.device
         if dev.type != "cuda":
@@ -109,7 +117,7 @@ class CA_PF(nn.Module):
                 eng._bound = {}
                 eng.bind_state({k: v.data for k, v in state.items()}, stream)
             else:
-                eng.params_changed(stream)
+                eng.lifter_params_changed(stream)      # only volume_net values moved (optimizer step)
             eng._packed_versions = lifter_versions
             if all(e._packed_versions == lifter_versions and e._bound for e in self._engines.values()):
                 self._dirty = False

@@ -97,6 +97,10 @@ int capf_set_param(capf_handle* h, const char* name, const void* dev_ptr, const 
  * Stream-ordered on `stream` (hipStream_t passed as void*). */
 int capf_params_changed(capf_handle* h, void* stream);
 
+/* Same, restricted to the private copies derived from volume_net.* parameters (the frozen backbone's
+ * folded conv weights are left alone): what a training step needs after its optimizer update. */
+int capf_lifter_params_changed(capf_handle* h, void* stream);
+
 /* ---- workspace (activations); caller-owned so the host allocator (torch) stays in charge ----- */
 size_t capf_workspace_bytes(const capf_handle* h, int batch);
 int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes);
