@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "contextaware-poseformer_amd"))
 
-PEAK_TFLOPS = {"f32": 157.3}          # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}          # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: backbone convs on bf16 MFMA (configs[2]/[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
     ap.add_argument("--lanes", type=int, default=1, help="1: independent backbone branches on side streams (default); 0: one stream")
     return ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     cfg.model.backbone.fix_weights = True
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg).eval()
+        model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32").eval()
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
 
@@ -187,7 +188,7 @@ def main():
         achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
         gemm_ms = sum(e[0] for k, e in acc.items() if k.startswith("igemm"))
         gemm_fl = sum(e[1] for k, e in acc.items() if k.startswith("igemm"))
-        peak = PEAK_TFLOPS["f32"]
+        peak = PEAK_TFLOPS[a.dtype]
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected
         traffic = None
@@ -214,7 +215,7 @@ def main():
         result = {
             "metric": "frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (f"configs[3]: TRAINING step, batch {B}/GPU {a.backbone} {H}x{W} (frozen backbone forward, lifter "
                                     f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), fp32" if a.train else
                                     f"configs[1]: batch {B}/GPU {a.backbone} {H}x{W} image + 17 kpts -> 17x3, "

@@ -13,7 +13,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
-    "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
+    "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
 ]
 
 
@@ -84,6 +84,8 @@ def load_library():
     lib.capf_op_pack_conv.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     lib.capf_op_linear.argtypes = [P, P, P, P, P, P] + [c_int] * 4
+    lib.capf_op_pack_conv_bf16.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
+    lib.capf_op_conv_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     _lib = lib
     return lib
 
@@ -235,6 +237,8 @@ class Engine:
         for s in shp:
             n *= s
         off = (ptr.value - self._ws.data_ptr()) // 4
+        if rc == 2:       # bf16 tensor: two elements per float slot
+            return self._ws[off:off + (n + 1) // 2].view(torch.bfloat16)[:n].view(*shp).clone()
         flat = self._ws[off:off + n]
         if rc == 1:
             flat = flat.view(torch.int32)
@@ -304,6 +308,36 @@ def conv_nhwc(x, wp, bias, ks, stride=1, act=0, residual=None):
     rc = lib.capf_op_conv(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, ks, stride, act)
     if rc:
         raise CapfError(f"capf_op_conv failed ({rc})")
+    return y
+
+
+def pack_conv_bf16(w, bn=None, eps=1e-5):
+    """-> (bf16 packed weights [Cout, Kpad64], fp32 bias [Cout])."""
+    import torch
+    lib = load_library()
+    co, ci, ks, _ = w.shape
+    kpad = (ks * ks * ci + 63) // 64 * 64
+    wp = torch.empty(co, kpad, device=w.device, dtype=torch.bfloat16)
+    bias = torch.empty(co, device=w.device)
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    rc = lib.capf_op_pack_conv_bf16(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci, ks)
+    if rc:
+        raise CapfError(f"capf_op_pack_conv_bf16 failed ({rc})")
+    return wp, bias
+
+
+def conv_nhwc_bf16(x, wp, bias, ks, stride=1, act=0, residual=None):
+    """x [B,H,W,Cin] cuda bf16 NHWC -> [B,Ho,Wo,Cout] bf16."""
+    import torch
+    lib = load_library()
+    B, H, W, ci = x.shape
+    co = wp.shape[0]
+    pad = ks // 2
+    ho, wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    y = torch.empty(B, ho, wo, co, device=x.device, dtype=torch.bfloat16)
+    rc = lib.capf_op_conv_bf16(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, ks, stride, act)
+    if rc:
+        raise CapfError(f"capf_op_conv_bf16 failed ({rc})")
     return y
 
 

@@ -6,9 +6,35 @@
 namespace capf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels of an NHWC tensor stored as fp32 (16 B) or bf16 (8 B); arithmetic is always fp32
+__device__ __forceinline__ unsigned short f2bf_e(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 load4(const float* base, long i4) {
+    if (!BF) return reinterpret_cast<const f32x4*>(base)[i4];
+    const u16x4 h = reinterpret_cast<const u16x4*>(base)[i4];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __uint_as_float((unsigned)h[e] << 16);
+    return v;
+}
+template <bool BF>
+__device__ __forceinline__ void store4(float* base, long i4, f32x4 v) {
+    if (!BF) { reinterpret_cast<f32x4*>(base)[i4] = v; return; }
+    u16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = f2bf_e(v[e]);
+    reinterpret_cast<u16x4*>(base)[i4] = h;
+}
 
 // ---- BN fold + re-layout of a conv weight (eval-mode BatchNorm, pose_hrnet.py:72-75 etc.) ---------
 //   y = (conv(x) - mean) / sqrt(var + eps) * gamma + beta  ==  conv_{w*s}(x) + (beta - mean*s)
+template <bool BF>
 __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ mean,
                                  const float* __restrict__ var, float eps, float* __restrict__ Wp,
@@ -24,7 +50,8 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
             const int kh = tap / ks, kw = tap - kh * ks;
             v = w[(((long)n * Cin + ci) * ks + kh) * ks + kw] * sc;
         }
-        Wp[i] = v;
+        if (BF) reinterpret_cast<unsigned short*>(Wp)[i] = f2bf_e(v);
+        else Wp[i] = v;
         if (k == 0 && bias) bias[n] = gamma ? beta[n] - mean[n] * sc : 0.f;
     }
 }
@@ -34,8 +61,19 @@ hipError_t launch_pack_conv(const float* w, const float* gamma, const float* bet
                             int ks, int Kpad, hipStream_t s) {
     const long total = (long)Cout * Kpad;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, Wp,
+    hipLaunchKernelGGL(pack_conv_kernel<false>, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, Wp,
                        bias, Cout, Cin, ks, Kpad);
+    return hipGetLastError();
+}
+
+// same fold, weights written as bf16 [Cout][Kpad] (Kpad a multiple of 64), bias stays fp32
+hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float* beta, const float* mean,
+                                 const float* var, float eps, void* Wp_bf16, float* bias, int Cout, int Cin, int ks,
+                                 int Kpad, hipStream_t s) {
+    const long total = (long)Cout * Kpad;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_conv_kernel<true>, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps,
+                       reinterpret_cast<float*>(Wp_bf16), bias, Cout, Cin, ks, Kpad);
     return hipGetLastError();
 }
 
@@ -56,6 +94,7 @@ hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad,
 
 // ---- HRNet fuse: out = relu(sum_i nearest_up(in_i))  (pose_hrnet.py:294-301, nn.Upsample nearest) --
 // Input i has resolution (H >> shift_i, W >> shift_i); nearest upsampling by 2^s reads (h>>s, w>>s).
+template <bool BF>
 __global__ void fuse_sum_kernel(FuseSumArgs a) {
     const int C4 = a.C >> 2;
     const long total = (long)a.B * a.H * a.W * C4;
@@ -73,7 +112,7 @@ __global__ void fuse_sum_kernel(FuseSumArgs a) {
                 const int s = a.shift[k];
                 const int hs = a.H >> s, ws = a.W >> s;
                 const long off = ((((long)b * hs + (h >> s)) * ws + (w >> s)) * C4 + c4);
-                const f32x4 v = reinterpret_cast<const f32x4*>(a.in[k])[off];
+                const f32x4 v = load4<BF>(a.in[k], off);
                 acc = k == 0 ? v : acc + v;          // same order as the reference: ((x0 + x1) + x2) + x3
             }
         }
@@ -81,7 +120,7 @@ __global__ void fuse_sum_kernel(FuseSumArgs a) {
             acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f);
             acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
         }
-        reinterpret_cast<f32x4*>(a.out)[i] = acc;
+        store4<BF>(a.out, i, acc);
     }
 }
 
@@ -89,11 +128,13 @@ hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.H * a.W * (a.C >> 2);
     const long want = (total + 255) / 256;
     const int blocks = (int)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL(fuse_sum_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (a.bf16) hipLaunchKernelGGL(fuse_sum_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fuse_sum_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 // ---- 3x3 stride-2 pad-1 max pool (networks/resnet.py:104, :140) ----------------------------------
+template <bool BF>
 __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                int C, int Ho, int Wo) {
     const int C4 = C >> 2;
@@ -112,20 +153,23 @@ __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__
             for (int kw = 0; kw < 3; ++kw) {
                 const int wi = wo * 2 - 1 + kw;
                 if ((unsigned)wi >= (unsigned)W) continue;
-                const f32x4 v = reinterpret_cast<const f32x4*>(in)[(((long)b * H + hi) * W + wi) * C4 + c4];
+                const f32x4 v = load4<BF>(in, (((long)b * H + hi) * W + wi) * C4 + c4);
                 m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]);
                 m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
             }
         }
-        reinterpret_cast<f32x4*>(out)[i] = m;
+        store4<BF>(out, i, m);
     }
 }
 
 hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
-                               hipStream_t s) {
+                               hipStream_t s, int bf16) {
     const long total = (long)B * Ho * Wo * (C >> 2);
     const long want = (total + 255) / 256;
-    hipLaunchKernelGGL(maxpool_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
+    if (bf16)
+        hipLaunchKernelGGL(maxpool_kernel<true>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo);
+    else
+    hipLaunchKernelGGL(maxpool_kernel<false>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
                        W, C, Ho, Wo);
     return hipGetLastError();
 }
@@ -133,6 +177,7 @@ hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W,
 // ---- bilinear resize, align_corners=True (globalNet.py:40, refineNet.py:61) ----------------------
 // ATen upsample_bilinear2d: src = dst * (in-1)/(out-1) (0 if out == 1); i0 = (int)src, i1 = i0 + (i0 < in-1);
 // l1 = src - i0, l0 = 1 - l1;  out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).
+template <bool BF>
 __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                 int C, int Ho, int Wo, float sh, float sw) {
     const int C4 = C >> 2;
@@ -148,24 +193,27 @@ __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict_
         const int h0 = (int)fh, w0 = (int)fw;
         const int h1 = h0 + (h0 < H - 1), w1 = w0 + (w0 < W - 1);
         const float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-        const f32x4* src = reinterpret_cast<const f32x4*>(in) + (long)b * H * W * C4 + c4;
-        const f32x4 v00 = src[((long)h0 * W + w0) * C4], v01 = src[((long)h0 * W + w1) * C4];
-        const f32x4 v10 = src[((long)h1 * W + w0) * C4], v11 = src[((long)h1 * W + w1) * C4];
+        const long sb = (long)b * H * W * C4 + c4;
+        const f32x4 v00 = load4<BF>(in, sb + ((long)h0 * W + w0) * C4), v01 = load4<BF>(in, sb + ((long)h0 * W + w1) * C4);
+        const f32x4 v10 = load4<BF>(in, sb + ((long)h1 * W + w0) * C4), v11 = load4<BF>(in, sb + ((long)h1 * W + w1) * C4);
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             r[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
-        reinterpret_cast<f32x4*>(out)[i] = r;
+        store4<BF>(out, i, r);
     }
 }
 
 hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
-                                  hipStream_t s) {
+                                  hipStream_t s, int bf16) {
     const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const long total = (long)B * Ho * Wo * (C >> 2);
     const long want = (total + 255) / 256;
-    hipLaunchKernelGGL(bilinear_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
+    if (bf16)
+        hipLaunchKernelGGL(bilinear_kernel<true>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
+    else
+    hipLaunchKernelGGL(bilinear_kernel<false>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
                        W, C, Ho, Wo, sh, sw);
     return hipGetLastError();
 }

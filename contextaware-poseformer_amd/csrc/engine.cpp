@@ -32,7 +32,10 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
         if (lifter_only && pk.kind == 0) continue;      // conv+BN packs belong to the frozen backbone
         float* W = pack_arena + pk.w_off;
         float* B = pack_arena + pk.b_off;
-        if (pk.kind == 0) {
+        if (pk.kind == 0 && pk.bf16) {
+            HIP_TRY(launch_pack_conv_bf16(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
+                                          params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks, pk.Kpad, s));
+        } else if (pk.kind == 0) {
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
                                      params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks,
                                      pk.Kpad, s));
@@ -71,6 +74,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.ks = op.ks; a.stride = op.stride; a.pad = op.pad;
     a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
     a.act = op.act;
+    a.out_bf16 = op.out_bf16;
     return a;
 }
 
@@ -101,7 +105,8 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 }
                 break;
             case OP_GEMM: {
-                HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
+                if (op.bf16) HIP_TRY(launch_gemm_bf16(gemm_args(op, batch), s));
+                else HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
                 break;
             }
             case OP_FUSE: {
@@ -114,14 +119,15 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 }
                 a.out = ptr(op.out);
                 a.B = batch; a.H = op.H; a.W = op.W; a.C = op.C; a.relu = op.relu;
+                a.bf16 = op.bf16;
                 HIP_TRY(launch_fuse_sum(a, s));
                 break;
             }
             case OP_MAXPOOL:
-                HIP_TRY(launch_maxpool3x3s2(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s));
+                HIP_TRY(launch_maxpool3x3s2(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
                 break;
             case OP_RESIZE:
-                HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s));
+                HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
                 break;
             case OP_PREP_EMBED:
                 HIP_TRY(launch_prep_embed(kcrop, k2d, params[op.p0].ptr, params[op.p1].ptr, params[op.p2].ptr,
@@ -129,7 +135,7 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 break;
             case OP_SAMPLE_REF:
                 HIP_TRY(launch_sample_ref(ptr(op.in[0]), kcrop, ptr(op.out), reinterpret_cast<int*>(ptr(op.aux2)),
-                                          batch, op.i0, op.H, op.W, op.C, s));
+                                          batch, op.i0, op.H, op.W, op.C, s, op.bf16));
                 break;
             case OP_LAYERNORM:
                 HIP_TRY(launch_layernorm(ptr(op.in[0]), op.amap, ptr(op.aux), op.rmap, params[op.p0].ptr,
@@ -146,6 +152,7 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 a.AO = ptr(op.aux);
                 a.ref = kcrop;
                 a.B = batch; a.J = op.i0; a.L = op.i1; a.NH = op.i2; a.NS = op.i3;
+                a.feat_bf16 = op.bf16;
                 HIP_TRY(launch_deform_sample(a, s));
                 break;
             }
@@ -186,8 +193,8 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
     Engine& e = h->e;
     e.cfg = *cfg;
     e.device = device;
-    if (cfg->compute_dtype != CAPF_F32) {
-        g_create_error = "compute_dtype: only CAPF_F32 is implemented in this build";
+    if (cfg->compute_dtype != CAPF_F32 && cfg->compute_dtype != CAPF_BF16) {
+        g_create_error = "compute_dtype must be CAPF_F32 or CAPF_BF16";
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
@@ -417,7 +424,7 @@ int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, in
     }
     if (ndim) *ndim = t.ndim;
     if (dev_ptr) *dev_ptr = (e.ws && e.last_batch > 0) ? e.bptr(t.buf, e.last_batch) : nullptr;
-    return t.is_int ? 1 : 0;
+    return t.is_int;      // 0 fp32, 1 int32, 2 bf16
 }
 
 int capf_op_pack_conv(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
@@ -452,6 +459,28 @@ int capf_op_linear(void* stream, const float* x, const float* w, const float* bi
     return capf::launch_gemm_f32(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_op_pack_conv_bf16(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, void* wp, float* bias, int Cout, int Cin, int ks) {
+    const int Kpad = (ks * ks * Cin + 63) / 64 * 64;
+    return capf::launch_pack_conv_bf16(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, ks, Kpad,
+                                       static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_bf16(void* stream, const void* x, const void* wp, const float* bias, const void* residual, void* y, int B,
+                      int H, int W, int Cin, int Cout, int ks, int stride, int act) {
+    capf::GemmArgs a{};
+    const int pad = ks / 2;
+    a.A = static_cast<const float*>(x); a.Wp = static_cast<const float*>(wp); a.bias = bias;
+    a.res = static_cast<const float*>(residual); a.out = static_cast<float*>(y);
+    a.Ho = (H + 2 * pad - ks) / stride + 1;
+    a.Wo = (W + 2 * pad - ks) / stride + 1;
+    a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = ks * ks * Cin; a.Kpad = (a.K + 63) / 64 * 64;
+    a.conv = 1; a.Cin = Cin; a.H = H; a.W = W; a.ks = ks; a.stride = stride; a.pad = pad;
+    a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
+    a.act = act;
+    return capf::launch_gemm_bf16(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
+}
+
 int capf_num_ops(const capf_handle* h) { return h ? (int)h->e.ops.size() : CAPF_ERR_INVALID; }
 
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel, double* flops) {
@@ -460,7 +489,8 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
                                "layernorm", "deform_sample", "attention", "head", "", ""};
     if (name) *name = op.name.c_str();
-    if (kernel) *kernel = op.kind == capf::OP_GEMM ? capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)) : kn[op.kind];
+    if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
+                                                                              : capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)));
     if (flops) *flops = op.flops_per_frame * batch;
     return CAPF_OK;
 }

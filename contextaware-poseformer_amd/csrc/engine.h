@@ -50,6 +50,7 @@ struct Pack {
     int N = 0, K = 0, Kpad = 0, Cin = 0, ks = 1;
     size_t w_off = 0, b_off = 0;   // element offsets inside the pack arena
     bool direct = false;           // linear with Kpad == K and no concat: use the parameter in place
+    bool bf16 = false;             // conv weights packed as bf16 (Kpad % 64 == 0)
 };
 
 enum OpKind {
@@ -81,6 +82,8 @@ struct Op {
     int lvlH[4] = {0, 0, 0, 0}, lvlW[4] = {0, 0, 0, 0}, lvlC[4] = {0, 0, 0, 0};
     int outs[4] = {-1, -1, -1, -1};
     double flops_per_frame = 0.0;
+    int bf16 = 0;                 // tensors of this op are bf16 (conv: bf16 MFMA kernel)
+    int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
     int region = -1;              // index of the enclosing fork/join region, -1 outside
 };
@@ -145,6 +148,8 @@ struct Engine {
     void build_lifter(const Tensor feats[4]);
     bool build();
     void assign_offsets();
+    bool bf16() const { return cfg.compute_dtype == CAPF_BF16; }
+    size_t act_elems(size_t n) const { return bf16() ? (n + 1) / 2 : n; }   // backbone activation size in float slots
     void use(int buf);   // mark buffer as read by the op being appended
     void push(Op op);    // append an op, tagging it with the current lane / region
     void fork(int n);    // open a region of n independent lanes (independent branches run on side streams)

@@ -1,0 +1,266 @@
+// bf16 implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[2] / [4]:
+// "bf16 inference ... MFMA bf16 path").  bf16 operands, fp32 accumulate, bf16 NHWC activations in HBM.
+//
+//   out[m, n] = act( sum_k A[m, k] * Wp[n, k] + bias[n] + res[m, n] ),  m = (b, ho, wo), k = (kh, kw, ci)
+//
+// Same machinery as igemm_f32.hip, re-dimensioned for 2-byte elements:
+//   * a tile row in LDS is still 128 B = 64 bf16 (BK = 64), staged by global_load_lds_dwordx4 with the same
+//     source-side XOR swizzle; ONE ds_read_b128 (8 bf16) is exactly one MFMA operand: lanes 0-31 carry
+//     k = 16*step + 0..7, lanes 32-63 carry k = 16*step + 8..15.
+//   * a 64-deep chunk is only 4 MFMAs (32 cycles each) per 32x32 tile, so this kernel lives on the load
+//     path, not on the matrix pipe (the bf16 peak is 16x the fp32 one): what matters is bytes, and every
+//     activation byte is half of what the fp32 path moves.
+//   * the accumulator is kept transposed (weights as the MFMA A operand) so each lane owns 4 consecutive
+//     output channels: bias in as 16 B, residual in / result out as 8-byte (4 x bf16) accesses.
+//   * bf16 rounding is round-to-nearest-even, done once, in the epilogue.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace capf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BKH = 64;     // K chunk in bf16 elements = 128 B per tile row
+
+__device__ __forceinline__ int fast_div_b(int n, FastDiv d) {
+    return (int)((__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__device__ __attribute__((aligned(16))) unsigned short capf_zero_page_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_b() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// 4 waves per block, block tile BM x BN, wave tile WM x WN, S LDS stages.  Conv mode only (the lifter's
+// GEMMs stay fp32: its LayerNorm / softmax / residual stream is kept in fp32).
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int NLOAD = RA + RB;
+    constexpr int STAGE = (BM + BN) * BKH;                // bf16 elements per stage
+    static_assert((BM / WM) * (BN / WN) == 4, "wave grid");
+
+    __shared__ __attribute__((aligned(16))) unsigned short lds[S * STAGE];
+
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(p.A);
+    const unsigned short* Wp = reinterpret_cast<const unsigned short*>(p.Wp);
+    const unsigned short* Rs = reinterpret_cast<const unsigned short*>(p.res);
+    unsigned short* Out = reinterpret_cast<unsigned short*>(p.out);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nblk = gridDim.x;
+    int bid;
+    {
+        const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int nbn = (p.N + BN - 1) / BN;
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int srow = tid >> 3;
+    const int kq = (((tid & 7) ^ ((srow >> 1) & 7))) * 8;      // logical k offset (bf16 elements) of this lane's quad
+
+    const unsigned short* zero = capf_zero_page_h;
+    const int nchunks = p.Kpad / BKH;
+    long a_off[RA];
+    unsigned long long a_mask[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + srow + 32 * i;
+        a_off[i] = 0;
+        a_mask[i] = 0ull;
+        if (m < p.M) {
+            const int b = fast_div_b(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
+            const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
+            const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+            a_off[i] = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            const int kw_lo = max(0, -w0), kw_hi = min(p.ks, p.W - w0);
+            const int kh_lo = max(0, -h0), kh_hi = min(p.ks, p.H - h0);
+            unsigned long long mk = 0ull;
+            if (kw_hi > kw_lo && kh_hi > kh_lo) {
+                const unsigned long long wbits = ((1ull << kw_hi) - 1) & ~((1ull << kw_lo) - 1);
+                const unsigned long long below_hi = kh_hi * p.ks >= 64 ? ~0ull : ((1ull << (kh_hi * p.ks)) - 1);
+                const unsigned long long below_lo = (1ull << (kh_lo * p.ks)) - 1;
+                mk = (wbits * p.spread) & below_hi & ~below_lo;
+            }
+            a_mask[i] = mk;
+        }
+    }
+    const unsigned short* b_src[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + srow + 32 * i;
+        b_src[i] = (n < p.N) ? Wp + (long)n * p.Kpad + kq : nullptr;
+    }
+
+    int tap = kq / p.Cin, ci = kq - tap * p.Cin;
+    int kh = tap / p.ks, kw = tap - kh * p.ks;
+
+    const unsigned short* src[NLOAD];
+    auto prepare = [&](int c) {
+        const long toff = ((long)kh * p.W + kw) * p.Cin + ci;
+        const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) src[i] = (a_mask[i] & bit) ? A + a_off[i] + toff : zero;
+        ci += BKH;
+        while (ci >= p.Cin) {
+            ci -= p.Cin;
+            ++tap;
+            if (++kw == p.ks) { kw = 0; ++kh; }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) src[RA + i] = (b_src[i] && c < nchunks) ? b_src[i] + c * BKH : zero;
+    };
+    auto fire = [&](int idx, int stage) {
+        unsigned short* As = lds + stage * STAGE;
+        unsigned short* dst = idx < RA ? As + (idx * 32 + wave * 8) * BKH : As + BM * BKH + ((idx - RA) * 32 + wave * 8) * BKH;
+        __builtin_amdgcn_global_load_lds((gptr_t)src[idx], (lptr_t)dst, 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    const int fhalf = lane >> 5;
+
+    constexpr int PER_STEP = (NLOAD + 1) / 2;
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) {
+        prepare(s);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) fire(i, s);
+    }
+    int st_read = 0, st_fill = S - 1;
+    prepare(S - 1);
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vmcnt_b<(S - 2) * NLOAD>();
+        __builtin_amdgcn_s_barrier();
+        const unsigned short* As = lds + st_read * STAGE;
+        const unsigned short* Bs = As + BM * BKH;
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            if (step == 2) prepare(c + S);
+            const int q = ((step * 2) + fhalf) ^ fsw;
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BKH + q * 8]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BKH + q * 8]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (step < 2) {
+#pragma unroll
+                for (int f = 0; f < PER_STEP; ++f) {
+                    const int idx = step * PER_STEP + f;
+                    if (idx < NLOAD) fire(idx, st_fill);
+                }
+            }
+        }
+        st_read = (st_read + 1 == S) ? 0 : st_read + 1;
+        st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
+    }
+    wait_vmcnt_b<0>();
+
+    // ---- epilogue (transposed accumulator: lane = one row m, register group g = 4 consecutive channels)
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + (lane & 31);
+        const bool m_ok = full || m < p.M;
+        const long o_row = (long)m * p.omap.S1 + p.omap.off;
+        const long r_row = (long)m * p.rmap.S1 + p.rmap.off;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + wn0 + j * 32 + 4 * (lane >> 5);
+            u16x4 rv[4];
+            f32x4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 8 * g;
+                const bool ok = m_ok && (full || n < p.N);
+                rv[g] = u16x4{0, 0, 0, 0};
+                bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok && p.bias) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (ok && Rs) rv[g] = *reinterpret_cast<const u16x4*>(Rs + r_row + n);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + 8 * g;
+                u16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * g + e] + bv[g][e] + bf2f(rv[g][e]);
+                    if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = f2bf(t);
+                }
+                if (m_ok && (full || n < p.N)) *reinterpret_cast<u16x4*>(Out + o_row + n) = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int S>
+static hipError_t launch_cfg_b(const GemmArgs& a, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, S>), dim3(nbm * nbn), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+const char* gemm_bf16_kernel_name(const GemmArgs& a) {
+    if (a.N <= 32) return "igemm_bf16<w4,128x32,conv>";
+    if (a.N <= 64) return ((long)a.M >= 128L * 512) ? "igemm_bf16<w4,128x64,conv>" : "igemm_bf16<w4,64x64,conv>";
+    if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return "igemm_bf16<w4,128x128,conv>";
+    return "igemm_bf16<w4,64x64,conv>";
+}
+
+// bf16 NHWC conv: A / res / out are bf16, Wp bf16 [N][Kpad] (Kpad % 64 == 0), bias fp32.  Cin % 8 == 0, N % 4 == 0.
+hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
+    if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
+    if (!a_in.conv || a_in.Kpad % BKH != 0 || a_in.Cin % 8 != 0 || a_in.N % 4 != 0 || a_in.act == ACT_GELU)
+        return hipErrorInvalidValue;
+    GemmArgs a = a_in;
+    a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.fd_wo = make_fastdiv((unsigned)a.Wo);
+    a.spread = 0ull;
+    for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+    if (a.N <= 32) return launch_cfg_b<128, 32, 32, 32, 3>(a, s);
+    if (a.N <= 64) return ((long)a.M >= 128L * 512) ? launch_cfg_b<128, 64, 64, 32, 3>(a, s) : launch_cfg_b<64, 64, 32, 32, 3>(a, s);
+    if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return launch_cfg_b<128, 128, 64, 64, 2>(a, s);
+    return launch_cfg_b<64, 64, 32, 32, 3>(a, s);
+}
+
+}  // namespace capf

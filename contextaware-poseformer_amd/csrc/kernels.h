@@ -40,6 +40,7 @@ struct GemmArgs {
     int rs_div;
     int splits, cps;        // split-K (rows mode): grid.y slices of `cps` chunks, slab s at out + s*split_stride
     long split_stride;
+    int out_bf16;           // small-Cin stem kernel only: fp32 image in, bf16 activations out
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
@@ -51,6 +52,12 @@ hipError_t launch_pack_conv(const float* w, const float* gamma, const float* bet
                             const float* var, float eps, float* Wp, float* bias, int Cout, int Cin,
                             int ks, int Kpad, hipStream_t s);
 // linear pack: Wp[n][k] = w[n][k] (zero padded to Kpad); rows [n0, n0+N) of the destination
+hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float* beta, const float* mean,
+                                 const float* var, float eps, void* Wp_bf16, float* bias, int Cout, int Cin, int ks,
+                                 int Kpad, hipStream_t s);
+// bf16 conv (igemm_bf16.hip): A / res / out bf16 NHWC, Wp bf16 [N][Kpad], Kpad % 64 == 0, bias fp32
+hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
+const char* gemm_bf16_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);
 
 // out = relu( sum_i up_{s_i}(in_i) ), NHWC, s_i = nearest-upsample factor (1 = same resolution)
@@ -61,14 +68,15 @@ struct FuseSumArgs {
     float* out;
     int B, H, W, C;
     int relu;
+    int bf16;      // tensors are bf16 (arithmetic stays fp32)
 };
 hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s);
 
 // 3x3 s2 p1 max-pool NHWC (resnet.py:140), bilinear align_corners=True resize NHWC (+ optional add)
 hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
-                               hipStream_t s);
+                               hipStream_t s, int bf16 = 0);
 hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
-                                  hipStream_t s);
+                                  hipStream_t s, int bf16 = 0);
 
 // ---- lifter -----------------------------------------------------------------------------------
 // kcrop -> ref in place (conpose.py:34-35);  X[b,p,0,:] = coord_embed(k2d[b,p]) + pos[0,p,:]
@@ -76,7 +84,7 @@ hipError_t launch_prep_embed(float* kcrop, const float* k2d, const float* w, con
                              const float* pos, float* X, int B, int J, int L1, int C, hipStream_t s);
 // reference-point sampling, padding zeros (pose_dformer.py:216-218): S[b,p,:] = bilinear(feat, ref[b,p])
 hipError_t launch_sample_ref(const float* feat, const float* ref, float* S, int* idx, int B, int J, int H,
-                             int W, int C, hipStream_t s);
+                             int W, int C, hipStream_t s, int feat_bf16 = 0);
 // LayerNorm over rows: out[r,:] = LN(in[imap(r)] (+ add[amap(r)]))   width C
 hipError_t launch_layernorm(const float* in, RowMap imap, const float* add, RowMap amap, const float* g,
                             const float* b, float eps, float* out, int rows, int C, hipStream_t s);
@@ -90,6 +98,7 @@ struct DeformArgs {
     const float* AO;
     const float* ref;
     int B, J, L, NH, NS;
+    int feat_bf16;           // the context maps are bf16
     int ld_ao;               // row pitch of AO (0 = 3*NH*NS, the inference layout; 64 in training)
     const float* dU[4];      // backward only: gradient w.r.t. U[l]
 };

@@ -69,8 +69,22 @@ __device__ __forceinline__ Corner corner_of(float gx, float gy, int H, int W) {
     return c;
 }
 
+// element c of an NHWC pixel stored as fp32 or bf16
+template <bool BF>
+__device__ __forceinline__ float ldf(const float* pix, int c) {
+    if (!BF) return pix[c];
+    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(pix)[c] << 16);
+}
+// pointer to pixel `pixel_index` (C channels) of a map stored as fp32 or bf16
+template <bool BF>
+__device__ __forceinline__ const float* pixptr(const float* base, long pixel_index, int C) {
+    if (!BF) return base + pixel_index * C;
+    return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + pixel_index * C);
+}
+
 // F.grid_sample(features, ref[B,17,1,2], bilinear, zeros, align_corners=True), pose_dformer.py:216-218.
 // One wave per (b, p); lanes stride over channels.
+template <bool BF>
 __global__ void sample_ref_kernel(const float* __restrict__ feat, const float* __restrict__ ref,
                                   float* __restrict__ S, int* __restrict__ idx, int BJ, int J, int H, int W,
                                   int C) {
@@ -90,19 +104,22 @@ __global__ void sample_ref_kernel(const float* __restrict__ feat, const float* _
     const float w10 = (vx0 && vy1) ? wx0 * k.wy1 : 0.f, w11 = (vx1 && vy1) ? k.wx1 * k.wy1 : 0.f;
     const int xa = min(max(k.x0, 0), W - 1), xb = min(max(k.x0 + 1, 0), W - 1);
     const int ya = min(max(k.y0, 0), H - 1), yb = min(max(k.y0 + 1, 0), H - 1);
-    const float* base = feat + (long)b * H * W * C;
-    const float* p00 = base + ((long)ya * W + xa) * C;
-    const float* p01 = base + ((long)ya * W + xb) * C;
-    const float* p10 = base + ((long)yb * W + xa) * C;
-    const float* p11 = base + ((long)yb * W + xb) * C;
+    const long ib = (long)b * H * W;
+    const float* p00 = pixptr<BF>(feat, ib + (long)ya * W + xa, C);
+    const float* p01 = pixptr<BF>(feat, ib + (long)ya * W + xb, C);
+    const float* p10 = pixptr<BF>(feat, ib + (long)yb * W + xa, C);
+    const float* p11 = pixptr<BF>(feat, ib + (long)yb * W + xb, C);
     for (int c = lane; c < C; c += 64)
-        S[(long)bp * C + c] = ((p00[c] * w00 + p01[c] * w01) + p10[c] * w10) + p11[c] * w11;
+        S[(long)bp * C + c] = ((ldf<BF>(p00, c) * w00 + ldf<BF>(p01, c) * w01) + ldf<BF>(p10, c) * w10) + ldf<BF>(p11, c) * w11;
 }
 
 hipError_t launch_sample_ref(const float* feat, const float* ref, float* S, int* idx, int B, int J, int H,
-                             int W, int C, hipStream_t s) {
+                             int W, int C, hipStream_t s, int feat_bf16) {
     const int BJ = B * J;
-    hipLaunchKernelGGL(sample_ref_kernel, dim3((BJ + 3) / 4), dim3(256), 0, s, feat, ref, S, idx, BJ, J, H, W, C);
+    if (feat_bf16)
+        hipLaunchKernelGGL(sample_ref_kernel<true>, dim3((BJ + 3) / 4), dim3(256), 0, s, feat, ref, S, idx, BJ, J, H, W, C);
+    else
+    hipLaunchKernelGGL(sample_ref_kernel<false>, dim3((BJ + 3) / 4), dim3(256), 0, s, feat, ref, S, idx, BJ, J, H, W, C);
     return hipGetLastError();
 }
 
@@ -166,7 +183,7 @@ hipError_t launch_layernorm(const float* in, RowMap imap, const float* add, RowM
 // so only U = sum_s w_s v_s  [(b,p,h), C_l] is produced here and the projection is a GEMM with
 // M = B*17*4 rows instead of B*17*16 (the [B,17,16,C_l] tensor is never materialised).
 // One block per (b, p); wave w handles level w; lanes stride over channels.
-template <int NS>
+template <int NS, bool BF>
 __global__ void deform_sample_kernel(DeformArgs a) {
     const int bp = blockIdx.x;
     const int l = threadIdx.x >> 6;
@@ -174,7 +191,7 @@ __global__ void deform_sample_kernel(DeformArgs a) {
     if (l >= a.L) return;
     const int b = bp / a.J;
     const int H = a.H[l], W = a.W[l], C = a.C[l];
-    const float* feat = a.feat[l] + (long)b * H * W * C;
+    const float* feat = pixptr<BF>(a.feat[l], (long)b * H * W, C);
     const int nk = a.NH * NS;
     const float* ao = a.AO + ((long)bp * a.L + l) * (a.ld_ao ? a.ld_ao : 3 * nk);
     const float rx = a.ref[bp * 2 + 0], ry = a.ref[bp * 2 + 1];
@@ -201,14 +218,14 @@ __global__ void deform_sample_kernel(DeformArgs a) {
             const float wx0 = 1.0f - q.wx1, wy0 = 1.0f - q.wy1;
             w00[s] = ws * (wx0 * wy0); w01[s] = ws * (q.wx1 * wy0);
             w10[s] = ws * (wx0 * q.wy1); w11[s] = ws * (q.wx1 * q.wy1);
-            p00[s] = feat + ((long)q.y0 * W + q.x0) * C; p01[s] = feat + ((long)q.y0 * W + xb) * C;
-            p10[s] = feat + ((long)yb * W + q.x0) * C;   p11[s] = feat + ((long)yb * W + xb) * C;
+            p00[s] = pixptr<BF>(feat, (long)q.y0 * W + q.x0, C); p01[s] = pixptr<BF>(feat, (long)q.y0 * W + xb, C);
+            p10[s] = pixptr<BF>(feat, (long)yb * W + q.x0, C);   p11[s] = pixptr<BF>(feat, (long)yb * W + xb, C);
         }
         for (int c = lane; c < C; c += 64) {
             float u = 0.f;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                u += ((p00[s][c] * w00[s] + p01[s][c] * w01[s]) + p10[s][c] * w10[s]) + p11[s][c] * w11[s];
+                u += ((ldf<BF>(p00[s], c) * w00[s] + ldf<BF>(p01[s], c) * w01[s]) + ldf<BF>(p10[s], c) * w10[s]) + ldf<BF>(p11[s], c) * w11[s];
             U[(long)h * C + c] = u;
         }
     }
@@ -216,7 +233,8 @@ __global__ void deform_sample_kernel(DeformArgs a) {
 
 hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s) {
     if (a.NS != 4 || a.L > 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(deform_sample_kernel<4>, dim3(a.B * a.J), dim3(64 * a.L), 0, s, a);
+    if (a.feat_bf16) hipLaunchKernelGGL((deform_sample_kernel<4, true>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a);
+    else hipLaunchKernelGGL((deform_sample_kernel<4, false>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a);
     return hipGetLastError();
 }
 

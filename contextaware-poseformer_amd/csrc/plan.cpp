@@ -18,6 +18,7 @@ static const int EXT_IMAGES = -2;
 
 static size_t round64(size_t n) { return (n + 63) / 64 * 64; }
 static int round32(int n) { return (n + 31) / 32 * 32; }
+static int round64(int n) { return (n + 63) / 64 * 64; }
 
 int Engine::add_param(const std::string& name, int kind, std::initializer_list<int64_t> shape) {
     auto it = param_index.find(name);
@@ -114,7 +115,9 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     pk.Cin = x.C;
     pk.ks = ks;
     pk.K = ks * ks * x.C;
-    pk.Kpad = round32(pk.K);
+    const bool use_bf16 = bf16() && x.C % 8 == 0;       // the Cin = 3 stem stays on the fp32 kernel
+    pk.bf16 = use_bf16;
+    pk.Kpad = use_bf16 ? round64(pk.K) : round32(pk.K);
     packs.push_back(pk);
 
     Op op;
@@ -135,7 +138,9 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
         op.aux = residual->buf;
         use(residual->buf);
     }
-    y.buf = new_buffer((size_t)y.H * y.W * Cout, conv);
+    op.bf16 = use_bf16 ? 1 : 0;
+    op.out_bf16 = (bf16() && !use_bf16) ? 1 : 0;
+    y.buf = new_buffer(act_elems((size_t)y.H * y.W * Cout), conv);
     op.out = y.buf;
     push(op);
     return y;
@@ -153,8 +158,9 @@ static Tensor fuse_sum(Engine& e, const std::string& name, const Tensor* terms, 
         e.use(terms[i].buf);
     }
     op.H = like.H; op.W = like.W; op.C = like.C; op.relu = relu;
+    op.bf16 = e.bf16() ? 1 : 0;
     Tensor y = like;
-    y.buf = e.new_buffer((size_t)like.H * like.W * like.C, name);
+    y.buf = e.new_buffer(e.act_elems((size_t)like.H * like.W * like.C), name);
     op.out = y.buf;
     e.push(op);
     return y;
@@ -281,8 +287,9 @@ static Tensor pool_or_resize(Engine& e, OpKind kind, const std::string& name, co
     op.in[0] = x.buf;
     e.use(x.buf);
     op.H = x.H; op.W = x.W; op.C = x.C; op.Ho = Ho; op.Wo = Wo;
+    op.bf16 = e.bf16() ? 1 : 0;
     Tensor y{-1, Ho, Wo, x.C};
-    y.buf = e.new_buffer((size_t)Ho * Wo * x.C, name);
+    y.buf = e.new_buffer(e.act_elems((size_t)Ho * Wo * x.C), name);
     op.out = y.buf;
     e.push(op);
     return y;
@@ -528,6 +535,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
         op.name = "sample_ref." + ls;
         op.in[0] = feats[l].buf;
         op.H = feats[l].H; op.W = feats[l].W; op.C = Cl[l]; op.i0 = J;
+        op.bf16 = bf16() ? 1 : 0;
         use(feats[l].buf);
         const int S = new_buffer((size_t)J * Cl[l], "sampled" + ls);
         const int I = new_buffer((size_t)J * 2, "idx" + ls);
@@ -575,6 +583,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
                     use(U[l]);
                 }
                 op.i0 = J; op.i1 = L; op.i2 = NH; op.i3 = NS;
+                op.bf16 = bf16() ? 1 : 0;
                 push(op);
             }
             for (int l = 0; l < L; ++l) {
@@ -704,7 +713,7 @@ bool Engine::build() {
         return false;
     }
     for (int l = 0; l < 4; ++l) {
-        name_tensor(*this, "feat" + std::to_string(l), feats[l].buf, {-1, feats[l].H, feats[l].W, feats[l].C});
+        name_tensor(*this, "feat" + std::to_string(l), feats[l].buf, {-1, feats[l].H, feats[l].W, feats[l].C}, bf16() ? 2 : 0);
         const int expect = cfg.backbone == CAPF_CPN50 ? cfg.base_dim : cfg.base_dim << l;
         if (feats[l].C != expect) {
             err = "poseformer.base_dim does not match the backbone's context-map widths";
@@ -730,7 +739,7 @@ bool Engine::build() {
     for (Pack& pk : packs) {
         if (pk.direct) continue;
         pk.w_off = off;
-        off += round64((size_t)pk.N * pk.Kpad);
+        off += round64(pk.bf16 ? ((size_t)pk.N * pk.Kpad + 1) / 2 : (size_t)pk.N * pk.Kpad);
         pk.b_off = off;
         off += round64((size_t)pk.N);
     }

@@ -161,7 +161,7 @@ int Engine::forward_train(hipStream_t s, int B, const float* masks) {
     for (int l = 0; l < Lv; ++l) {
         const std::string fe = V + ".feat_embed." + std::to_string(l);
         float* S = tw + L.S[l];
-        HIP_TRY(launch_sample_ref(bptr(feat_buf[l], B), kcrop, S, nullptr, B, J, feat_H[l], feat_W[l], feat_C[l], s));
+        HIP_TRY(launch_sample_ref(bptr(feat_buf[l], B), kcrop, S, nullptr, B, J, feat_H[l], feat_W[l], feat_C[l], s, bf16() ? 1 : 0));
         int rc = t_gemm(s, S, row_ld(feat_C[l]), B * J, C, feat_C[l], P(*this, fe + ".weight"), feat_C[l],
                         P(*this, fe + ".bias"), X, row_ld(D, (long)(1 + l) * C), pos, RowMap{J, 0, C, (long)(1 + l) * J * C},
                         ACT_NONE, nullptr, 1);
@@ -187,6 +187,7 @@ int Engine::forward_train(hipStream_t s, int B, const float* masks) {
             da.U[l] = tw + c.U[l];
         }
         da.AO = tw + c.ao; da.ref = kcrop; da.B = B; da.J = J; da.L = Lv; da.NH = NH; da.NS = NS; da.ld_ao = 64;
+        da.feat_bf16 = bf16() ? 1 : 0;
         HIP_TRY(launch_deform_sample(da, s));
         for (int l = 0; l < Lv; ++l) {
             const std::string ep = p + ".embed_proj." + std::to_string(l);
@@ -364,6 +365,7 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
             da.dU[l] = tw + L.dU[l];
         }
         da.AO = tw + c.ao; da.ref = kcrop; da.B = B; da.J = J; da.L = Lv; da.NH = NH; da.NS = NS; da.ld_ao = 64;
+        da.feat_bf16 = bf16() ? 1 : 0;
         HIP_TRY(launch_deform_bwd(da, gA, 64, s));                                  // gA = dAO [R, 64]
         // [attention_weights | sampling_offsets] were one GEMM with N = 48: gradients land in a [48, C] temp
         const Pack& pk = packs[ctx_ao_pack[i]];

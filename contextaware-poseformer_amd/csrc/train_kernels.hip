@@ -384,7 +384,18 @@ hipError_t launch_attention_bwd(const float* qkv, const float* dO, float* dqkv, 
 //            <= 0 or >= size-1)
 //   dlogit = softmax backward, do = dpos * (1 - tanh^2)
 // One block per (b, p); wave = level; lanes stride over channels; wave-level reductions.
-template <int NS>
+template <bool BF>
+__device__ __forceinline__ float ldf_t(const float* pix, int c) {
+    if (!BF) return pix[c];
+    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(pix)[c] << 16);
+}
+template <bool BF>
+__device__ __forceinline__ const float* pixptr_t(const float* base, long pixel_index, int C) {
+    if (!BF) return base + pixel_index * C;
+    return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + pixel_index * C);
+}
+
+template <int NS, bool BF>
 __global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd) {
     const int bp = blockIdx.x;
     const int l = threadIdx.x >> 6;
@@ -392,7 +403,7 @@ __global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd
     if (l >= a.L) return;
     const int b = bp / a.J;
     const int H = a.H[l], W = a.W[l], C = a.C[l];
-    const float* feat = a.feat[l] + (long)b * H * W * C;
+    const float* feat = pixptr_t<BF>(a.feat[l], (long)b * H * W, C);
     const int nk = a.NH * NS;
     const long row = (long)bp * a.L + l;
     const float* ao = a.AO + row * ldd;
@@ -423,14 +434,15 @@ __global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd
             const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
             const bool vx = x0 + 1 <= W - 1, vy = y0 + 1 <= H - 1;       // +1 corner inside the map
             const int xb = vx ? x0 + 1 : x0, yb = vy ? y0 + 1 : y0;
-            const float* p00 = feat + ((long)y0 * W + x0) * C;
-            const float* p01 = feat + ((long)y0 * W + xb) * C;
-            const float* p10 = feat + ((long)yb * W + x0) * C;
-            const float* p11 = feat + ((long)yb * W + xb) * C;
+            const float* p00 = pixptr_t<BF>(feat, (long)y0 * W + x0, C);
+            const float* p01 = pixptr_t<BF>(feat, (long)y0 * W + xb, C);
+            const float* p10 = pixptr_t<BF>(feat, (long)yb * W + x0, C);
+            const float* p11 = pixptr_t<BF>(feat, (long)yb * W + xb, C);
             float a_dw = 0.f, a_gx = 0.f, a_gy = 0.f;
             for (int c = lane; c < C; c += 64) {
                 const float g = dU[(long)h * C + c];
-                const float f00 = p00[c], f01 = vx ? p01[c] : 0.f, f10 = vy ? p10[c] : 0.f, f11 = (vx && vy) ? p11[c] : 0.f;
+                const float f00 = ldf_t<BF>(p00, c), f01 = vx ? ldf_t<BF>(p01, c) : 0.f, f10 = vy ? ldf_t<BF>(p10, c) : 0.f,
+                            f11 = (vx && vy) ? ldf_t<BF>(p11, c) : 0.f;
                 a_dw += g * (((f00 * (wx0 * wy0) + f01 * (wx1 * wy0)) + f10 * (wx0 * wy1)) + f11 * (wx1 * wy1));
                 a_gx += g * ((f01 - f00) * wy0 + (f11 - f10) * wy1);
                 a_gy += g * ((f10 - f00) * wx0 + (f11 - f01) * wx1);
@@ -458,7 +470,8 @@ __global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd
 
 hipError_t launch_deform_bwd(const DeformArgs& a, float* dAO, int ldd, hipStream_t s) {
     if (a.NS != 4 || a.L > 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(deform_bwd_kernel<4>, dim3(a.B * a.J), dim3(64 * a.L), 0, s, a, dAO, ldd);
+    if (a.feat_bf16) hipLaunchKernelGGL((deform_bwd_kernel<4, true>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a, dAO, ldd);
+    else hipLaunchKernelGGL((deform_bwd_kernel<4, false>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a, dAO, ldd);
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ from capf.lib import CPN50, HRNET, CapfConfig, CapfError, Engine
 MAX_BATCH = 8192
 
 
-def make_capf_config(config, height=256, width=192, context_blocks=True):
+def make_capf_config(config, height=256, width=192, context_blocks=True, compute_dtype="fp32"):
     bb = config.model.backbone
     pf = config.model.poseformer
     c = CapfConfig()
@@ -55,7 +55,9 @@ def make_capf_config(config, height=256, width=192, context_blocks=True):
     c.deform_heads = 4
     c.deform_samples = 4
     c.context_blocks = 1 if context_blocks else 0
-    c.compute_dtype = 0
+    if compute_dtype not in ("fp32", "bf16"):
+        raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+    c.compute_dtype = 1 if compute_dtype == "bf16" else 0
     c.max_batch = MAX_BATCH
     c.height, c.width = height, width
     c.training = 1                  # workspace also holds what capf_backward needs (6.4 MB/frame)

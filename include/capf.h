@@ -160,7 +160,8 @@ int capf_set_debug(capf_handle* h, int on);
  *   idx0..idx3     int32 [B,17,2] (ix0, iy0) bilinear NW corner of those samples (bit-exact check)
  *   tok_ctx / tok_res / tok_joint   token buffer [B,17,L+1,c] after each block group (layout b p l c)
  * Pointers are into the workspace and valid until the next forward on this handle.
- * Returns 0 for an fp32 tensor, 1 for an int32 tensor, negative on error. */
+ * Returns 0 for an fp32 tensor, 1 for an int32 tensor, 2 for a bf16 tensor (context maps of a
+ * CAPF_BF16 handle), negative on error. */
 int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, int64_t shape[4],
                 int* ndim);
 
@@ -184,6 +185,14 @@ int capf_op_conv(void* stream, const float* x_nhwc, const float* w_packed, const
                  int stride, int act);
 int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual,
                    float* y, int M, int N, int K, int act);
+/* bf16 twins (igemm_bf16.hip, v_mfma_f32_32x32x16_bf16): x / residual / y are bf16 NHWC, w_packed is bf16
+ * [Cout][Kpad] with Kpad = ks*ks*Cin rounded up to 64, bias stays fp32.  Cin % 8 == 0, Cout % 4 == 0. */
+int capf_op_pack_conv_bf16(void* stream, const float* w_oihw, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, void* w_packed_bf16, float* bias,
+                           int Cout, int Cin, int ks);
+int capf_op_conv_bf16(void* stream, const void* x_nhwc_bf16, const void* w_packed_bf16, const float* bias,
+                      const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout,
+                      int ks, int stride, int act);
 
 /* ---- measurement aids (bench.py roofline line; no reference counterpart) -------------------------
  * capf_op_info: op `index` in launch order: its plan name, the kernel (template instantiation) it

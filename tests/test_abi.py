@@ -14,7 +14,7 @@ from conftest import ROOT
 def _header_symbols():
     text = open(os.path.join(ROOT, "include", "capf.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(capf_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(capf_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -71,3 +71,35 @@ def test_linear_matches_torch(M, N, K, act, res):
         want = F.gelu(want)
     got = capf.linear(x.cuda(), w.cuda(), b.cuda(), act, r.cuda() if res else None).cpu()
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+BF16_CASES = [(32, 32, 3, 1, 64, 64, 2, 1, True), (64, 64, 3, 1, 32, 32, 2, 1, False), (48, 48, 3, 1, 24, 20, 1, 1, True),
+              (256, 256, 3, 1, 8, 8, 3, 0, True), (64, 256, 1, 1, 16, 12, 2, 1, True), (96, 48, 1, 1, 10, 6, 2, 0, False),
+              (32, 64, 3, 2, 16, 12, 3, 1, False), (2048, 256, 1, 1, 4, 3, 1, 1, False), (128, 128, 3, 1, 5, 3, 7, 1, True)]
+
+
+@pytest.mark.parametrize("ci,co,ks,st,H,W,B,act,res", BF16_CASES)
+def test_conv_bf16_matches_torch_on_bf16_rounded_operands(ci, co, ks, st, H, W, B, act, res):
+    """bf16 MFMA conv == fp32 conv of the SAME bf16-rounded inputs/weights (products of two bf16 numbers are
+    exact in fp32, so only accumulation order and the final bf16 rounding differ)."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(ci + co * 3 + ks + H)
+    x = torch.randn(B, ci, H, W, generator=g).bfloat16()
+    w = (torch.randn(co, ci, ks, ks, generator=g) / (ci * ks * ks) ** 0.5)
+    bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+           torch.rand(co, generator=g) * 0.4 + 0.8)
+    wp, bias = capf.pack_conv_bf16(w.cuda(), tuple(t.cuda() for t in bnp))
+    kreal = ks * ks * ci
+    w_fold = wp[:, :kreal].float().cpu().view(co, ks, ks, ci).permute(0, 3, 1, 2).contiguous()   # what the kernel multiplies
+    want = F.conv2d(x.float(), w_fold, bias.cpu(), st, ks // 2)
+    r = torch.randn_like(want).bfloat16() if res else None
+    if res:
+        want = want + r.float()
+    if act == 1:
+        want = F.relu(want)
+    got = capf.conv_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, ks, st, act,
+                              r.permute(0, 2, 3, 1).contiguous().cuda() if res else None)
+    got = got.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5          # one bf16 rounding of the result
+    assert (got - want).abs().max().item() <= tol

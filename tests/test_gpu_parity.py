@@ -91,3 +91,36 @@ def test_batch_independence_and_determinism():
         one = model(img[2:3].cuda(), k2d[2:3].cuda(), kc[2:3].clone().cuda())
     assert torch.equal(a, b)
     assert (a[2:3] - one).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("backbone,B,H,W", [("hrnet_32", 2, 256, 256), ("hrnet_48", 2, 256, 256), ("cpn", 1, 384, 288)])
+def test_bf16_backbone_path_tracks_the_fp32_oracle(backbone, B, H, W):
+    """compute_dtype='bf16' (BASELINE configs[2]/[4]): bf16 MFMA convolutions with bf16 activations, fp32
+    lifter.  bf16 carries 8 bits of mantissa, so after ~100 layers the context maps agree with the fp32 oracle
+    to about 1e-2 relative and the 17x3 joints to a few 1e-2 absolute — reported, and bounded here."""
+    import copy, contextlib, io
+    from capf import synth
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), backbone)
+    cfg.model.backbone.fix_weights = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = CA_PF(cfg, compute_dtype="bf16").eval()
+    sd = synth.load_synthetic(model, seed=31, bn_mode="random")
+    model = model.cuda()
+    img, k2d, kc = synth.synth_inputs(B, H, W, seed=32)
+    taps = {}
+    with torch.no_grad():
+        want = oracle.ca_pf_forward(sd, img, k2d, kc.clone(), backbone=backbone, taps=taps)
+        got = model(img.cuda(), k2d.cuda(), kc.cuda()).cpu()
+    eng = model.engine_for(img.cuda())
+    for l in range(4):
+        f = eng.tensor(f"feat{l}").float().cpu().permute(0, 3, 1, 2)
+        ref = taps["features"][l]
+        rel = (f - ref).norm().item() / ref.norm().item()
+        print(f"{backbone} feat{l}: relative L2 error {rel:.3e}")
+        assert rel < 3e-2
+    err = (got - want).abs().max().item()
+    mpj = (got - want).norm(dim=-1).mean().item()
+    print(f"{backbone} bf16: max|joint delta| {err:.3e}, mean joint distance {mpj:.3e}")
+    assert err < 8e-2 and mpj < 3e-2
