@@ -18,10 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.match(r"void capf::igemm_f32_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+), (\w+), (\w+)>", name)
+    m = re.match(r"void capf::igemm_f32_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+),", name)
     if m:
-        nw, bm, bn, mode, gelu, plain = m.groups()
+        nw, bm, bn, mode = m.groups()
         return f"igemm_f32<w{nw},{bm}x{bn},{'conv' if mode == '1' else 'rows'}>"
+    m = re.match(r"void capf::igemm_bf16_kernel<(\d+), (\d+),", name)
+    if m:
+        return f"igemm_bf16<w4,{m.group(1)}x{m.group(2)},conv>"
     m = re.match(r"void capf::igemm_f32_smallc_kernel", name)
     if m:
         return "igemm_f32_smallc<w4,128x64>"
