@@ -45,17 +45,18 @@ class _LifterStep(torch.autograd.Function):
 
 
 class CA_PF(nn.Module):
-    def __init__(self, config, device="cuda:0", compute_dtype="fp32"):
+    def __init__(self, config, device="cuda:0", compute_dtype="fp32", context_blocks=True):
         """compute_dtype: 'fp32' (exact fp32 MFMA, the reference's precision) or 'bf16' (backbone convolutions on
         bf16 MFMA with bf16 activations and fp32 accumulation; the lifter stays fp32) — an extension of the
         reference signature for BASELINE.json's bf16 configurations."""
         super().__init__()
         self.compute_dtype = compute_dtype
+        self.context_blocks = context_blocks       # False: the MPI-INF-3DHP variant (model/conpose.py)
         self.num_joints = config.model.backbone.num_joints
         self._config = config
         self._backbone_type = config.model.backbone.type
         # schema from a plan-only handle (no GPU needed): names == reference state_dict
-        plan = Engine(_native.make_capf_config(config, 256, 192), device=None)
+        plan = Engine(_native.make_capf_config(config, 256, 192, context_blocks=context_blocks), device=None)
         schema = plan.schema()
         plan.close()
         self.backbone = _native.build_param_tree(_native.Container(), schema, "backbone")
@@ -107,7 +108,8 @@ class CA_PF(nn.Module):
         key = (dev.index, H, W)
         eng = self._engines.get(key)
         if eng is None:
-            eng = Engine(_native.make_capf_config(self._config, H, W, compute_dtype=self.compute_dtype), device=dev.index)
+            eng = Engine(_native.make_capf_config(self._config, H, W, context_blocks=self.context_blocks,
+                                                  compute_dtype=self.compute_dtype), device=dev.index)
             eng._packed_versions = None
             self._engines[key] = eng
         lifter_versions = tuple(p._version for p in self.volume_net.parameters())

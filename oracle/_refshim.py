@@ -43,11 +43,19 @@ def install():
         models = types.ModuleType("timm.models")
         layers = types.ModuleType("timm.models.layers")
         layers.DropPath = DropPath
+        # imported (not used on the path) by ContextPose_mpi/model/pose_dformer.py
+        layers.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+        layers.trunc_normal_ = nn.init.trunc_normal_
         models.layers = layers
         timm.models = models
         sys.modules["timm"] = timm
         sys.modules["timm.models"] = models
         sys.modules["timm.models.layers"] = layers
+        registry = types.ModuleType("timm.models.registry")          # imported, unused (ContextPose_mpi)
+        registry.register_model = lambda fn: fn
+        models.registry = registry
+        models.__path__ = []
+        sys.modules["timm.models.registry"] = registry
 
     if "easydict" not in sys.modules:
         class EasyDict(dict):
@@ -109,4 +117,35 @@ def build_reference(backbone="hrnet_32", embed_dim_ratio=128):
     c = reference_config(backbone, embed_dim_ratio)
     with contextlib.redirect_stdout(io.StringIO()):
         m = CA_PF(c, device="cpu")
+    return m.eval(), c
+
+
+MPI_ROOT = "/root/reference/ContextPose_mpi"
+
+
+def build_reference_mpi(backbone="hrnet_32"):
+    """The sibling app's model (ContextPose_mpi/model/conpose.py) with run_3dhp.py:219-235's config patch.
+    Its packages are called `model` / `common`; they are imported under a clean sys.path entry."""
+    install()
+    import contextlib, copy, importlib, io
+    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "common" or k.startswith("common.")]:
+        del sys.modules[k]          # the build's own mirror package is also called `model`
+    # a regular package (the build's model/ has an __init__.py) beats the reference's namespace package no
+    # matter the path order, so the build's source root is taken off sys.path for the duration of the import
+    saved_path = list(sys.path)
+    sys.path[:] = [MPI_ROOT] + [p for p in sys.path if "contextaware-poseformer_amd" not in p]
+    cfgmod = importlib.import_module("common.cfg")
+    c = copy.deepcopy(cfgmod.config)
+    if backbone == "hrnet_32":
+        c.model.backbone.STAGE2.NUM_CHANNELS = [32, 64]
+        c.model.backbone.STAGE3.NUM_CHANNELS = [32, 64, 128]
+        c.model.backbone.STAGE4.NUM_CHANNELS = [32, 64, 128, 256]
+        c.model.poseformer.base_dim = 32
+        c.model.poseformer.embed_dim_ratio = 64
+    net = importlib.import_module("model.conpose").VolumetricTriangulationNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = net(c)
+    sys.path[:] = saved_path
+    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "common" or k.startswith("common.")]:
+        del sys.modules[k]
     return m.eval(), c

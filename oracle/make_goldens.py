@@ -34,7 +34,22 @@ GRAD_KEYS = ["volume_net.head.1.weight", "volume_net.context_blocks.0.sampling_o
              "volume_net.feat_embed.3.weight", "volume_net.Spatial_pos_embed"]
 
 
+def run_case_mpi(name, case):
+    """ContextPose_mpi/model: outputs only (x [B,3,1,17,1], in-place ref)."""
+    torch.set_num_threads(8)
+    model, _ = _refshim.build_reference_mpi(case["backbone"])
+    synth.load_synthetic(model, seed=case["wseed"], bn_mode=case["bn"])
+    img, k2d, kc = case_inputs(case)
+    kc_io = kc.clone()
+    with torch.no_grad():
+        out, _ = model(img, k2d, kc_io)
+    return {"out": out.numpy(), "ref": kc_io.numpy(),
+            "schema_names": np.array(list(model.state_dict().keys()))}
+
+
 def run_case(name, case):
+    if case.get("mpi"):
+        return run_case_mpi(name, case)
     torch.set_num_threads(8)
     model, _ = _refshim.build_reference(case["backbone"])
     synth.load_synthetic(model, seed=case["wseed"], bn_mode=case["bn"])

@@ -9,6 +9,8 @@ CASES = {
     "w32_256x256_adv": dict(backbone="hrnet_32", B=2, H=256, W=256, wseed=1, iseed=5, bn="default", crop="adv"),
     "w48_256x256_b1": dict(backbone="hrnet_48", B=1, H=256, W=256, wseed=6, iseed=7, bn="random", crop=(256, 256)),
     "cpn_384x288_b1": dict(backbone="cpn", B=1, H=384, W=288, wseed=8, iseed=9, bn="random", crop=(288, 384)),
+    # MPI-INF-3DHP variant (ContextPose_mpi): no deformable blocks, embed 64, output [B,3,1,17,1]
+    "mpi_w32_e64_b2": dict(backbone="hrnet_32", B=2, H=256, W=192, wseed=12, iseed=13, bn="random", crop=(192, 256), mpi=True),
     "cpn_256x192_b1": dict(backbone="cpn", B=1, H=256, W=192, wseed=8, iseed=10, bn="random", crop=(192, 256)),
 }
 
