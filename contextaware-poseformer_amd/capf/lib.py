@@ -13,7 +13,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
-    "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
+    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
 ]
 
 
@@ -84,6 +84,8 @@ def load_library():
     lib.capf_op_pack_conv.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     lib.capf_op_linear.argtypes = [P, P, P, P, P, P] + [c_int] * 4
+    lib.capf_preprocess.argtypes = [P, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, P, P, P, P, P, P, P]
+    lib.capf_fliptest_fuse.argtypes = [P, P, c_int, P]
     lib.capf_op_pack_conv_bf16.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     _lib = lib
@@ -351,3 +353,47 @@ def linear(x, w, bias=None, act=0, residual=None):
     if rc:
         raise CapfError(f"capf_op_linear failed ({rc})")
     return y
+
+
+# ---- neighbours of the path: N1 preprocessing, N2 flip-test fusion -------------------------------------
+HRNET_MEAN, HRNET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # datasets/utils.py:24-26
+CPN_MEAN = tuple(v / 255.0 for v in (122.7717, 115.9465, 102.9801))             # :27-29
+
+
+def preprocess(images_u8, gt, k2d, kcrop, backbone="hrnet_32", mode=0):
+    """uint8 BGR [B,H,W,3] + labels (all CUDA) -> (images fp32 RGB NHWC, gt root-relative, k2d, kcrop).
+    mode 0 plain, 1 train-time horizontal flip, 2 flip-test ([2,B,...] outputs: original then mirrored)."""
+    import torch
+    lib = load_library()
+    B, H, W, _ = images_u8.shape
+    nsets = 2 if mode == 2 else 1
+    dev = images_u8.device
+    img_out = torch.empty((nsets, B, H, W, 3) if nsets == 2 else (B, H, W, 3), dtype=torch.float32, device=dev)
+    k2d_out = torch.empty((nsets, B, 17, 2) if nsets == 2 else (B, 17, 2), dtype=torch.float32, device=dev)
+    kc_out = torch.empty_like(k2d_out)
+    gt_out = torch.empty_like(gt) if gt is not None else None
+    if backbone == "cpn":
+        mean = torch.tensor([122.7717, 115.9465, 102.9801]) / 255.0              # fp32 division, like the reference
+        std = None
+    else:
+        mean, std = torch.tensor(HRNET_MEAN), torch.tensor(HRNET_STD)
+    m3 = (c_float * 3)(*mean.tolist())
+    s3 = (c_float * 3)(*std.tolist()) if std is not None else None
+    rc = lib.capf_preprocess(_stream(images_u8), _p(images_u8.contiguous()), B, H, W, m3, s3, mode, _p(img_out),
+                             _p(gt.contiguous()) if gt is not None else c_void_p(0), _p(gt_out), _p(k2d.contiguous()), _p(k2d_out),
+                             _p(kcrop.contiguous()), _p(kc_out))
+    if rc:
+        raise CapfError(f"capf_preprocess failed ({rc})")
+    return img_out, gt_out, k2d_out, kc_out
+
+
+def fliptest_fuse(pred2):
+    """pred2 [2,B,1,17,3] (original, mirrored) -> [B,1,17,3]  (train.py:177-180)."""
+    import torch
+    lib = load_library()
+    B = pred2.shape[1]
+    out = torch.empty(B, 1, 17, 3, dtype=torch.float32, device=pred2.device)
+    rc = lib.capf_fliptest_fuse(_stream(pred2), _p(pred2.contiguous()), B, _p(out))
+    if rc:
+        raise CapfError(f"capf_fliptest_fuse failed ({rc})")
+    return out

@@ -481,6 +481,22 @@ int capf_op_conv_bf16(void* stream, const void* x, const void* wp, const float* 
     return capf::launch_gemm_bf16(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
 }
 
+int capf_preprocess(void* stream, const uint8_t* images_bgr, int batch, int height, int width, const float mean[3],
+                    const float* std3, int mode, float* images_out, const float* gt_in, float* gt_out, const float* k2d_in,
+                    float* k2d_out, const float* kcrop_in, float* kcrop_out) {
+    if (!images_bgr || !images_out || !k2d_in || !k2d_out || !kcrop_in || !kcrop_out || !mean || batch <= 0 || mode < 0 ||
+        mode > 2 || (gt_in && !gt_out))
+        return CAPF_ERR_INVALID;
+    return capf::launch_preprocess(images_bgr, batch, height, width, mean, std3, mode, images_out, gt_in, gt_out, k2d_in,
+                                   k2d_out, kcrop_in, kcrop_out, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out) {
+    if (!pred2 || !out || batch <= 0) return CAPF_ERR_INVALID;
+    return capf::launch_fliptest_fuse(pred2, batch, out, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_num_ops(const capf_handle* h) { return h ? (int)h->e.ops.size() : CAPF_ERR_INVALID; }
 
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel, double* flops) {

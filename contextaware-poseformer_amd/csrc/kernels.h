@@ -137,4 +137,11 @@ hipError_t launch_head_dgrad(const float* dOut, const float* W, float* dY, int r
 // dpos[l, p, c] = sum_b dX[b, p, l, c]
 hipError_t launch_pos_grad(const float* dX, float* dpos, int B, int J, int L1, int C, hipStream_t s);
 
+// ---- neighbours of the path (preprocess.hip): N1 input preprocessing, N2 flip-test fusion ---------------
+// mode 0: as is; 1: train-time horizontal flip of the whole batch; 2: flip-test (outputs hold [orig | mirrored])
+hipError_t launch_preprocess(const unsigned char* images_bgr, int B, int H, int W, const float mean[3], const float* stdv,
+                             int mode, float* images_out, const float* gt_in, float* gt_out, const float* k2d_in,
+                             float* k2d_out, const float* kc_in, float* kc_out, hipStream_t s);
+hipError_t launch_fliptest_fuse(const float* pred2, int B, float* out, hipStream_t s);
+
 }  // namespace capf

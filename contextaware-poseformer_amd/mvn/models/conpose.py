@@ -170,6 +170,17 @@ class CA_PF(nn.Module):
                         parts.append(torch.empty(per, device=device).bernoulli_(keep).div_(keep))
         return torch.cat(parts).contiguous()
 
+    def forward_flip_test(self, images2, keypoints_2d_cpn2, keypoints_2d_cpn_crop2):
+        """Flip-test evaluation (train.py:170-181) as ONE forward: inputs are the [2,B,...] stacks that
+        capf_preprocess(mode=2) emits (original, mirrored); the two predictions are un-mirrored and averaged
+        by capf_fliptest_fuse.  Returns [B,1,17,3].  The crop keypoints are normalised in place."""
+        from capf.lib import fliptest_fuse
+        two, B = images2.shape[0], images2.shape[1]
+        assert two == 2 and images2.is_contiguous() and keypoints_2d_cpn_crop2.is_contiguous()
+        pred = self.forward(images2.view(2 * B, *images2.shape[2:]), keypoints_2d_cpn2.reshape(2 * B, 17, 2),
+                            keypoints_2d_cpn_crop2.view(2 * B, 17, 2))
+        return fliptest_fuse(pred.view(2, B, 1, 17, 3))
+
     def engine_for(self, images):
         """The native engine serving inputs of this shape/device (tests, bench)."""
         return self._engine(images.contiguous())

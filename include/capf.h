@@ -194,6 +194,19 @@ int capf_op_conv_bf16(void* stream, const void* x_nhwc_bf16, const void* w_packe
                       const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout,
                       int ks, int stride, int act);
 
+/* ---- the steps on either side of the path ---------------------------------
+ * capf_preprocess: data_prefetcher.preload (ContextPose/mvn/datasets/utils.py:33-82) as one launch pair:
+ *   images_bgr uint8 [B,H,W,3] -> images_out fp32 RGB NHWC ((u/255 - mean) / std; std == NULL: CPN, mean only);
+ *   gt_in [B,1,17,3] -> gt_out root-relative (:52-53); k2d / kcrop [B,17,2] copied or mirrored.
+ *   mode 0: as is.  mode 1: train-time horizontal flip of the whole batch incl. left/right joint swap and
+ *   `192 - x - 1` (:55-65).  mode 2: flip-test stacking (:67-80): images_out [2,B,H,W,3], k2d_out / kcrop_out
+ *   [2,B,17,2] hold the original followed by the mirrored sample, so ONE capf_forward of batch 2B serves both.
+ * capf_fliptest_fuse: train.py:177-180 — pred2 [2,B,1,17,3] -> out [B,1,17,3] = mean(pred, un-mirrored pred). */
+int capf_preprocess(void* stream, const uint8_t* images_bgr, int batch, int height, int width, const float mean[3],
+                    const float* std3, int mode, float* images_out, const float* gt_in, float* gt_out,
+                    const float* k2d_in, float* k2d_out, const float* kcrop_in, float* kcrop_out);
+int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out);
+
 /* ---- measurement aids (bench.py roofline line; no reference counterpart) -------------------------
  * capf_op_info: op `index` in launch order: its plan name, the kernel (template instantiation) it
  *   launches at `batch`, and its algorithmic FLOPs at `batch`.

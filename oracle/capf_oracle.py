@@ -366,3 +366,55 @@ def mpjpe(pred, gt):
 
 def gelu_exact(x):
     return 0.5 * x * (1.0 + math.erf(x / math.sqrt(2.0)))
+
+
+# ----------------------------------------------------------------------------------------------
+# neighbours of the path.  The reference class needs a CUDA stream and cannot run in
+# the build container, so these are restated from ContextPose/mvn/datasets/utils.py:33-82 and train.py:170-181
+# and pinned by hand-computable vectors in tests/test_oracle_golden.py.
+# ----------------------------------------------------------------------------------------------
+JOINTS_LEFT = [4, 5, 6, 11, 12, 13]      # datasets/utils.py:12
+JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]     # :13
+
+
+def prefetch_preprocess(images_u8, gt, k2d, kcrop, backbone="hrnet_32", is_train=False, flip=False, flip_test=False):
+    """data_prefetcher.preload.  `flip` replaces the reference's `random.random() <= 0.5` draw (:55).
+    `images / 255.0` is written as a multiplication by the fp32 reciprocal: that is what ATen's CUDA kernel does
+    for a Python-scalar divisor, and the reference's prefetcher only runs on a GPU."""
+    images = torch.flip(images_u8, [-1]).float() * torch.tensor(1.0, dtype=torch.float32).div(255.0)      # :45,:47
+    if backbone in ("hrnet_32", "hrnet_48"):
+        mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+        images = (images - mean) / std                                                                  # :47-48
+    else:
+        images = images - (torch.tensor([122.7717, 115.9465, 102.9801]) / 255.0).view(1, 1, 1, 3)        # :27-29,:50
+    gt, k2d, kcrop = gt.clone(), k2d.clone(), kcrop.clone()
+    gt[:, :, 1:] -= gt[:, :, :1]                                                                        # :52
+    gt[:, :, 0] = 0                                                                                     # :53
+    L, R = JOINTS_LEFT, JOINTS_RIGHT
+    if flip and is_train:                                                                               # :55-65
+        images = torch.flip(images, [-2])
+        k2d[..., 0] *= -1
+        k2d[..., L + R, :] = k2d[..., R + L, :]
+        kcrop[:, :, 0] = 192 - kcrop[:, :, 0] - 1
+        kcrop[:, L + R] = kcrop[:, R + L]
+        gt[:, :, :, 0] *= -1
+        gt[:, :, L + R] = gt[:, :, R + L]
+    if (not is_train) and flip_test:                                                                    # :67-80
+        images = torch.stack([images, torch.flip(images, [2])], dim=1)
+        k2f = k2d.clone()
+        k2f[..., 0] *= -1
+        k2f[..., L + R, :] = k2f[..., R + L, :]
+        k2d = torch.stack([k2d, k2f], dim=1)
+        kcf = kcrop.clone()
+        kcf[:, :, 0] = 192 - kcf[:, :, 0] - 1
+        kcf[:, L + R] = kcf[:, R + L]
+        kcrop = torch.stack([kcrop, kcf], dim=1)
+    return images.float(), gt.float(), k2d.float(), kcrop.float()
+
+
+def fliptest_fuse(pred, pred_flip):
+    """train.py:177-180."""
+    pred_flip = pred_flip.clone()
+    pred_flip[:, :, :, 0] *= -1
+    pred_flip[:, :, JOINTS_LEFT + JOINTS_RIGHT] = pred_flip[:, :, JOINTS_RIGHT + JOINTS_LEFT]
+    return torch.mean(torch.cat((pred, pred_flip), dim=1), dim=1, keepdim=True)

@@ -103,3 +103,57 @@ def test_conv_bf16_matches_torch_on_bf16_rounded_operands(ci, co, ks, st, H, W, 
     assert got.shape == want.shape
     tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5          # one bf16 rounding of the result
     assert (got - want).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("backbone,mode", [("hrnet_32", 0), ("hrnet_32", 1), ("hrnet_32", 2), ("cpn", 2), ("cpn", 1)])
+def test_preprocess_kernel_is_bit_exact(backbone, mode):
+    """N1: capf_preprocess == the prefetcher's torch expressions (restated in the oracle), bit for bit."""
+    import capf_oracle as oracle
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(mode + len(backbone))
+    B, H, W = 3, 256, 192
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    gt = torch.randn(B, 1, 17, 3, generator=g)
+    k2d = torch.rand(B, 17, 2, generator=g) * 2 - 1
+    kc = torch.rand(B, 17, 2, generator=g) * 191
+    want = oracle.prefetch_preprocess(img, gt, k2d, kc, backbone, is_train=(mode == 1), flip=(mode == 1), flip_test=(mode == 2))
+    got = capf.preprocess(img.cuda(), gt.cuda(), k2d.cuda(), kc.cuda(), backbone, mode)
+    wi, wg, wk, wc = want
+    if mode == 2:      # the reference stacks on dim 1 ([B,2,...]); the kernel emits [2,B,...] so ONE forward serves both
+        wi, wk, wc = wi.transpose(0, 1), wk.transpose(0, 1), wc.transpose(0, 1)
+    assert torch.equal(got[0].cpu(), wi.contiguous())
+    assert torch.equal(got[1].cpu(), wg)
+    assert torch.equal(got[2].cpu(), wk.contiguous())
+    assert torch.equal(got[3].cpu(), wc.contiguous())
+
+
+def test_fliptest_fusion_is_bit_exact_and_end_to_end():
+    """N2: the fused un-mirror + average == train.py:177-180; and one 2B forward == two B forwards."""
+    import capf_oracle as oracle
+    from capf import lib as capf
+    p = torch.randn(2, 5, 1, 17, 3)
+    want = oracle.fliptest_fuse(p[0], p[1])
+    assert torch.equal(capf.fliptest_fuse(p.cuda()).cpu(), want)
+
+
+def test_flip_test_single_forward_equals_two_forwards_and_prefetcher_runs():
+    """N1+N2 end to end: prefetcher mirror (flip-test mode) -> one 2B forward + fused un-mirror/average ==
+    the reference's two forwards + torch fusion (computed here with the oracle's restatement of the fusion)."""
+    import capf_oracle as oracle
+    from conftest import make_model
+    from mvn.datasets.utils import data_prefetcher
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    batch = (torch.randint(0, 256, (B, 256, 192, 3), generator=g, dtype=torch.uint8), torch.randn(B, 1, 17, 3, generator=g),
+             torch.rand(B, 17, 2, generator=g) * 2 - 1, torch.rand(B, 17, 2, generator=g) * 191)
+    pf = data_prefetcher([batch], torch.device("cuda"), is_train=False, flip_test=True, backbone="hrnet_32")
+    images, gt, k2d, kc = pf.next()
+    assert pf.next() is None and images.shape == (B, 2, 256, 192, 3)
+    model, _ = make_model("hrnet_32", device="cuda", wseed=9)
+    with torch.no_grad():
+        a = model(images[:, 0], k2d[:, 0], kc[:, 0].clone())              # train.py:171-176
+        b = model(images[:, 1], k2d[:, 1], kc[:, 1].clone())
+        want = oracle.fliptest_fuse(a.cpu(), b.cpu())
+        got = model.forward_flip_test(images.transpose(0, 1).contiguous(), k2d.transpose(0, 1).contiguous(),
+                                      kc.transpose(0, 1).contiguous().clone())
+    assert (got.cpu() - want).abs().max().item() < 1e-5

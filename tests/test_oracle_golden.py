@@ -92,3 +92,28 @@ def test_oracle_matches_mpi_variant_golden():
     out = out.view(case["B"], 1, 17, 3, 1).permute(0, 3, 1, 2, 4)
     np.testing.assert_allclose(out.numpy(), g["out"], atol=TOL, rtol=0)
     np.testing.assert_array_equal(kc.numpy(), g["ref"])
+
+
+def test_prefetch_preprocess_hand_computed():
+    """N1 pin: one pixel / a few joints worked out by hand (datasets/utils.py:45-65)."""
+    img = torch.zeros(1, 2, 3, 3, dtype=torch.uint8)
+    img[0, 0, 0] = torch.tensor([255, 0, 128])                 # B, G, R
+    gt = torch.zeros(1, 1, 17, 3); gt[0, 0, 0] = torch.tensor([1.0, 2.0, 3.0]); gt[0, 0, 4] = torch.tensor([2.0, 2.0, 2.0])
+    k2d = torch.zeros(1, 17, 2); k2d[0, 1] = torch.tensor([0.25, -0.5])
+    kc = torch.zeros(1, 17, 2); kc[0, 1] = torch.tensor([10.0, 20.0])
+    im, g, k, c = oracle.prefetch_preprocess(img, gt, k2d, kc, "hrnet_32", is_train=True, flip=True)
+    # the pixel moves from w=0 to w=2 and its channels become (R, G, B) = (128, 0, 255)
+    want = (torch.tensor([128.0, 0.0, 255.0]) * torch.tensor(1.0).div(255.0) - torch.tensor([0.485, 0.456, 0.406])) / torch.tensor([0.229, 0.224, 0.225])
+    assert torch.equal(im[0, 0, 2], want)
+    assert g[0, 0, 0].tolist() == [-0.0, 0.0, 0.0]
+    assert g[0, 0, 1].tolist() == [-1.0, 0.0, -1.0]            # joint 4 (left) lands on joint 1 (right), x negated
+    assert k[0, 4].tolist() == [-0.25, -0.5] and k[0, 1].tolist() == [-0.0, 0.0]
+    assert c[0, 4].tolist() == [181.0, 20.0] and c[0, 1].tolist() == [191.0, 0.0]
+    # flip-test stacking and its fusion are inverse bookkeeping
+    im2, g2, k2, c2 = oracle.prefetch_preprocess(img, gt, k2d, kc, "cpn", is_train=False, flip_test=True)
+    assert im2.shape == (1, 2, 2, 3, 3) and k2.shape == (1, 2, 17, 2)
+    assert torch.equal(im2[:, 1], torch.flip(im2[:, 0], [2])) and c2[0, 1, 4].tolist() == [181.0, 20.0]
+    p = torch.randn(3, 1, 17, 3)
+    pf = p.clone(); pf[..., 0] *= -1
+    pf[:, :, oracle.JOINTS_LEFT + oracle.JOINTS_RIGHT] = pf[:, :, oracle.JOINTS_RIGHT + oracle.JOINTS_LEFT]
+    assert torch.allclose(oracle.fliptest_fuse(p, pf), p, atol=0)
