@@ -36,10 +36,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-__device__ __attribute__((aligned(16))) unsigned short capf_zero_page_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_b() {
@@ -50,6 +48,7 @@ __device__ __forceinline__ void wait_vmcnt_b() {
 // GEMMs stay fp32: its LayerNorm / softmax / residual stream is kept in fp32).
 template <int BM, int BN, int WM, int WN, int S>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist on the device side only
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
@@ -81,61 +80,97 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
     const int srow = tid >> 3;
     const int kq = (((tid & 7) ^ ((srow >> 1) & 7))) * 8;      // logical k offset (bf16 elements) of this lane's quad
 
-    const unsigned short* zero = capf_zero_page_h;
+    // Operand fetch = `buffer_load_dwordx4 ... lds` with block-uniform descriptors and 32-bit per-lane byte
+    // offsets; out-of-range offsets make the hardware write zeros (see igemm_f32.hip for the scheme).
     const int nchunks = p.Kpad / BKH;
-    long a_off[RA];
-    unsigned long long a_mask[RA];
+    constexpr unsigned OOB_A = 0x80000000u;
+    long a_base;
+    {
+        const int b = fast_div_b(m0, p.fd_hw), rem = m0 - b * p.Ho * p.Wo;
+        const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
+        a_base = ((long)b * p.H * p.W + (long)(ho * p.stride - p.pad) * p.W + (wo * p.stride - p.pad)) * p.Cin;
+    }
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + a_base), 0, 0x7FFFFF00u, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * p.Kpad), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)p.Kpad * 2u, 0x00020000);
+    unsigned a_rel[RA];                // byte offset of (row, tap 0, channel kq) from the descriptor base
+    unsigned a_mask[RA];               // bit t set <=> tap t of this row reads real data
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + srow + 32 * i;
-        a_off[i] = 0;
-        a_mask[i] = 0ull;
+        a_rel[i] = 0;
+        a_mask[i] = 0u;
         if (m < p.M) {
             const int b = fast_div_b(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
             const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
             const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
-            a_off[i] = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            const long off = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            a_rel[i] = (unsigned)(off - a_base + kq) * 2u;
             const int kw_lo = max(0, -w0), kw_hi = min(p.ks, p.W - w0);
             const int kh_lo = max(0, -h0), kh_hi = min(p.ks, p.H - h0);
-            unsigned long long mk = 0ull;
             if (kw_hi > kw_lo && kh_hi > kh_lo) {
-                const unsigned long long wbits = ((1ull << kw_hi) - 1) & ~((1ull << kw_lo) - 1);
-                const unsigned long long below_hi = kh_hi * p.ks >= 64 ? ~0ull : ((1ull << (kh_hi * p.ks)) - 1);
-                const unsigned long long below_lo = (1ull << (kh_lo * p.ks)) - 1;
-                mk = (wbits * p.spread) & below_hi & ~below_lo;
+                const unsigned wbits = ((1u << kw_hi) - 1) & ~((1u << kw_lo) - 1);
+                const unsigned below_hi = kh_hi * p.ks >= 32 ? ~0u : ((1u << (kh_hi * p.ks)) - 1);
+                const unsigned below_lo = (1u << (kh_lo * p.ks)) - 1;
+                a_mask[i] = (wbits * (unsigned)p.spread) & below_hi & ~below_lo;
             }
-            a_mask[i] = mk;
         }
     }
-    const unsigned short* b_src[RB];
+    unsigned w_off[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int n = n0 + srow + 32 * i;
-        b_src[i] = (n < p.N) ? Wp + (long)n * p.Kpad + kq : nullptr;
+    for (int i = 0; i < RB; ++i) w_off[i] = (unsigned)((srow + 32 * i) * p.Kpad + kq) * 2u;
+
+    // Cin % 64 == 0: a chunk lies inside one tap -> block-uniform walk, tap offset in the scalar offset
+    const bool uni = (p.Cin & (BKH - 1)) == 0;
+    int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;
+    int tap = 0, ci = kq, kh = 0, kw = 0;
+    if (!uni) {
+        tap = kq / p.Cin;
+        ci = kq - tap * p.Cin;
+        kh = tap / p.ks;
+        kw = tap - kh * p.ks;
     }
 
-    int tap = kq / p.Cin, ci = kq - tap * p.Cin;
-    int kh = tap / p.ks, kw = tap - kh * p.ks;
-
-    const unsigned short* src[NLOAD];
+    unsigned voff[NLOAD];
+    unsigned soff_a = 0;
     auto prepare = [&](int c) {
-        const long toff = ((long)kh * p.W + kw) * p.Cin + ci;
-        const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;
+        if (uni) {
+            const unsigned bit = u_tap < 32 ? (1u << u_tap) : 0u;
+            soff_a = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * p.W + u_kw) * p.Cin + u_ci) * 2u);
 #pragma unroll
-        for (int i = 0; i < RA; ++i) src[i] = (a_mask[i] & bit) ? A + a_off[i] + toff : zero;
-        ci += BKH;
-        while (ci >= p.Cin) {
-            ci -= p.Cin;
-            ++tap;
-            if (++kw == p.ks) { kw = 0; ++kh; }
+            for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] : OOB_A;
+            u_ci += BKH;
+            if (u_ci >= p.Cin) {
+                u_ci = 0;
+                ++u_tap;
+                if (++u_kw == p.ks) { u_kw = 0; ++u_kh; }
+            }
+        } else {
+            const unsigned bit = tap < 32 ? (1u << tap) : 0u;
+            const unsigned t = (unsigned)((kh * p.W + kw) * p.Cin + ci - kq) * 2u;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] + t : OOB_A;
+            ci += BKH;
+            while (ci >= p.Cin) {
+                ci -= p.Cin;
+                ++tap;
+                if (++kw == p.ks) { kw = 0; ++kh; }
+            }
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) src[RA + i] = (b_src[i] && c < nchunks) ? b_src[i] + c * BKH : zero;
+        for (int i = 0; i < RB; ++i) {
+            voff[RA + i] = w_off[i];
+            w_off[i] += BKH * 2u;
+        }
     };
     auto fire = [&](int idx, int stage) {
         unsigned short* As = lds + stage * STAGE;
-        unsigned short* dst = idx < RA ? As + (idx * 32 + wave * 8) * BKH : As + BM * BKH + ((idx - RA) * 32 + wave * 8) * BKH;
-        __builtin_amdgcn_global_load_lds((gptr_t)src[idx], (lptr_t)dst, 16, 0, 0);
+        if (idx < RA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(As + (idx * 32 + wave * 8) * BKH), 16, voff[idx],
+                                                     soff_a, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc_w, (lptr_t)(As + BM * BKH + ((idx - RA) * 32 + wave * 8) * BKH), 16, voff[idx], 0, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -231,6 +266,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
             }
         }
     }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int S>
@@ -250,7 +286,8 @@ const char* gemm_bf16_kernel_name(const GemmArgs& a) {
 // bf16 NHWC conv: A / res / out are bf16, Wp bf16 [N][Kpad] (Kpad % 64 == 0), bias fp32.  Cin % 8 == 0, N % 4 == 0.
 hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
-    if (!a_in.conv || a_in.Kpad % BKH != 0 || a_in.Cin % 8 != 0 || a_in.N % 4 != 0 || a_in.act == ACT_GELU)
+    if (!a_in.conv || a_in.Kpad % BKH != 0 || a_in.Cin % 8 != 0 || a_in.N % 4 != 0 || a_in.act == ACT_GELU ||
+        a_in.ks * a_in.ks > 32)   // 32-bit tap masks
         return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));

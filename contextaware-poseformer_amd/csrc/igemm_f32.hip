@@ -10,18 +10,18 @@
 //   * activations are NHWC, weights are pre-packed [N][Kpad] with k = (kh, kw, ci): both MFMA operands
 //     are "row-major with K contiguous".  One ds_read_b128 feeds FOUR 32x32x2 MFMAs: lanes 0-31 hold
 //     k = kk+j, lanes 32-63 hold k = kk+4+j (the K order inside an MFMA is free as long as A and B agree).
-//   * tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  The LDS
-//     image of such a load is lane-linear (8 rows x 128 B per wave instruction), so the bank-conflict
+//   * tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write).  The
+//     LDS image of such a load is lane-linear (8 rows x 128 B per wave instruction), so the bank-conflict
 //     fix is an XOR swizzle applied to the SOURCE k-quad and to the ds_read_b128 address.
-//   * every tap's validity (zero padding, ragged M) is one bit of a per-row mask computed ONCE before
-//     the K loop; a staged element's address is row_offset + tap_offset or a 16-byte zero page: the K
-//     loop has no branch and ~10 VALU instructions per staged KiB.
-//   * S-stage LDS ring, counted s_waitcnt vmcnt, at most ONE raw s_barrier per 32-deep K chunk; the DMA
+//   * addressing is a block-uniform buffer descriptor + a 32-bit per-lane byte offset (+ a scalar tap
+//     offset when Cin % 32 == 0).  Every tap's validity (zero padding, ragged M) is one bit of a per-row
+//     mask computed ONCE before the K loop; an invalid element gets an out-of-range offset and the
+//     hardware writes zeros to LDS without a memory access: the K loop has no branch, no zero page and
+//     3 VALU instructions per staged KiB (the 64-bit-pointer version of this loader cost ~12 and was
+//     6 % slower end to end).
+//   * S-stage LDS ring, counted s_waitcnt vmcnt, ONE raw s_barrier per 32-deep K chunk; the DMA
 //     instructions of chunk c+S-1 are issued in the 64-cycle shadows of the MFMAs of chunk c.
-//   * two block shapes: 4 wave64 sharing A/B tiles (small M, wide N: fewer L2->LDS bytes per FLOP) and
-//     single-wave blocks with a private ring and NO barrier at all (huge M, N <= 64: the 32- and
-//     64-channel high-resolution branches of HRNet) — waves then drift freely and keep the MFMA pipe
-//     fed instead of convoying through per-chunk barriers.
+//   * 4 wave64 per block share the A/B tiles (fewer L2->LDS bytes per FLOP than private tiles).
 //   * blockIdx is remapped so that consecutive tiles (which share halo rows / the same weights) land on
 //     the same XCD and hit its private L2.
 //   * f32 MFMA is an exact fmaf chain (1/16 of the bf16 rate): results match an fp32 reference to
@@ -55,10 +55,8 @@ __device__ __forceinline__ int fast_div(int n, FastDiv d) {
     return (int)((__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
 }
 
-__device__ __attribute__((aligned(16))) float capf_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -71,6 +69,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ABL: ablation for diagnosis only (0 = product kernel; 1 = no DMA inside the K loop; 2 = no MFMA)
 template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist on the device side only
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -108,71 +107,105 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     const int srow = tid >> 3;
     const int kq = (((tid & 7) ^ ((srow >> KEYSH) & 7))) * 4;
 
-    const float* zero = capf_zero_page;
     const int nchunks = p.Kpad / BK;
     // split-K (rows mode, weight gradients): grid.y slices the chunk range, each slice writes its own slab
     const int c_begin = blockIdx.y * p.cps;
     const int c_end = min(nchunks, c_begin + p.cps);
-    long a_off[RA];                    // element offset of (row, tap 0, channel 0); rows mode: row base
-    unsigned long long a_mask[RA];     // bit t set <=> tap t of this row reads real data
+
+    // Both operands are fetched with `buffer_load_dwordx4 ... lds`: a block-uniform resource descriptor
+    // (SGPRs) plus a 32-bit per-lane byte offset.  An offset past num_records makes the hardware write
+    // ZEROS into LDS without touching memory, so padding taps, rows >= M, k >= K and weight rows >= N
+    // need no zero page and no 64-bit per-lane pointers: the per-chunk address work is one select per load.
+    //   A, conv mode: base = address of (first row of the tile, tap 0, channel 0) -- row offsets are
+    //     monotonic in m, so every real tap of every row of the tile is at a small non-negative offset;
+    //     OOB_A is far beyond num_records even after the scalar tap offset is added.
+    //   A, rows mode: base = A, absolute 32-bit offsets (the launcher rejects operands >= 4 GiB).
+    //   W: base = first weight row of the tile, num_records = bytes up to the end of the packed matrix
+    //     (rows >= N and chunks past Kpad fall off the end by themselves).
+    constexpr unsigned OOB_A = AMODE == AMODE_CONV ? 0x80000000u : 0xFFFFFFFFu;
+    constexpr unsigned NREC_A = AMODE == AMODE_CONV ? 0x7FFFFF00u : 0xFFFFFF00u;
+    long a_base = 0;                   // element offset of the descriptor base (block-uniform)
+    if (AMODE == AMODE_CONV) {
+        const int b = fast_div(m0, p.fd_hw), rem = m0 - b * p.Ho * p.Wo;
+        const int ho = fast_div(rem, p.fd_wo), wo = rem - ho * p.Wo;
+        a_base = ((long)b * p.H * p.W + (long)(ho * p.stride - p.pad) * p.W + (wo * p.stride - p.pad)) * p.Cin;
+    }
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a_base), 0, NREC_A, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wp + (long)n0 * p.Kpad), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)p.Kpad * 4u, 0x00020000);
+
+    unsigned a_rel[RA];                // byte offset of (row, tap 0, channel kq) from the descriptor base
+    unsigned a_mask[RA];               // bit t set <=> tap t of this row reads real data (ks <= 5)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + srow + RPR * i;
-        a_off[i] = 0;
-        a_mask[i] = 0ull;
+        a_rel[i] = 0;
+        a_mask[i] = 0u;
         if (m < p.M) {
             if (AMODE == AMODE_ROWS) {
-                a_off[i] = rowmap(p.amap, m);
-                a_mask[i] = 1ull;
+                a_rel[i] = (unsigned)(rowmap(p.amap, m) + kq) * 4u;
+                a_mask[i] = 1u;
             } else {
                 const int b = fast_div(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
                 const int ho = fast_div(rem, p.fd_wo), wo = rem - ho * p.Wo;
                 const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
-                a_off[i] = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+                const long off = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+                a_rel[i] = (unsigned)(off - a_base + kq) * 4u;
                 // valid taps: kw in [max(0,-w0), min(ks, W-w0)), kh likewise; mask = wbits * spread(hbits)
                 // (bit kh*ks+kw; no carries because wbits < 2^ks and spread has its bits ks apart)
                 const int kw_lo = max(0, -w0), kw_hi = min(p.ks, p.W - w0);
                 const int kh_lo = max(0, -h0), kh_hi = min(p.ks, p.H - h0);
-                unsigned long long mk = 0ull;
                 if (kw_hi > kw_lo && kh_hi > kh_lo) {
-                    const unsigned long long wbits = ((1ull << kw_hi) - 1) & ~((1ull << kw_lo) - 1);
-                    const unsigned long long below_hi = kh_hi * p.ks >= 64 ? ~0ull : ((1ull << (kh_hi * p.ks)) - 1);
-                    const unsigned long long below_lo = (1ull << (kh_lo * p.ks)) - 1;
-                    mk = (wbits * p.spread) & below_hi & ~below_lo;      // rows [kh_lo, kh_hi) only
+                    const unsigned wbits = ((1u << kw_hi) - 1) & ~((1u << kw_lo) - 1);
+                    const unsigned below_hi = kh_hi * p.ks >= 32 ? ~0u : ((1u << (kh_hi * p.ks)) - 1);
+                    const unsigned below_lo = (1u << (kh_lo * p.ks)) - 1;
+                    a_mask[i] = (wbits * (unsigned)p.spread) & below_hi & ~below_lo;   // rows [kh_lo, kh_hi) only
                 }
-                a_mask[i] = mk;
             }
         }
     }
-    const float* b_src[RB];
+    unsigned w_off[RB];                // running byte offset of this thread's weight quad (advances 128 B / chunk)
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int n = n0 + srow + RPR * i;
-        b_src[i] = (n < p.N) ? p.Wp + (long)n * p.Kpad + kq : nullptr;
-    }
+    for (int i = 0; i < RB; ++i) w_off[i] = (unsigned)((srow + RPR * i) * p.Kpad + c_begin * BK + kq) * 4u;
 
-    // running decomposition of this thread's k = c*32 + kq into (tap, ci)
-    int tap = 0, ci = kq, kh = 0, kw = 0;
-    if (AMODE == AMODE_CONV) {
+    // k decomposition of the chunk being prepared.  Cin % 32 == 0 (every HRNet-32 / CPN conv): a chunk
+    // lies inside ONE tap, the decomposition is block-uniform (SGPRs) and the tap offset rides in the
+    // load's scalar offset.  Otherwise each thread walks its own (tap, ci) sequence.
+    const bool uni = AMODE == AMODE_CONV && (p.Cin & (BK - 1)) == 0;
+    int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;  // uniform walk (u_ci = first channel of the chunk)
+    int tap = 0, ci = kq, kh = 0, kw = 0;         // per-thread walk (ci = this thread's channel)
+    if (AMODE == AMODE_CONV && !uni) {
         tap = kq / p.Cin;
         ci = kq - tap * p.Cin;
         kh = tap / p.ks;
         kw = tap - kh * p.ks;
     }
 
-    // source pointers of the chunk being staged (computed once per chunk, fired between MFMAs)
-    const float* src[NLOAD];
+    // offsets of the chunk being staged (computed once per chunk, fired between MFMAs)
+    unsigned voff[NLOAD];
+    unsigned soff_a = 0;
     auto prepare = [&](int c) {
         if (AMODE == AMODE_ROWS) {
             const int k = c * BK + kq;
-            const bool k_ok = k < p.K && c < c_end;
+            const bool k_ok = k < p.K;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) src[i] = (k_ok && a_mask[i]) ? p.A + a_off[i] + k : zero;
+            for (int i = 0; i < RA; ++i) voff[i] = (k_ok && a_mask[i]) ? a_rel[i] + (unsigned)(c * BK) * 4u : OOB_A;
+        } else if (uni) {
+            const unsigned bit = u_tap < 32 ? (1u << u_tap) : 0u;
+            soff_a = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * p.W + u_kw) * p.Cin + u_ci) * 4u);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] : OOB_A;
+            u_ci += BK;
+            if (u_ci >= p.Cin) {
+                u_ci = 0;
+                ++u_tap;
+                if (++u_kw == p.ks) { u_kw = 0; ++u_kh; }
+            }
         } else {
-            const long toff = ((long)kh * p.W + kw) * p.Cin + ci;
-            const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;
+            const unsigned bit = tap < 32 ? (1u << tap) : 0u;
+            const unsigned t = (unsigned)((kh * p.W + kw) * p.Cin + ci - kq) * 4u;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) src[i] = (a_mask[i] & bit) ? p.A + a_off[i] + toff : zero;
+            for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] + t : OOB_A;
             ci += BK;
             while (ci >= p.Cin) {
                 ci -= p.Cin;
@@ -181,13 +214,20 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) src[RA + i] = (b_src[i] && c < c_end) ? b_src[i] + c * BK : zero;
+        for (int i = 0; i < RB; ++i) {
+            voff[RA + i] = w_off[i];
+            w_off[i] += BK * 4u;
+        }
     };
     // fire load #idx of the prepared chunk into `stage` (LDS image: 8 rows x 128 B per wave instruction)
     auto fire = [&](int idx, int stage) {
         float* As = lds + stage * STAGE;
-        float* dst = idx < RA ? As + (idx * RPR + wave * 8) * BK : As + BM * BK + ((idx - RA) * RPR + wave * 8) * BK;
-        __builtin_amdgcn_global_load_lds((gptr_t)src[idx], (lptr_t)dst, 16, 0, 0);
+        if (idx < RA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(As + (idx * RPR + wave * 8) * BK), 16, voff[idx],
+                                                     soff_a, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc_w, (lptr_t)(As + BM * BK + ((idx - RA) * RPR + wave * 8) * BK), 16, voff[idx], 0, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -225,8 +265,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             // the address arithmetic of the NEXT iteration's loads runs in the MFMA shadows of k-step 2
-            // (this iteration's loads were all fired in steps 0-1); past the last chunk every source is
-            // the zero page: branch-free, harmless
+            // (this iteration's loads were all fired in steps 0-1); past the last chunk the offsets are out of
+            // range or point at data nobody reads: branch-free, harmless
             if (step == 2) prepare(c + S);
             const int q = ((step * 2) + fhalf) ^ fsw;          // physical quad of logical quad 2*step + half
             f32x4 af[TM], bf[TN];
@@ -328,6 +368,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
             }
         }
     }
+#endif
 }
 
 // =====================================================================================================
@@ -470,18 +511,17 @@ FastDiv make_fastdiv(unsigned d) {
     return f;
 }
 
-enum TileCfg { W1_64x32 = 0, W1_64x64, W4_128x64, W4_64x64, W4_128x128, W4_256x32, N_TILES };
-static const char* kTileNames[N_TILES] = {"w1,64x32", "w1,64x64", "w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32"};
+enum TileCfg { W4_128x64 = 0, W4_64x64, W4_128x128, W4_256x32, N_TILES };
+static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32"};
 
-// N decides the column tile; M decides whether single-wave blocks (private LDS ring, no barrier) still
-// give every SIMD several waves, or whether the tile must be shared by 4 waves to keep L2->LDS traffic
-// per FLOP down (small M, wide N).  CAPF_TILE=<index> forces a tile (micro-benchmark tuning only).
+// N decides the column tile, M how tall it can be while the grid still fills 256 CUs several times over.
+// CAPF_TILE=<index> forces a tile (micro-benchmark tuning only).
 static TileCfg pick_tile(const GemmArgs& a) {
     static const int forced = [] { const char* e = getenv("CAPF_TILE"); return e ? atoi(e) : -1; }();
     if (forced >= 0 && forced < N_TILES) return (TileCfg)forced;
     // measured on MI355X (tools/bench_conv.py, batch 64): N <= 32 -> 256x32 (69 TF on 32->32@64^2 vs 45-55 for
-    // the others); N <= 64 -> 128x64 for big M (95 TF on 64->64@64^2), 64x64 otherwise; the single-wave
-    // blocks (w1,*) lose 15-25 % to their extra L2->LDS traffic and are kept for experiments only.
+    // the others); N <= 64 -> 128x64 for big M (95 TF on 64->64@64^2), 64x64 otherwise; single-wave
+    // blocks (private LDS ring, no barrier) lost 15-25 % to their extra L2->LDS traffic and were dropped.
     if (a.N <= 32) return ((long)a.M >= 256L * 512) ? W4_256x32 : W4_64x64;
     if (a.N <= 64) return ((long)a.M >= 128L * 512) ? W4_128x64 : W4_64x64;
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -544,6 +584,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
         a.spread = 0ull;
         for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
         if (a.act == ACT_GELU) return hipErrorInvalidValue;
+        if (a.Cin % 4 == 0 && a.ks * a.ks > 32) return hipErrorInvalidValue;   // 32-bit tap masks (ks <= 5)
         if (a.Cin % 4 != 0) {
             dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64)), block(256);
             hipLaunchKernelGGL((igemm_f32_smallc_kernel<128, 64, 64, 32>), grid, block, 0, s, a);
@@ -551,8 +592,6 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
         }
     }
     switch (pick_tile(a)) {
-        case W1_64x32: return launch_cfg<1, 64, 32, 64, 32, 3>(a, s);
-        case W1_64x64: return launch_cfg<1, 64, 64, 64, 64, 3>(a, s);
         case W4_128x64: return launch_cfg<4, 128, 64, 64, 32, 2>(a, s);
         case W4_64x64: return launch_cfg<4, 64, 64, 32, 32, 3>(a, s);
         case W4_128x128: return launch_cfg<4, 128, 128, 64, 64, 2>(a, s);
