@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: backbone convs on bf16 MFMA (configs[2]/[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
-    ap.add_argument("--lanes", type=int, default=1, help="1: independent backbone branches on side streams (default); 0: one stream")
+    ap.add_argument("--lanes", type=int, default=-1,
+                    help="independent backbone branches: 2 grouped launches (fp32 default), 1 side streams (bf16 default), 0 program order")
     return ap.parse_args()
 
 
@@ -119,7 +120,8 @@ def main():
     img, k2d, kc0, gt = img.to(dev), k2d.to(dev), kc.to(dev), gt.to(dev)
     kc_work = kc0.clone()
     stream = torch.cuda.current_stream(dev)
-    model.engine_for(img).set_lanes(a.lanes)
+    if a.lanes >= 0:
+        model.engine_for(img).set_lanes(a.lanes)
 
     if a.train:
         from capf.optim import FusedAdamW, flatten_

@@ -78,20 +78,133 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     return a;
 }
 
-int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev) {
+// one non-control op on stream s
+int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
     auto ptr = [&](int buf) -> float* {
         if (buf >= 0) return bptr(buf, batch);
         return nullptr;
     };
+    switch (op.kind) {
+        case OP_GEMM: {
+            if (op.bf16) HIP_TRY(launch_gemm_bf16(gemm_args(op, batch), s));
+            else HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
+            break;
+        }
+        case OP_FUSE: {
+            if (op.i0 == 1 && !debug) break;
+            FuseSumArgs a{};
+            a.n_in = op.n_in;
+            for (int i = 0; i < op.n_in; ++i) {
+                a.in[i] = ptr(op.in[i]);
+                a.shift[i] = op.shift[i];
+            }
+            a.out = ptr(op.out);
+            a.B = batch; a.H = op.H; a.W = op.W; a.C = op.C; a.relu = op.relu;
+            a.bf16 = op.bf16;
+            HIP_TRY(launch_fuse_sum(a, s));
+            break;
+        }
+        case OP_MAXPOOL:
+            HIP_TRY(launch_maxpool3x3s2(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
+            break;
+        case OP_RESIZE:
+            HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
+            break;
+        case OP_PREP_EMBED:
+            HIP_TRY(launch_prep_embed(kcrop, k2d, params[op.p0].ptr, params[op.p1].ptr, params[op.p2].ptr,
+                                      ptr(op.out), batch, op.i0, op.i1, op.C, s));
+            break;
+        case OP_SAMPLE_REF:
+            HIP_TRY(launch_sample_ref(ptr(op.in[0]), kcrop, ptr(op.out), reinterpret_cast<int*>(ptr(op.aux2)),
+                                      batch, op.i0, op.H, op.W, op.C, s, op.bf16));
+            break;
+        case OP_LAYERNORM:
+            HIP_TRY(launch_layernorm(ptr(op.in[0]), op.amap, ptr(op.aux), op.rmap, params[op.p0].ptr,
+                                     params[op.p1].ptr, op.eps, ptr(op.out), (int)(op.rows_per_frame * batch),
+                                     op.C, s));
+            break;
+        case OP_DEFORM: {
+            DeformArgs a{};
+            for (int l = 0; l < op.i1; ++l) {
+                a.feat[l] = ptr(op.in[l]);
+                a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.C[l] = op.lvlC[l];
+                a.U[l] = ptr(op.outs[l]);
+            }
+            a.AO = ptr(op.aux);
+            a.ref = kcrop;
+            a.B = batch; a.J = op.i0; a.L = op.i1; a.NH = op.i2; a.NS = op.i3;
+            a.feat_bf16 = op.bf16;
+            HIP_TRY(launch_deform_sample(a, s));
+            break;
+        }
+        case OP_ATTENTION:
+            HIP_TRY(launch_attention(ptr(op.in[0]), ptr(op.out), op.i0 * batch, op.i1, op.i2, op.i3, s));
+            break;
+        case OP_HEAD:
+            HIP_TRY(launch_head(ptr(op.in[0]), params[op.p0].ptr, params[op.p1].ptr, op.eps, params[op.p2].ptr,
+                                params[op.p3].ptr, out, (int)(op.rows_per_frame * batch), op.C, op.i0, s));
+            break;
+        default: break;
+    }
+    return CAPF_OK;
+}
+
+// Fork/join region as dependency levels on ONE stream: the fp32 convs of a level (one per HRNet branch, or
+// the many small convs of a fuse layer) go out as grouped launches, everything else one by one.  Any
+// topological order is valid on a single stream, and no two buffers of a region share memory
+// (assign_offsets keeps them alive for the whole region).  With `log` every launch is bracketed by
+// events (profiling): log gets (event index, leader op) pairs and member ops point at their leader.
+int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log) {
+    for (const std::vector<int>& level : region_levels[region]) {
+        GemmArgs group[MAXG];
+        int members[MAXG];
+        int n = 0;
+        auto flush = [&]() -> int {
+            if (n == 0) return CAPF_OK;
+            if (log) HIP_TRY(log->mark(s, members, n));
+            HIP_TRY(launch_gemm_f32_group(group, n, s));
+            n = 0;
+            return CAPF_OK;
+        };
+        for (int oi : level) {
+            const Op& op = ops[oi];
+            if (op.kind != OP_GEMM || op.bf16) continue;
+            const GemmArgs a = gemm_args(op, batch);
+            if (!gemm_f32_groupable(a)) continue;
+            group[n] = a;
+            members[n++] = oi;
+            if (n == MAXG) { int rc = flush(); if (rc) return rc; }
+        }
+        { int rc = flush(); if (rc) return rc; }
+        for (int oi : level) {
+            const Op& op = ops[oi];
+            if (op.kind == OP_GEMM && !op.bf16 && gemm_f32_groupable(gemm_args(op, batch))) continue;
+            if (op.kind == OP_FUSE && op.i0 == 1 && !debug) continue;
+            if (log) HIP_TRY(log->mark(s, &oi, 1));
+            int rc = exec_op(op, s, batch);
+            if (rc) return rc;
+        }
+    }
+    return CAPF_OK;
+}
+
+// ev: per-op events (profiling, everything in program order on one stream).  log: per-launch events of
+// the product schedule (grouped launches included).
+int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev, LaunchLog* log) {
     hipStream_t main_stream = s;
-    const bool par = lanes && !ev && side[0];        // profiling runs everything in order on one stream
+    const bool grouped = lanes == 2 && !ev;
+    const bool par = lanes == 1 && !ev && !log && side[0];
     for (int oi = first_op; oi < last_op; ++oi) {
         const Op& op = ops[oi];
         s = (par && op.lane > 0) ? side[op.lane - 1] : main_stream;
         if (ev) HIP_TRY(hipEventRecord(ev[oi], s));
         switch (op.kind) {
             case OP_FORK:
-                if (par) {
+                if (grouped && regions[op.region].second <= last_op) {
+                    int rc = run_region_grouped(main_stream, batch, op.region, log);
+                    if (rc) return rc;
+                    oi = regions[op.region].second;      // continue after the join
+                } else if (par) {
                     HIP_TRY(hipEventRecord(events[op.i1], main_stream));
                     for (int l = 1; l < op.i0; ++l) HIP_TRY(hipStreamWaitEvent(side[l - 1], events[op.i1], 0));
                 }
@@ -104,68 +217,16 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                     }
                 }
                 break;
-            case OP_GEMM: {
-                if (op.bf16) HIP_TRY(launch_gemm_bf16(gemm_args(op, batch), s));
-                else HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
-                break;
+            default: {
+                if (op.kind == OP_FUSE && op.i0 == 1 && !debug) break;
+                if (log) HIP_TRY(log->mark(s, &oi, 1));
+                int rc = exec_op(op, s, batch);
+                if (rc) return rc;
             }
-            case OP_FUSE: {
-                if (op.i0 == 1 && !debug) break;
-                FuseSumArgs a{};
-                a.n_in = op.n_in;
-                for (int i = 0; i < op.n_in; ++i) {
-                    a.in[i] = ptr(op.in[i]);
-                    a.shift[i] = op.shift[i];
-                }
-                a.out = ptr(op.out);
-                a.B = batch; a.H = op.H; a.W = op.W; a.C = op.C; a.relu = op.relu;
-                a.bf16 = op.bf16;
-                HIP_TRY(launch_fuse_sum(a, s));
-                break;
-            }
-            case OP_MAXPOOL:
-                HIP_TRY(launch_maxpool3x3s2(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
-                break;
-            case OP_RESIZE:
-                HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
-                break;
-            case OP_PREP_EMBED:
-                HIP_TRY(launch_prep_embed(kcrop, k2d, params[op.p0].ptr, params[op.p1].ptr, params[op.p2].ptr,
-                                          ptr(op.out), batch, op.i0, op.i1, op.C, s));
-                break;
-            case OP_SAMPLE_REF:
-                HIP_TRY(launch_sample_ref(ptr(op.in[0]), kcrop, ptr(op.out), reinterpret_cast<int*>(ptr(op.aux2)),
-                                          batch, op.i0, op.H, op.W, op.C, s, op.bf16));
-                break;
-            case OP_LAYERNORM:
-                HIP_TRY(launch_layernorm(ptr(op.in[0]), op.amap, ptr(op.aux), op.rmap, params[op.p0].ptr,
-                                         params[op.p1].ptr, op.eps, ptr(op.out), (int)(op.rows_per_frame * batch),
-                                         op.C, s));
-                break;
-            case OP_DEFORM: {
-                DeformArgs a{};
-                for (int l = 0; l < op.i1; ++l) {
-                    a.feat[l] = ptr(op.in[l]);
-                    a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.C[l] = op.lvlC[l];
-                    a.U[l] = ptr(op.outs[l]);
-                }
-                a.AO = ptr(op.aux);
-                a.ref = kcrop;
-                a.B = batch; a.J = op.i0; a.L = op.i1; a.NH = op.i2; a.NS = op.i3;
-                a.feat_bf16 = op.bf16;
-                HIP_TRY(launch_deform_sample(a, s));
-                break;
-            }
-            case OP_ATTENTION:
-                HIP_TRY(launch_attention(ptr(op.in[0]), ptr(op.out), op.i0 * batch, op.i1, op.i2, op.i3, s));
-                break;
-            case OP_HEAD:
-                HIP_TRY(launch_head(ptr(op.in[0]), params[op.p0].ptr, params[op.p1].ptr, op.eps, params[op.p2].ptr,
-                                    params[op.p3].ptr, out, (int)(op.rows_per_frame * batch), op.C, op.i0, s));
-                break;
         }
     }
     if (ev) HIP_TRY(hipEventRecord(ev[last_op], main_stream));
+    if (log) HIP_TRY(log->mark(main_stream, nullptr, 0));
     return CAPF_OK;
 }
 
@@ -193,6 +254,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
     Engine& e = h->e;
     e.cfg = *cfg;
     e.device = device;
+    e.lanes = cfg->compute_dtype == CAPF_BF16 ? 1 : 2;   // grouped launches exist for the fp32 kernels
     if (cfg->compute_dtype != CAPF_F32 && cfg->compute_dtype != CAPF_BF16) {
         g_create_error = "compute_dtype must be CAPF_F32 or CAPF_BF16";
         delete h;
@@ -301,7 +363,8 @@ int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes) {
 
 int capf_set_lanes(capf_handle* h, int on) {
     if (!h) return CAPF_ERR_INVALID;
-    h->e.lanes = on != 0;
+    if (on < 0 || on > 2) return CAPF_ERR_INVALID;
+    h->e.lanes = on;
     return CAPF_OK;
 }
 

@@ -107,6 +107,28 @@ struct TrainLayout {
     size_t total;
 };
 
+// Per-launch event log of the product schedule (capf_forward_profile): launch k is bracketed by ev[k] and
+// ev[k + 1]; leader[k] is the first op of the launch, op_leader[op] the leader of the launch an op rode in.
+struct LaunchLog {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> leader;
+    std::vector<int> op_leader;
+    hipError_t mark(hipStream_t s, const int* members, int n) {
+        hipEvent_t e;
+        hipError_t r = hipEventCreate(&e);
+        if (r != hipSuccess) return r;
+        ev.push_back(e);
+        if (n > 0) {
+            leader.push_back(members[0]);
+            for (int i = 0; i < n; ++i) op_leader[members[i]] = members[0];
+        }
+        return hipEventRecord(e, s);
+    }
+    ~LaunchLog() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+};
+
 struct Engine {
     capf_config cfg{};
     int device = -1;
@@ -120,6 +142,8 @@ struct Engine {
     int n_backbone_ops = 0;
     int cur_lane = 0, cur_region = -1, n_regions = 0, n_events = 0;
     std::vector<std::pair<int, int>> regions;   // [fork op, join op]
+    std::vector<std::vector<std::vector<int>>> region_levels;   // per region: dependency levels -> op indices
+    void schedule_regions();
     std::map<std::string, NamedTensor> named;
     size_t ws_elems_per_frame = 0;
     size_t pack_elems = 0;
@@ -129,7 +153,7 @@ struct Engine {
     size_t ws_bytes = 0;
     bool packed = false;
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
-    bool lanes = true;             // run fork/join regions on side streams (capf_set_lanes)
+    int lanes = 2;                 // fork/join regions: 0 in program order, 1 on side streams, 2 as grouped launches (capf_set_lanes)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> events;
     int last_batch = 0;
@@ -174,7 +198,9 @@ struct Engine {
     // ---- execution (engine.cpp)
     float* bptr(int buf, int batch) const { return ws + bufs[buf].offset * (size_t)batch; }
     int repack(hipStream_t s, bool lifter_only = false);
-    int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr);
+    int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr, LaunchLog* log = nullptr);
+    int exec_op(const Op& op, hipStream_t s, int batch);
+    int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log);
     GemmArgs gemm_args(const Op& op, int batch) const;
 };
 

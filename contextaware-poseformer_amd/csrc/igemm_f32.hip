@@ -58,6 +58,11 @@ __device__ __forceinline__ int fast_div(int n, FastDiv d) {
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
+// (diagnosis, CAPF_ABLATE=7) per-block timeline: 8 x u64 per block = {t_entry, t_prologue_done, t_loop_done,
+// t_exit, realtime_entry, hw_id, xcc_id, realtime_exit}; read back with capf_debug_timeline()
+static constexpr int DBG_BLOCKS = 8192;
+__device__ unsigned long long capf_dbg_timeline[DBG_BLOCKS * 8];
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -67,9 +72,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // PLAIN: out / res rows are addressed with a plain leading dimension (every conv, most linears);
 // otherwise the (G, S1, S2) row maps of the lifter's strided token views are evaluated per row.
 // ABL: ablation for diagnosis only (0 = product kernel; 1 = no DMA inside the K loop; 2 = no MFMA)
-template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL = 0>
-__global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
+//
+// igemm_tile computes ONE output tile (logical tile id `bid`, split-K slice `ky`) with the calling block;
+// `lds` is the block's ring (S stages).  It is the body of both the one-problem kernel and the grouped kernel.
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist on the device side only
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL>
+__device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, const int ky, float* __restrict__ lds,
+                                           const int dbg_block) {
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -81,20 +90,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     static_assert((BM / WM) * (BN / WN) == NW, "wave grid");
     static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows per DMA round");
 
-    __shared__ __attribute__((aligned(16))) float lds[S * STAGE];
-
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+    if (ABL == 7) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware tile order: physical block b runs on XCD b % 8; give each XCD a contiguous range of
-    // logical tiles (bijective for any grid size).
-    const int nblk = gridDim.x;
-    int bid;
-    {
-        const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
     const int nbn = (p.N + BN - 1) / BN;
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
 
     const int nchunks = p.Kpad / BK;
     // split-K (rows mode, weight gradients): grid.y slices the chunk range, each slice writes its own slab
-    const int c_begin = blockIdx.y * p.cps;
+    const int c_begin = ky * p.cps;
     const int c_end = min(nchunks, c_begin + p.cps);
 
     // Both operands are fetched with `buffer_load_dwordx4 ... lds`: a block-uniform resource descriptor
@@ -245,9 +246,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     const int fhalf = lane >> 5;              // which 4-wide k half of an 8-wide step this lane feeds
 
     // Pipeline.  Chunks c+1 .. c+S-2 are in flight at the top of iteration c; chunk c+S-1 is fired into
-    // the stage that iteration c-1 read, AFTER this iteration's barrier (every wave of the block has then
-    // finished reading it), between the MFMAs of the first two k-steps.  Single-wave blocks need no
-    // barrier: the wave's own counted vmcnt orders its DMA against its ds_reads.
+    // the stage that iteration c-1 read, AFTER the barrier that closed iteration c-1 (every wave of the
+    // block has then finished reading it), between the MFMAs of the first two k-steps.
     constexpr int PER_STEP = (NLOAD + 1) / 2;
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) {
@@ -257,25 +257,50 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     }
     int st_read = 0, st_fill = S - 1;
     prepare(c_begin + S - 1);    // sources of the chunk fired in iteration 0
-    for (int c = c_begin; c < c_end; ++c) {
-        wait_vmcnt<(S - 2) * NLOAD>();
-        if (NW > 1) __builtin_amdgcn_s_barrier();
-        const float* As = lds + st_read * STAGE;
+
+    // Fragment registers are double buffered: the ds_read_b128 of k-step s+1 are issued BEFORE the MFMAs
+    // of k-step s, so the ~130-cycle LDS latency hides under 8+ x 64 MFMA cycles instead of stalling the
+    // wave four times per chunk.  The step-0 fragments of chunk c+1 are read during step 3 of chunk c,
+    // right after the chunk-boundary wait + barrier.
+    f32x4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](int stage, int step, int buf) {
+        const float* As = lds + stage * STAGE;
         const float* Bs = As + BM * BK;
+        const int q = ((step * 2) + fhalf) ^ fsw;              // physical quad of logical quad 2*step + half
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[buf][i] = *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BK + q * 4]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bf[buf][j] = *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BK + q * 4]);
+    };
+    wait_vmcnt<(S - 2) * NLOAD>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0);
+    if (ABL == 7) dbg_t1 = __builtin_amdgcn_s_memtime();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int st_next = (st_read + 1 == S) ? 0 : st_read + 1;
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             // the address arithmetic of the NEXT iteration's loads runs in the MFMA shadows of k-step 2
             // (this iteration's loads were all fired in steps 0-1); past the last chunk the offsets are out of
             // range or point at data nobody reads: branch-free, harmless
             if (step == 2) prepare(c + S);
-            const int q = ((step * 2) + fhalf) ^ fsw;          // physical quad of logical quad 2*step + half
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BK + q * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BK + q * 4]);
+            constexpr bool NO_DMA = ABL == 1 || ABL == 6, NO_LDS = ABL == 3 || ABL == 6, NO_SYNC = ABL == 4 || ABL == 6;
+            if (step < 3) {
+                if (!NO_LDS) read_frags(st_read, step + 1, (step + 1) & 1);
+            } else if (NO_SYNC) {
+                if (!NO_LDS) read_frags(st_next, 0, 0);
+            } else {
+                // chunk boundary: chunk c+1 has landed (all but the S-2 youngest chunks), every wave's
+                // fragment reads of chunk c have returned (lgkmcnt) -> after the barrier stage st_read may
+                // be overwritten by the loads fired in iteration c+1
+                wait_vmcnt<(S - 2) * NLOAD>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (!NO_LDS) read_frags(st_next, 0, 0);
+            }
+            const int fb = step & 1;
             int fired = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -283,11 +308,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
-                        else { acc[i][j][e] += af[i][e] * bf[j][e]; }   // (ablation only)
+                        if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fb][j][e], af[fb][i][e], acc[i][j], 0, 0, 0);
+                        else { acc[i][j][e] += af[fb][i][e] * bf[fb][j][e]; }   // (ablation only)
                         if (step < 2 && fired < PER_STEP) {
                             const int idx = step * PER_STEP + fired;
-                            if (idx < NLOAD && ABL != 1) fire(idx, st_fill);
+                            if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
                             ++fired;
                         }
                     }
@@ -295,14 +320,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
 #pragma unroll
                 for (int f = TM * TN * 4; f < PER_STEP; ++f) {
                     const int idx = step * PER_STEP + f;
-                    if (idx < NLOAD && ABL != 1) fire(idx, st_fill);
+                    if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
                 }
             }
         }
-        st_read = (st_read + 1 == S) ? 0 : st_read + 1;
+        st_read = st_next;
         st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
     }
     wait_vmcnt<0>();
+    if (ABL == 7) dbg_t2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue.  The MFMAs were issued with the WEIGHTS as the A operand, so the accumulator holds the
     // transposed tile: C/D map of the 32x32 MFMA gives this lane ONE output row m = lane & 31 and, per
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     // a short-K tile is issue-bound), bias and residual come in as 16-byte loads, and a row's address is
     // computed once per lane.  Residuals are loaded for the whole tile before anything is stored (an
     // in-place residual aliases `out`).
+    if (ABL == 5 && p.M > 0) return;     // (ablation) no epilogue; the condition is opaque to the compiler, the MFMAs stay
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
@@ -321,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
         float rs = 1.0f;            // per-row scale of the branch output (DropPath keep mask / keep_prob)
         if (m_ok) {
             if (p.rscale) rs = p.rscale[m / p.rs_div];
-            o_row = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (long)blockIdx.y * p.split_stride;
+            o_row = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (long)ky * p.split_stride;
             if (p.res) r_row = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : rowmap(p.rmap, m);
         }
 #pragma unroll
@@ -359,7 +386,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
                     v[e] = t;
                 }
                 if (vec_ok) {
-                    if (m_ok && (full || n < p.N)) *reinterpret_cast<f32x4*>(p.out + o_row + n) = v;
+                    if (m_ok && (full || n < p.N)) {
+                        if (ABL == 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.out + o_row + n));
+                        else *reinterpret_cast<f32x4*>(p.out + o_row + n) = v;
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -367,6 +397,70 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
                 }
             }
         }
+    }
+    if (ABL == 7 && tid == 0 && dbg_block < DBG_BLOCKS && ky == 0) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();   // stores still in flight
+        unsigned long long* d = capf_dbg_timeline + (size_t)dbg_block * 8;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = t3;
+        d[4] = dbg_r0; d[5] = hw; d[6] = xcc; d[7] = r3;
+    }
+}
+#endif
+
+// XCD-aware tile order: physical block b runs on XCD b % 8; give each XCD a contiguous range of logical
+// tiles (bijective for any grid size).
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL = 0>
+__global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float lds[S * (BM + BN) * BK];
+    igemm_tile<NW, BM, BN, WM, WN, S, AMODE, GELU, PLAIN, ABL>(p, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, lds,
+                                                                blockIdx.x);
+#endif
+}
+
+// =====================================================================================================
+// Grouped launch: up to MAXG independent convolutions (the branches of an HRNet module at the same depth,
+// the 1x1 / stride-2 convs of a fuse layer) share ONE grid.  A kernel per conv leaves the chip idle while
+// its last tiles drain and the next kernel's first tiles wait for their first loads (5-10 us out of ~50),
+// and separate streams overlap almost nothing because each kernel fills every CU; inside one grid the
+// block scheduler back-fills every freed slot at once and the problems' prologue / epilogue bursts
+// interleave.  Problems are ordered longest-K first (the 256-channel 8x8 branch has 8x the K loop of the
+// 32-channel 64x64 one); each problem's tile range is padded to a multiple of 8 blocks so that the
+// XCD-contiguous tile order of the single-problem kernel holds per problem.
+struct GroupArgs {
+    GemmArgs g[MAXG];
+    int start[MAXG + 1];   // first physical block of problem i (multiples of 8)
+    int tiles[MAXG];       // real tiles of problem i
+    int cfg[MAXG];         // 0: 128x64 (S=2), 1: 64x64 (S=3), 2: 128x32 (S=2)
+    int n;
+};
+static constexpr int GROUP_LDS_FLOATS = 2 * (128 + 64) * BK;   // 48 KiB: 3 blocks per CU for every configuration
+static_assert(3 * (64 + 64) * BK <= GROUP_LDS_FLOATS && 2 * (128 + 32) * BK <= GROUP_LDS_FLOATS, "group LDS");
+
+template <int ABL>
+__global__ __launch_bounds__(256) void igemm_f32_group_kernel(GroupArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float lds[GROUP_LDS_FLOATS];
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;          // block-uniform
+    const int l = b - ga.start[pi];
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int bid = (l & 7) * per_xcd + (l >> 3);
+    if (bid >= ga.tiles[pi]) return;                              // padding block
+    const GemmArgs& p = ga.g[pi];
+    switch (ga.cfg[pi]) {
+        case 0: igemm_tile<4, 128, 64, 64, 32, 2, AMODE_CONV, false, true, ABL>(p, bid, 0, lds, b); break;
+        case 1: igemm_tile<4, 64, 64, 32, 32, 3, AMODE_CONV, false, true, ABL>(p, bid, 0, lds, b); break;
+        default: igemm_tile<4, 128, 32, 32, 32, 2, AMODE_CONV, false, true, ABL>(p, bid, 0, lds, b); break;
     }
 #endif
 }
@@ -511,8 +605,8 @@ FastDiv make_fastdiv(unsigned d) {
     return f;
 }
 
-enum TileCfg { W4_128x64 = 0, W4_64x64, W4_128x128, W4_256x32, N_TILES };
-static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32"};
+enum TileCfg { W4_128x64 = 0, W4_64x64, W4_128x128, W4_256x32, X_128x64_S3, X_128x32_S3, X_256x32_S3, X_64x64_S2, X_128x128_S3, N_TILES };
+static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32", "x,128x64,s3", "x,128x32,s3", "x,256x32,s3", "x,64x64,s2", "x,128x128,s3"};
 
 // N decides the column tile, M how tall it can be while the grid still fills 256 CUs several times over.
 // CAPF_TILE=<index> forces a tile (micro-benchmark tuning only).
@@ -553,6 +647,18 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
         static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
         if (abl == 1)
             hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 1>), grid, block, 0, s, a);
+        else if (abl == 3)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 3>), grid, block, 0, s, a);
+        else if (abl == 4)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 4>), grid, block, 0, s, a);
+        else if (abl == 5)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 5>), grid, block, 0, s, a);
+        else if (abl == 6)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 6>), grid, block, 0, s, a);
+        else if (abl == 7)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 7>), grid, block, 0, s, a);
+        else if (abl == 8)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 8>), grid, block, 0, s, a);
         else if (abl == 2)
             hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 2>), grid, block, 0, s, a);
         else
@@ -568,6 +674,77 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s);
+
+// conv mode: index-math constants; false if the shape is outside what the kernels address
+static bool prep_conv(GemmArgs& a) {
+    a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.fd_wo = make_fastdiv((unsigned)a.Wo);
+    a.spread = 0ull;
+    for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+    if (a.act == ACT_GELU) return false;
+    if (a.Cin % 4 == 0 && a.ks * a.ks > 32) return false;   // 32-bit tap masks (ks <= 5)
+    return true;
+}
+
+bool gemm_f32_groupable(const GemmArgs& a) {
+    return a.conv && a.Cin % 4 == 0 && a.ks * a.ks <= 32 && a.splits <= 1 && !a.rscale && a.act != ACT_GELU &&
+           a.omap.G == 1 && (!a.res || a.rmap.G == 1) && a.M > 0 && a.N > 0 && a.Kpad % BK == 0 && !a.out_bf16;
+}
+
+hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n == 1) return launch_gemm_f32(list[0], s);
+    if (n > MAXG) return hipErrorInvalidValue;
+    static const int BMs[3] = {128, 64, 128}, BNs[3] = {64, 64, 32};
+    // work in units of one 64x64x32 tile-chunk (1024 MFMA cycles of a CU), per CU
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (!gemm_f32_groupable(list[i])) return hipErrorInvalidValue;
+        total += (double)list[i].M * list[i].N * (list[i].Kpad / BK) / 4096.0;
+    }
+    const double per_cu = total / 256.0;
+    struct Item { int idx, cfg, tiles; double cost; };
+    Item it[MAXG];
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs& a = list[i];
+        const int chunks = a.Kpad / BK;
+        int cfg;
+        if (a.N <= 32) cfg = 2;
+        else {
+            // a tile shares its CU with two others: the big tile must not outlast the whole launch
+            const double big = chunks * 2.0 * 3.0;
+            cfg = (big <= 0.8 * per_cu || chunks * 3.0 > 0.8 * per_cu) && a.M >= 128 ? 0 : 1;
+        }
+        it[i] = Item{i, cfg, ((a.M + BMs[cfg] - 1) / BMs[cfg]) * ((a.N + BNs[cfg] - 1) / BNs[cfg]),
+                     chunks * (BMs[cfg] * BNs[cfg] / 4096.0)};
+    }
+    for (int i = 1; i < n; ++i)                  // longest tile first (insertion sort, n <= 8)
+        for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    GroupArgs ga;
+    ga.n = n;
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs a = list[it[i].idx];
+        a.splits = 1; a.cps = a.Kpad / BK; a.split_stride = 0;
+        if (a.rs_div <= 0) a.rs_div = 1;
+        if ((double)a.M * (double)a.omap.S1 >= 4.0e9 || (a.res && (double)a.M * (double)a.rmap.S1 >= 4.0e9))
+            return hipErrorInvalidValue;
+        if (!prep_conv(a)) return hipErrorInvalidValue;
+        ga.g[i] = a;
+        ga.cfg[i] = it[i].cfg;
+        ga.tiles[i] = it[i].tiles;
+        ga.start[i] = start;
+        start += (it[i].tiles + 7) & ~7;
+    }
+    ga.start[n] = start;
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
+    static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
+    if (abl == 7) hipLaunchKernelGGL((igemm_f32_group_kernel<7>), dim3(start), dim3(256), 0, s, ga);
+    else hipLaunchKernelGGL((igemm_f32_group_kernel<0>), dim3(start), dim3(256), 0, s, ga);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
@@ -579,12 +756,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a.omap.G == 1 && (double)a.M * (double)a.omap.S1 >= 4.0e9) return hipErrorInvalidValue;
     if (a.res && a.rmap.G == 1 && (double)a.M * (double)a.rmap.S1 >= 4.0e9) return hipErrorInvalidValue;
     if (a.conv) {
-        a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
-        a.fd_wo = make_fastdiv((unsigned)a.Wo);
-        a.spread = 0ull;
-        for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
-        if (a.act == ACT_GELU) return hipErrorInvalidValue;
-        if (a.Cin % 4 == 0 && a.ks * a.ks > 32) return hipErrorInvalidValue;   // 32-bit tap masks (ks <= 5)
+        if (!prep_conv(a)) return hipErrorInvalidValue;
         if (a.Cin % 4 != 0) {
             dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64)), block(256);
             hipLaunchKernelGGL((igemm_f32_smallc_kernel<128, 64, 64, 32>), grid, block, 0, s, a);
@@ -596,8 +768,19 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
         case W4_64x64: return launch_cfg<4, 64, 64, 32, 32, 3>(a, s);
         case W4_128x128: return launch_cfg<4, 128, 128, 64, 64, 2>(a, s);
         case W4_256x32: return launch_cfg<4, 256, 32, 64, 32, 2>(a, s);
+        case X_128x64_S3: return launch_cfg<4, 128, 64, 64, 32, 3>(a, s);
+        case X_128x32_S3: return launch_cfg<4, 128, 32, 32, 32, 3>(a, s);
+        case X_256x32_S3: return launch_cfg<4, 256, 32, 64, 32, 3>(a, s);
+        case X_64x64_S2: return launch_cfg<4, 64, 64, 32, 32, 2>(a, s);
+        case X_128x128_S3: return launch_cfg<4, 128, 128, 64, 64, 3>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace capf
+
+// (diagnosis only, not part of include/capf.h) copy the CAPF_ABLATE=7 block timeline to the host
+extern "C" int capf_debug_timeline(unsigned long long* dst, int blocks) {
+    if (blocks > capf::DBG_BLOCKS) blocks = capf::DBG_BLOCKS;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_dbg_timeline), (size_t)blocks * 64);
+}

@@ -44,6 +44,11 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
+// several independent fp32 convs in one grid (see igemm_f32.hip "Grouped launch"); n <= MAXG, every problem
+// must satisfy gemm_f32_groupable()
+static constexpr int MAXG = 8;
+bool gemm_f32_groupable(const GemmArgs& a);
+hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_f32_kernel_name(const GemmArgs& a);   // which template instantiation launch_gemm_f32 picks
 
 // conv weight fold + pack:  Wp[n][(kh*ks+kw)*Cin+ci] = w[n][ci][kh][kw] * gamma[n]/sqrt(var[n]+eps)

@@ -687,6 +687,50 @@ void Engine::assign_offsets() {
     ws_elems_per_frame = top;
 }
 
+// Dependency levels of every fork/join region (run_region_grouped): an op's level is one more than the
+// highest level of any earlier op of the region it conflicts with on a buffer (read-after-write,
+// write-after-read, write-after-write).
+void Engine::schedule_regions() {
+    region_levels.assign(regions.size(), {});
+    for (size_t r = 0; r < regions.size(); ++r) {
+        const int lo = regions[r].first + 1, hi = regions[r].second;
+        std::vector<int> level(hi - lo, 0);
+        auto reads = [&](const Op& o, int b) {
+            if (b < 0) return false;
+            for (int i = 0; i < 4; ++i) if (o.in[i] == b) return true;
+            return o.aux == b;
+        };
+        auto writes = [&](const Op& o, int b) {
+            if (b < 0) return false;
+            if (o.out == b || o.aux2 == b) return true;
+            for (int i = 0; i < 4; ++i) if (o.outs[i] == b) return true;
+            return false;
+        };
+        auto touched = [&](const Op& o) {
+            std::vector<int> v;
+            for (int i = 0; i < 4; ++i) { if (o.in[i] >= 0) v.push_back(o.in[i]); if (o.outs[i] >= 0) v.push_back(o.outs[i]); }
+            if (o.aux >= 0) v.push_back(o.aux);
+            if (o.out >= 0) v.push_back(o.out);
+            if (o.aux2 >= 0) v.push_back(o.aux2);
+            return v;
+        };
+        int max_level = 0;
+        for (int i = lo; i < hi; ++i) {
+            const Op& oi = ops[i];
+            for (int j = lo; j < i; ++j) {
+                const Op& oj = ops[j];
+                bool dep = false;
+                for (int b : touched(oi))
+                    if ((writes(oj, b)) || (reads(oj, b) && writes(oi, b))) { dep = true; break; }
+                if (dep) level[i - lo] = std::max(level[i - lo], level[j - lo] + 1);
+            }
+            max_level = std::max(max_level, level[i - lo]);
+        }
+        region_levels[r].assign(max_level + 1, {});
+        for (int i = lo; i < hi; ++i) region_levels[r][level[i - lo]].push_back(i);
+    }
+}
+
 bool Engine::build() {
     if (cfg.height % 32 != 0 || cfg.width % 32 != 0) {
         err = "height and width must be multiples of 32";
@@ -734,6 +778,7 @@ bool Engine::build() {
             grad_elems += params[i].numel();
         }
     assign_offsets();
+    schedule_regions();
     // pack arena layout
     size_t off = 0;
     for (Pack& pk : packs) {

@@ -146,9 +146,13 @@ int capf_adamw_step(void* stream, float* params, const float* grads, float* exp_
 int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* kcrop_inout, int batch,
                         float* out);
 
-/* Independent branches of the backbone (the 2-4 resolution branches of an HRNet module, the fused
- * outputs, the CPN refine cascades) are enqueued on library-owned side streams, forked from / joined
- * to the caller's stream with events (default on).  0 = everything in order on the caller's stream. */
+/* How the independent branches of the backbone (the 2-4 resolution branches of an HRNet module, the
+ * fused outputs, the CPN refine cascades) are issued:
+ *   0 = everything in program order on the caller's stream;
+ *   1 = on library-owned side streams, forked from / joined to the caller's stream with events;
+ *   2 = (default) by dependency level on the caller's stream, the fp32 convolutions of a level sharing
+ *       ONE grouped launch (bf16 convolutions are launched one by one in this mode).
+ * The results are bit-identical in all three modes. */
 int capf_set_lanes(capf_handle* h, int on);
 
 /* When on, forward also snapshots the token buffer after each block group (tok_ctx/tok_res/tok_joint). */

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Per-block timeline of one fp32 conv launch (diagnosis; needs CAPF_ABLATE=7, GPU box).
+Usage: CAPF_ABLATE=7 python tools/timeline.py --shape 5 [--batch 64]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "contextaware-poseformer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import torch
+from capf import lib as capf
+from bench_conv import SHAPES
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--warm", type=int, default=300)
+    a = ap.parse_args()
+    assert os.environ.get("CAPF_ABLATE") == "7", "run with CAPF_ABLATE=7"
+    ci, co, ks, st, H, W = SHAPES[a.shape]
+    x = torch.randn(a.batch, H, W, ci, device="cuda")
+    w = torch.randn(co, ci, ks, ks, device="cuda") * 0.05
+    wp, bias = capf.pack_conv(w)
+    for _ in range(a.warm):
+        y = capf.conv_nhwc(x, wp, bias, ks, st, act=1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y = capf.conv_nhwc(x, wp, bias, ks, st, act=1)
+    e1.record()
+    torch.cuda.synchronize()
+    lib = capf.load_library()
+    nb = 8192
+    buf = np.zeros((nb, 8), dtype=np.uint64)
+    rc = lib.capf_debug_timeline(buf.ctypes.data_as(ctypes.c_void_p), nb)
+    assert rc == 0
+    used = buf[:, 0] != 0
+    t = buf[used].astype(np.int64)
+    n = t.shape[0]
+    pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+    tot = t[:, 3] - t[:, 0]
+    r0 = (t[:, 4] - t[:, 4].min()) * 10e-3          # us since first block start (100 MHz counter)
+    dr = (t[:, 7] - t[:, 4]).astype(np.float64) * 10.0      # ns per block (100 MHz counter)
+    ghz = float((tot / dr).mean())                          # measured shader clock while the kernel ran
+    print(f"  measured shader clock {ghz * 1e3:.0f} MHz")
+    print(f"shape {SHAPES[a.shape]} batch {a.batch}: event time {e0.elapsed_time(e1) * 1e3:.1f} us, {n} blocks recorded")
+    for name, v in (("prologue", pro), ("k-loop", loop), ("epilogue", epi), ("block", tot)):
+        us = v / ghz / 1e3
+        print(f"  {name:9s} cycles: mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}"
+              f"  p90 {np.percentile(v, 90):9.0f}   (~{us.mean():6.2f} us mean)")
+    end = r0 + tot / ghz / 1e3
+    print(f"  first block start 0.00 us, last block start {r0.max():.2f} us, last block end {end.max():.2f} us")
+    hist, edges = np.histogram(r0, bins=12)
+    print("  block starts per time bin:", " ".join(f"{edges[i]:.0f}us:{hist[i]}" for i in range(len(hist))))
+    # concurrency: how many blocks are alive per CU (hw id = se/sh/cu + xcc)
+    cu = (t[:, 5] >> 8) & 0xFF
+    key = (t[:, 6] & 0xF) * 256 + cu
+    ids, counts = np.unique(key, return_counts=True)
+    print(f"  distinct (xcc, cu) = {len(ids)}, blocks per CU min {counts.min()} max {counts.max()}")
+    k0 = ids[0]
+    sel = np.where(key == k0)[0]
+    order = sel[np.argsort(r0[sel])]
+    print(f"  timeline of CU key {k0}:")
+    for i in order[:16]:
+        print(f"    block start {r0[i]:7.2f} us  prologue {pro[i] / ghz / 1e3:6.2f}  loop {loop[i] / ghz / 1e3:6.2f}  epilogue {epi[i] / ghz / 1e3:6.2f}"
+              f"  end {end[i]:7.2f}")
+
+
+if __name__ == "__main__":
+    main()
