@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
-    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_tensor", "capf_forward_stats",
+    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
 ]
@@ -73,6 +73,8 @@ def load_library():
     lib.capf_op_info.argtypes = [H, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double)]
     lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          POINTER(c_float), c_int]
+    lib.capf_forward_profile_launches.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                                  POINTER(c_float), POINTER(c_int32), c_int]
     P = c_void_p
     lib.capf_forward_train.argtypes = [H, P, P, P, P, c_int, P, P]
     lib.capf_backward.argtypes = [H, P, P, c_int, P, P]
@@ -267,6 +269,19 @@ class Engine:
                                                   c_void_p(out.data_ptr()), ms, n), "forward_profile")
         return list(ms)
 
+    def forward_profile_launches(self, images, k2d, kcrop, out, stream):
+        """One forward of the product schedule with an event pair around every LAUNCH (grouped launches
+        included); returns (ms per op, leader per op): see capf_forward_profile_launches."""
+        B = images.shape[0]
+        self.ensure_workspace(B)
+        n = self.lib.capf_num_ops(self.h)
+        ms = (c_float * n)()
+        leader = (c_int32 * n)()
+        self._check(self.lib.capf_forward_profile_launches(self.h, c_void_p(stream), c_void_p(images.data_ptr()),
+                                                           c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
+                                                           c_void_p(out.data_ptr()), ms, leader, n), "forward_profile_launches")
+        return list(ms), list(leader)
+
     def stats(self, batch):
         n, f = c_int64(), c_double()
         self._check(self.lib.capf_forward_stats(self.h, batch, byref(n), byref(f)), "forward_stats")
@@ -311,6 +326,37 @@ def conv_nhwc(x, wp, bias, ks, stride=1, act=0, residual=None):
     if rc:
         raise CapfError(f"capf_op_conv failed ({rc})")
     return y
+
+
+class ConvDesc(ctypes.Structure):
+    """mirrors include/capf.h :: capf_conv_desc"""
+    _fields_ = [("x", ctypes.c_void_p), ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("y", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int32) for k in ("B", "H", "W", "Cin", "Cout", "ks", "stride", "act")]
+
+
+def conv_nhwc_group(problems):
+    """problems: list of (x, wp, bias, ks, stride, act, residual) -> list of outputs; ONE grouped launch."""
+    import torch
+    lib = load_library()
+    lib.capf_op_conv_group.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ConvDesc)]
+    lib.capf_op_conv_group.restype = ctypes.c_int
+    descs = (ConvDesc * len(problems))()
+    outs = []
+    for d, (x, wp, bias, ks, stride, act, residual) in zip(descs, problems):
+        B, H, W, ci = x.shape
+        co = wp.shape[0]
+        pad = ks // 2
+        ho, wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y = torch.empty(B, ho, wo, co, device=x.device)
+        outs.append(y)
+        d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
+        d.residual = residual.data_ptr() if residual is not None else None
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, co, ks, stride, act
+    rc = lib.capf_op_conv_group(_stream(problems[0][0]), len(problems), descs)
+    if rc:
+        raise CapfError(f"capf_op_conv_group failed ({rc})")
+    return outs
 
 
 def pack_conv_bf16(w, bn=None, eps=1e-5):

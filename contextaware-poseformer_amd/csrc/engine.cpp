@@ -511,6 +511,25 @@ int capf_op_conv(void* stream, const float* x, const float* wp, const float* bia
     return capf::launch_gemm_f32(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_op_conv_group(void* stream, int n, const capf_conv_desc* d) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i) {
+        capf::GemmArgs a{};
+        const int pad = d[i].ks / 2;
+        a.A = d[i].x; a.Wp = d[i].w_packed; a.bias = d[i].bias; a.res = d[i].residual; a.out = d[i].y;
+        a.Ho = (d[i].H + 2 * pad - d[i].ks) / d[i].stride + 1;
+        a.Wo = (d[i].W + 2 * pad - d[i].ks) / d[i].stride + 1;
+        a.M = d[i].B * a.Ho * a.Wo; a.N = d[i].Cout; a.K = d[i].ks * d[i].ks * d[i].Cin; a.Kpad = (a.K + 31) / 32 * 32;
+        a.conv = 1; a.Cin = d[i].Cin; a.H = d[i].H; a.W = d[i].W; a.ks = d[i].ks; a.stride = d[i].stride; a.pad = pad;
+        a.omap = capf::row_ld(d[i].Cout); a.rmap = capf::row_ld(d[i].Cout); a.amap = capf::row_ld(0);
+        a.act = d[i].act;
+        if (!capf::gemm_f32_groupable(a)) return CAPF_ERR_UNSUPPORTED;
+        g[i] = a;
+    }
+    return capf::launch_gemm_f32_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual, float* y,
                    int M, int N, int K, int act) {
     if (K % 32 != 0) return CAPF_ERR_UNSUPPORTED;
@@ -593,6 +612,27 @@ int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc,
     for (int i = 0; i < n && rc == CAPF_OK; ++i)
         if (hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = CAPF_ERR_HIP;
     for (auto& x : ev) (void)hipEventDestroy(x);
+    return rc;
+}
+
+int capf_forward_profile_launches(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
+                                  float* kcrop_inout, int batch, float* out, float* op_ms, int32_t* op_leader, int n_ops) {
+    if (!h || !images_nhwc || !k2d || !kcrop_inout || !out || !op_ms || !op_leader) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    const int n = (int)e.ops.size();
+    if (n_ops < n) return CAPF_ERR_INVALID;
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
+    e.last_batch = batch;
+    capf::LaunchLog log;
+    log.op_leader.assign(n, -1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = e.run(s, batch, 0, n, nullptr, &log);
+    if (rc == CAPF_OK && hipStreamSynchronize(s) != hipSuccess) rc = CAPF_ERR_HIP;
+    for (int i = 0; i < n; ++i) { op_ms[i] = 0.f; op_leader[i] = log.op_leader[i]; }
+    for (size_t k = 0; k < log.leader.size() && rc == CAPF_OK; ++k)
+        if (hipEventElapsedTime(&op_ms[log.leader[k]], log.ev[k], log.ev[k + 1]) != hipSuccess) rc = CAPF_ERR_HIP;
     return rc;
 }
 

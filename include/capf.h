@@ -187,6 +187,19 @@ int capf_op_pack_conv(void* stream, const float* w_oihw, const float* gamma, con
 int capf_op_conv(void* stream, const float* x_nhwc, const float* w_packed, const float* bias,
                  const float* residual, float* y_nhwc, int B, int H, int W, int Cin, int Cout, int ks,
                  int stride, int act);
+/* capf_op_conv_group : up to 8 INDEPENDENT capf_op_conv problems (Cin % 4 == 0, ks <= 5) as ONE grouped
+ *     launch -- what the engine issues for the same-depth convs of the HRNet branches
+ *     (pose_hrnet.py:242-255: the branches of a HighResolutionModule do not depend on each other) and of
+ *     a fuse layer (:257-303).  Results are bit-identical to n capf_op_conv calls. */
+typedef struct capf_conv_desc {
+    const float* x;         /* [B,H,W,Cin] NHWC */
+    const float* w_packed;  /* capf_op_pack_conv output */
+    const float* bias;
+    const float* residual;  /* [B,Ho,Wo,Cout] or NULL */
+    float* y;               /* [B,Ho,Wo,Cout] */
+    int32_t B, H, W, Cin, Cout, ks, stride, act;
+} capf_conv_desc;
+int capf_op_conv_group(void* stream, int n, const capf_conv_desc* convs);
 int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual,
                    float* y, int M, int N, int K, int act);
 /* bf16 twins (igemm_bf16.hip, v_mfma_f32_32x32x16_bf16): x / residual / y are bf16 NHWC, w_packed is bf16
@@ -215,12 +228,20 @@ int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out);
  * capf_op_info: op `index` in launch order: its plan name, the kernel (template instantiation) it
  *   launches at `batch`, and its algorithmic FLOPs at `batch`.
  * capf_forward_profile: capf_forward with a hipEvent pair recorded on `stream` around every launch;
- *   synchronises the stream and writes the elapsed milliseconds per op into op_ms[0..n_ops).        */
+ *   synchronises the stream and writes the elapsed milliseconds per op into op_ms[0..n_ops).  Every op is
+ *   launched on its own, in program order (capf_set_lanes is ignored).
+ * capf_forward_profile_launches: the same for the PRODUCT schedule (capf_set_lanes 0 or 2; side streams are
+ *   not used): one event pair per launch.  op_leader[i] = first op of the launch op i rode in (-1: not
+ *   launched); op_ms[i] = elapsed ms of that launch if i is a leader, else 0.  A grouped launch therefore
+ *   shows up as one time for several ops.                                                              */
 int capf_num_ops(const capf_handle* h);
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel,
                  double* flops);
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
                          float* kcrop_inout, int batch, float* out, float* op_ms, int n_ops);
+int capf_forward_profile_launches(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
+                                  float* kcrop_inout, int batch, float* out, float* op_ms, int32_t* op_leader,
+                                  int n_ops);
 
 #ifdef __cplusplus
 }

@@ -157,3 +157,59 @@ def test_flip_test_single_forward_equals_two_forwards_and_prefetcher_runs():
         got = model.forward_flip_test(images.transpose(0, 1).contiguous(), k2d.transpose(0, 1).contiguous(),
                                       kc.transpose(0, 1).contiguous().clone())
     assert (got.cpu() - want).abs().max().item() < 1e-5
+
+
+# ---- grouped launch (capf_op_conv_group): independent convs of one dependency level in ONE grid ----------
+GROUPS = [
+    # the four branches of an HRNet-W32 stage-4 module at the same depth (conv2 of a BasicBlock: residual + ReLU)
+    [(32, 32, 3, 1, 64, 64, 2, 1, True), (64, 64, 3, 1, 32, 32, 2, 1, True), (128, 128, 3, 1, 16, 16, 2, 1, True),
+     (256, 256, 3, 1, 8, 8, 2, 1, True)],
+    # a fuse layer: 1x1 convs at low resolution + the first stride-2 convs of the down paths, ragged sizes
+    [(64, 32, 1, 1, 12, 10, 3, 0, False), (128, 32, 1, 1, 6, 5, 3, 0, False), (32, 32, 3, 2, 24, 20, 3, 1, False),
+     (32, 64, 3, 2, 24, 20, 3, 0, False), (48, 96, 3, 2, 12, 10, 1, 0, False), (256, 17, 3, 1, 9, 7, 1, 0, False),
+     (32, 32, 3, 1, 5, 3, 7, 1, True), (96, 48, 1, 1, 10, 6, 2, 0, False)],
+    # two problems, one of them a single tile
+    [(64, 64, 3, 1, 8, 8, 1, 1, False), (32, 32, 3, 1, 64, 48, 5, 1, True)],
+]
+
+
+@pytest.mark.parametrize("gi", range(len(GROUPS)))
+def test_grouped_conv_launch_is_bit_identical_to_single_launches(gi):
+    from capf import lib as capf
+    probs, singles = [], []
+    for k, (ci, co, ks, st, H, W, B, act, res) in enumerate(GROUPS[gi]):
+        g = torch.Generator().manual_seed(1000 * gi + k)
+        x = torch.randn(B, H, W, ci, generator=g).cuda()
+        w = (torch.randn(co, ci, ks, ks, generator=g) / (ci * ks * ks) ** 0.5).cuda()
+        wp, bias = capf.pack_conv(w)
+        pad = ks // 2
+        ho, wo = (H + 2 * pad - ks) // st + 1, (W + 2 * pad - ks) // st + 1
+        r = torch.randn(B, ho, wo, co, generator=g).cuda() if res else None
+        probs.append((x, wp, bias, ks, st, act, r))
+        singles.append(capf.conv_nhwc(x, wp, bias, ks, st, act=act, residual=r))
+    outs = capf.conv_nhwc_group(probs)
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(outs, singles)):
+        assert torch.equal(a, b), f"problem {k} of group {gi} differs from its single launch"
+
+
+def test_engine_modes_are_bit_identical():
+    """capf_set_lanes 0 / 1 / 2 (program order, side streams, grouped launches) give the same bits."""
+    import copy, contextlib, io
+    from capf import synth
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = CA_PF(cfg).eval()
+    synth.load_synthetic(model, seed=3, bn_mode="random")
+    model = model.cuda()
+    img, k2d, kc = synth.synth_inputs(3, 128, 96, seed=5, crop_range=(96, 128))
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    outs = []
+    with torch.no_grad():
+        for mode in (0, 1, 2):
+            model.engine_for(img).set_lanes(mode)
+            outs.append(model(img, k2d, kc.clone()).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

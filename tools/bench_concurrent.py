@@ -28,11 +28,16 @@ def main():
         wp, bias = capf.pack_conv(w)
         probs.append((x, wp, bias, torch.cuda.Stream()))
 
+    group = [(x, wp, bias, 3, 1, 1, None) for x, wp, bias, _ in probs]
+
     def run(concurrent):
         main_s = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        if concurrent:
+        if concurrent == "group":
+            for _ in range(a.iters):
+                capf.conv_nhwc_group(group)
+        elif concurrent:
             evs = []
             for x, wp, bias, s in probs:
                 s.wait_stream(main_s)
@@ -50,9 +55,9 @@ def main():
         return e0.elapsed_time(e1) * 1e3 / a.iters
 
     for _ in range(2):
-        run(False), run(True)
+        run(False), run(True), run("group")
     flops = sum(2.0 * a.batch * r * r * c * c * 9 for c, r in (BRANCHES[b] for b in sel))
-    for name, conc in (("back to back", False), ("one stream per branch", True)):
+    for name, conc in (("back to back", False), ("one stream per branch", True), ("one grouped launch", "group")):
         us = run(conc)
         print(f"branches {sel}: {name:22s} {us:8.1f} us per level   {flops / us / 1e6:7.2f} TFLOP/s")
 

@@ -1,8 +1,9 @@
 #!/bin/bash
-# tile sweep of selected shapes on the GPU box
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu 2>&1 | tail -2
-echo "== default"; python tools/bench_conv.py 2>&1 | grep "^\["
-for t in 0 1 3 4 5 6 7; do
+# tile sweep of selected conv shapes on the GPU box: tools/sweep_tiles.sh "<shape ids>" "<tile ids>"
+shapes=${1:-"1 2 3 5 8"}
+tiles=${2:-"0 1 2 3 4 5 6 7 8"}
+echo "== default"; for i in $shapes; do python tools/bench_conv.py --only $i 2>&1 | grep "^\["; done
+for t in $tiles; do
   echo "== CAPF_TILE=$t"
-  for i in 1 2 3 5 8; do CAPF_TILE=$t python tools/bench_conv.py --only $i 2>&1 | grep "^\["; done
+  for i in $shapes; do CAPF_TILE=$t python tools/bench_conv.py --only $i 2>&1 | grep "^\["; done
 done

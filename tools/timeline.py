@@ -20,18 +20,32 @@ def main():
     ap.add_argument("--shape", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--warm", type=int, default=300)
+    ap.add_argument("--group", type=str, default="", help="comma list of HRNet branches (0-3): time ONE grouped launch of their 3x3 convs")
     a = ap.parse_args()
     assert os.environ.get("CAPF_ABLATE") == "7", "run with CAPF_ABLATE=7"
-    ci, co, ks, st, H, W = SHAPES[a.shape]
-    x = torch.randn(a.batch, H, W, ci, device="cuda")
-    w = torch.randn(co, ci, ks, ks, device="cuda") * 0.05
-    wp, bias = capf.pack_conv(w)
+    if a.group:
+        probs = []
+        for b in [int(v) for v in a.group.split(",")]:
+            c, r = [(32, 64), (64, 32), (128, 16), (256, 8)][b]
+            x = torch.randn(a.batch, r, r, c, device="cuda")
+            w = torch.randn(c, c, 3, 3, device="cuda") * 0.05
+            wp, bias = capf.pack_conv(w)
+            probs.append((x, wp, bias, 3, 1, 1, None))
+        launch = lambda: capf.conv_nhwc_group(probs)
+        label = f"group of branches {a.group}"
+    else:
+        ci, co, ks, st, H, W = SHAPES[a.shape]
+        x = torch.randn(a.batch, H, W, ci, device="cuda")
+        w = torch.randn(co, ci, ks, ks, device="cuda") * 0.05
+        wp, bias = capf.pack_conv(w)
+        launch = lambda: capf.conv_nhwc(x, wp, bias, ks, st, act=1)
+        label = f"shape {SHAPES[a.shape]}"
     for _ in range(a.warm):
-        y = capf.conv_nhwc(x, wp, bias, ks, st, act=1)
+        launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    y = capf.conv_nhwc(x, wp, bias, ks, st, act=1)
+    launch()
     e1.record()
     torch.cuda.synchronize()
     lib = capf.load_library()
@@ -48,7 +62,7 @@ def main():
     dr = (t[:, 7] - t[:, 4]).astype(np.float64) * 10.0      # ns per block (100 MHz counter)
     ghz = float((tot / dr).mean())                          # measured shader clock while the kernel ran
     print(f"  measured shader clock {ghz * 1e3:.0f} MHz")
-    print(f"shape {SHAPES[a.shape]} batch {a.batch}: event time {e0.elapsed_time(e1) * 1e3:.1f} us, {n} blocks recorded")
+    print(f"{label} batch {a.batch}: event time {e0.elapsed_time(e1) * 1e3:.1f} us, {n} blocks recorded")
     for name, v in (("prologue", pro), ("k-loop", loop), ("epilogue", epi), ("block", tot)):
         us = v / ghz / 1e3
         print(f"  {name:9s} cycles: mean {v.mean():9.0f}  p10 {np.percentile(v, 10):9.0f}  p50 {np.percentile(v, 50):9.0f}"
@@ -66,7 +80,7 @@ def main():
     sel = np.where(key == k0)[0]
     order = sel[np.argsort(r0[sel])]
     print(f"  timeline of CU key {k0}:")
-    for i in order[:16]:
+    for i in order[:40]:
         print(f"    block start {r0[i]:7.2f} us  prologue {pro[i] / ghz / 1e3:6.2f}  loop {loop[i] / ghz / 1e3:6.2f}  epilogue {epi[i] / ghz / 1e3:6.2f}"
               f"  end {end[i]:7.2f}")
 
