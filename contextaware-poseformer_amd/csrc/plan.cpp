@@ -175,10 +175,15 @@ static Tensor hr_basic_block(Engine& e, const std::string& p, const Tensor& x) {
 }
 
 static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, int planes, bool down) {  // :98-136
+    if (down) e.fork(2);             // the projection shortcut only reads x: independent of conv1 / conv2
     Tensor y = e.conv_bn(p + ".conv1", p + ".bn1", x, planes, 1, 1, ACT_RELU, nullptr);
     y = e.conv_bn(p + ".conv2", p + ".bn2", y, planes, 3, 1, ACT_RELU, nullptr);
     Tensor r = x;
-    if (down) r = e.conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes * 4, 1, 1, ACT_NONE, nullptr);
+    if (down) {
+        e.set_lane(1);
+        r = e.conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes * 4, 1, 1, ACT_NONE, nullptr);
+        e.join();
+    }
     return e.conv_bn(p + ".conv3", p + ".bn3", y, planes * 4, 1, 1, ACT_RELU, &r);
 }
 
@@ -198,9 +203,9 @@ static void hr_module(Engine& e, const std::string& p, std::vector<Tensor>& xs, 
     e.join();
     if (branch_out) *branch_out = br;
     std::vector<Tensor> outs(n_out);
-    if (n_out > 1) e.fork(n_out);    // each fused output only reads the branch outputs: independent lanes again
+    e.fork(n_out);                   // each fused output only reads the branch outputs: independent lanes again
     for (int i = 0; i < n_out; ++i) {
-        if (n_out > 1) e.set_lane(i);
+        e.set_lane(i);
         Tensor terms[4];
         int shifts[4] = {0, 0, 0, 0};
         for (int j = 0; j < nb; ++j) {
@@ -223,7 +228,7 @@ static void hr_module(Engine& e, const std::string& p, std::vector<Tensor>& xs, 
         }
         outs[i] = fuse_sum(e, p + ".fuse" + std::to_string(i), terms, shifts, nb, br[i], 1);
     }
-    if (n_out > 1) e.join();
+    e.join();
     xs = outs;
 }
 
@@ -241,7 +246,9 @@ void Engine::build_hrnet(Tensor img, Tensor feats[4]) {
         std::vector<Tensor> xs(nb);
         const std::string tp = B + ".transition" + std::to_string(stage - 1) + ".";
         const int npre = (int)pre_ch.size();
+        fork(nb);                    // every transition path reads the previous stage's outputs only
         for (int i = 0; i < nb; ++i) {
+            set_lane(std::min(i, 3));
             const int ch = cfg.hr_channels[i];
             if (i < npre) {
                 if (ch != pre_ch[i])
@@ -259,6 +266,7 @@ void Engine::build_hrnet(Tensor img, Tensor feats[4]) {
                 xs[i] = t;
             }
         }
+        join();
         const int nmod = cfg.hr_modules[stage - 2];
         for (int m = 0; m < nmod; ++m) {
             const bool last = (stage == 4 && m == nmod - 1);          // multi_scale_output=False (:359-360)
@@ -315,10 +323,15 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
         for (int k = 0; k < nblk[li]; ++k) {                                               // :58-93, :119-133
             const std::string p = R + ".layer" + std::to_string(li + 1) + "." + std::to_string(k);
             const int st = (k == 0) ? strides[li] : 1;
+            if (k == 0) fork(2);         // projection shortcut: independent of conv1 / conv2
             Tensor y = conv_bn(p + ".conv1", p + ".bn1", x, planes[li], 1, 1, ACT_RELU, nullptr);
             y = conv_bn(p + ".conv2", p + ".bn2", y, planes[li], 3, st, ACT_RELU, nullptr);
             Tensor r = x;
-            if (k == 0) r = conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes[li] * 4, 1, st, ACT_NONE, nullptr);
+            if (k == 0) {
+                set_lane(1);
+                r = conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes[li] * 4, 1, st, ACT_NONE, nullptr);
+                join();
+            }
             x = conv_bn(p + ".conv3", p + ".bn3", y, planes[li] * 4, 1, 1, ACT_RELU, &r);
         }
         c[li] = x;

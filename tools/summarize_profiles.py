@@ -47,7 +47,7 @@ def main():
                 for r in rows:
                     if "capf" not in r["Name"]:
                         continue
-                    fo.write(f"\"{r['Name']}\",{short(r['Name'])},{r['Calls']},{float(r['TotalDurationNs']) / 1e6:.3f},"
+                    fo.write(f"\"{r['Name']}\",\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e6:.3f},"
                              f"{float(r['AverageNs']) / 1e3:.2f},{r['Percentage']},{float(r['MinNs']) / 1e3:.2f},"
                              f"{float(r['MaxNs']) / 1e3:.2f}\n")
             print("wrote", dst)
