@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
-    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
+    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
 ]
@@ -268,6 +268,18 @@ class Engine:
                                                   c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
                                                   c_void_p(out.data_ptr()), ms, n), "forward_profile")
         return list(ms)
+
+    def op_schedule(self):
+        """[(region, level, lane, reads, writes)] per op: see capf_op_schedule."""
+        self.lib.capf_op_schedule.argtypes = [c_void_p, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                              POINTER(c_int32), POINTER(c_int32)]
+        out = []
+        for i in range(self.lib.capf_num_ops(self.h)):
+            rg, lv, ln = c_int32(), c_int32(), c_int32()
+            rd, wr = (c_int32 * 5)(), (c_int32 * 6)()
+            self._check(self.lib.capf_op_schedule(self.h, i, byref(rg), byref(lv), byref(ln), rd, wr), "op_schedule")
+            out.append((rg.value, lv.value, ln.value, [v for v in rd if v != -1], [v for v in wr if v != -1]))
+        return out
 
     def forward_profile_launches(self, images, k2d, kcrop, out, stream):
         """One forward of the product schedule with an event pair around every LAUNCH (grouped launches

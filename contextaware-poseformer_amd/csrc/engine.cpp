@@ -593,6 +593,35 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     return CAPF_OK;
 }
 
+int capf_op_schedule(const capf_handle* h, int index, int32_t* region, int32_t* level, int32_t* lane, int32_t* reads,
+                     int32_t* writes) {
+    if (!h || index < 0 || index >= (int)h->e.ops.size()) return CAPF_ERR_INVALID;
+    const capf::Engine& e = h->e;
+    const capf::Op& op = e.ops[index];
+    const bool control = op.kind == capf::OP_FORK || op.kind == capf::OP_JOIN;
+    if (region) *region = control ? -1 : op.region;
+    if (lane) *lane = op.lane;
+    if (level) {
+        *level = -1;
+        if (!control && op.region >= 0) {
+            const auto& lv = e.region_levels[op.region];
+            for (size_t l = 0; l < lv.size(); ++l)
+                for (int oi : lv[l])
+                    if (oi == index) *level = (int32_t)l;
+        }
+    }
+    if (reads) {
+        for (int i = 0; i < 4; ++i) reads[i] = op.in[i];
+        reads[4] = op.aux;
+    }
+    if (writes) {
+        writes[0] = op.out;
+        writes[1] = op.aux2;
+        for (int i = 0; i < 4; ++i) writes[2 + i] = op.outs[i];
+    }
+    return CAPF_OK;
+}
+
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
                          int batch, float* out, float* op_ms, int n_ops) {
     if (!h || !images_nhwc || !k2d || !kcrop_inout || !out || !op_ms) return CAPF_ERR_INVALID;

@@ -237,6 +237,12 @@ int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out);
 int capf_num_ops(const capf_handle* h);
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel,
                  double* flops);
+/* capf_op_schedule: where op `index` sits in the launch schedule: its fork/join region (-1 outside / control op),
+ *   its dependency level inside the region (capf_set_lanes mode 2 issues a region level by level), its lane
+ *   (mode 1: side stream), and the workspace buffer ids it reads (5 slots) and writes (6 slots), -1 = unused,
+ *   -2 = the external image.  Lets host-side tests check that the schedule is a valid topological order. */
+int capf_op_schedule(const capf_handle* h, int index, int32_t* region, int32_t* level, int32_t* lane,
+                     int32_t reads[5], int32_t writes[6]);
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
                          float* kcrop_inout, int batch, float* out, float* op_ms, int n_ops);
 int capf_forward_profile_launches(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,

@@ -100,3 +100,40 @@ def test_errors_are_reported():
         m = CA_PF(_cfg("hrnet_32"))
     with pytest.raises(CapfError):                                 # no CPU fallback
         m(torch.zeros(1, 256, 192, 3), torch.zeros(1, 17, 2), torch.zeros(1, 17, 2))
+
+
+@pytest.mark.parametrize("backbone", ["hrnet_32", "hrnet_48", "cpn"])
+def test_region_schedule_is_a_valid_topological_order(backbone):
+    """capf_set_lanes mode 2 issues every fork/join region level by level (the fp32 convs of a level in one
+    grouped launch).  Host-side check on the static plan: inside a region an op's level is above the level of
+    every earlier op it conflicts with on a workspace buffer, and the ops of one level are pairwise
+    independent (so one grid may run them concurrently)."""
+    from capf import Engine
+    from mvn.models import _native
+    eng = Engine(_native.make_capf_config(_cfg(backbone), 256, 192), device=None)
+    sched = eng.op_schedule()
+    regions = {}
+    for i, (rg, lv, ln, rd, wr) in enumerate(sched):
+        if rg >= 0:
+            assert lv >= 0, f"op {i} of region {rg} has no level"
+            regions.setdefault(rg, []).append(i)
+    assert len(regions) >= (20 if backbone != "cpn" else 5)
+    widest = 0
+    for rg, ops in regions.items():
+        by_level = {}
+        for a_pos, a in enumerate(ops):
+            _, la, _, ra, wa = sched[a]
+            by_level.setdefault(la, []).append(a)
+            for b in ops[:a_pos]:                       # b precedes a in program order
+                _, lb, _, rb, wb = sched[b]
+                conflict = (set(wb) & (set(ra) | set(wa))) or (set(rb) & set(wa))
+                if conflict:
+                    assert la > lb, f"op {a} (level {la}) depends on op {b} (level {lb}) via buffers {conflict}"
+        for lv, members in by_level.items():
+            widest = max(widest, len(members))
+            for x in members:
+                for y in members:
+                    if x < y:
+                        assert not (set(sched[x][4]) & (set(sched[y][3]) | set(sched[y][4])))
+                        assert not (set(sched[y][4]) & set(sched[x][3]))
+    assert widest >= 4          # e.g. the four branches of a stage-4 module / the CPN refine cascades
