@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: backbone convs on bf16 MFMA (configs[2]/[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
     ap.add_argument("--lanes", type=int, default=-1,
-                    help="independent backbone branches: 2 grouped launches (fp32 default), 1 side streams (bf16 default), 0 program order")
+                    help="independent backbone branches: 2 grouped launches (default), 1 side streams, 0 program order")
     return ap.parse_args()
 
 
@@ -185,7 +185,7 @@ def main():
                     if l >= 0:
                         members.setdefault(l, []).append(i)
                 for l, ops_ in members.items():
-                    kern = table[l][1] if len(ops_) == 1 else "igemm_f32_group"
+                    kern = table[l][1] if len(ops_) == 1 else ("igemm_bf16_group" if table[l][1].startswith("igemm_bf16") else "igemm_f32_group")
                     if not kern or table[l][0].startswith("copy."):
                         continue
                     e = acc.setdefault(kern, [0.0, 0.0, 0])

@@ -155,30 +155,37 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
 // (assign_offsets keeps them alive for the whole region).  With `log` every launch is bracketed by
 // events (profiling): log gets (event index, leader op) pairs and member ops point at their leader.
 int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log) {
+    auto groupable = [&](const Op& op, const GemmArgs& a) {
+        return op.kind == OP_GEMM && (op.bf16 ? gemm_bf16_groupable(a) : gemm_f32_groupable(a));
+    };
     for (const std::vector<int>& level : region_levels[region]) {
-        GemmArgs group[MAXG];
-        int members[MAXG];
-        int n = 0;
-        auto flush = [&]() -> int {
-            if (n == 0) return CAPF_OK;
-            if (log) HIP_TRY(log->mark(s, members, n));
-            HIP_TRY(launch_gemm_f32_group(group, n, s));
-            n = 0;
-            return CAPF_OK;
-        };
-        for (int oi : level) {
-            const Op& op = ops[oi];
-            if (op.kind != OP_GEMM || op.bf16) continue;
-            const GemmArgs a = gemm_args(op, batch);
-            if (!gemm_f32_groupable(a)) continue;
-            group[n] = a;
-            members[n++] = oi;
-            if (n == MAXG) { int rc = flush(); if (rc) return rc; }
+        for (int pass = 0; pass < 2; ++pass) {           // pass 0: fp32 convs, pass 1: bf16 convs
+            GemmArgs group[MAXG];
+            int members[MAXG];
+            int n = 0;
+            auto flush = [&]() -> int {
+                if (n == 0) return CAPF_OK;
+                if (log) HIP_TRY(log->mark(s, members, n));
+                if (pass == 0) HIP_TRY(launch_gemm_f32_group(group, n, s));
+                else HIP_TRY(launch_gemm_bf16_group(group, n, s));
+                n = 0;
+                return CAPF_OK;
+            };
+            for (int oi : level) {
+                const Op& op = ops[oi];
+                if (op.kind != OP_GEMM || (op.bf16 != 0) != (pass == 1)) continue;
+                const GemmArgs a = gemm_args(op, batch);
+                if (!groupable(op, a)) continue;
+                group[n] = a;
+                members[n++] = oi;
+                if (n == MAXG) { int rc = flush(); if (rc) return rc; }
+            }
+            int rc = flush();
+            if (rc) return rc;
         }
-        { int rc = flush(); if (rc) return rc; }
         for (int oi : level) {
             const Op& op = ops[oi];
-            if (op.kind == OP_GEMM && !op.bf16 && gemm_f32_groupable(gemm_args(op, batch))) continue;
+            if (op.kind == OP_GEMM && groupable(op, gemm_args(op, batch))) continue;
             if (op.kind == OP_FUSE && op.i0 == 1 && !debug) continue;
             if (log) HIP_TRY(log->mark(s, &oi, 1));
             int rc = exec_op(op, s, batch);
@@ -254,7 +261,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
     Engine& e = h->e;
     e.cfg = *cfg;
     e.device = device;
-    e.lanes = cfg->compute_dtype == CAPF_BF16 ? 1 : 2;   // grouped launches exist for the fp32 kernels
+    e.lanes = 2;
     if (cfg->compute_dtype != CAPF_F32 && cfg->compute_dtype != CAPF_BF16) {
         g_create_error = "compute_dtype must be CAPF_F32 or CAPF_BF16";
         delete h;

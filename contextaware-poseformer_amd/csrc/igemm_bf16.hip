@@ -46,17 +46,16 @@ __device__ __forceinline__ void wait_vmcnt_b() {
 
 // 4 waves per block, block tile BM x BN, wave tile WM x WN, S LDS stages.  Conv mode only (the lifter's
 // GEMMs stay fp32: its LayerNorm / softmax / residual stream is kept in fp32).
-template <int BM, int BN, int WM, int WN, int S>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist on the device side only
+// one output tile (logical id `bid`) with the calling block; body of the single and the grouped kernel
+template <int BM, int BN, int WM, int WN, int S>
+__device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid, unsigned short* __restrict__ lds) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
     constexpr int NLOAD = RA + RB;
     constexpr int STAGE = (BM + BN) * BKH;                // bf16 elements per stage
     static_assert((BM / WM) * (BN / WN) == 4, "wave grid");
-
-    __shared__ __attribute__((aligned(16))) unsigned short lds[S * STAGE];
 
     const unsigned short* A = reinterpret_cast<const unsigned short*>(p.A);
     const unsigned short* Wp = reinterpret_cast<const unsigned short*>(p.Wp);
@@ -67,12 +66,6 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int nblk = gridDim.x;
-    int bid;
-    {
-        const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, x = b & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
     const int nbn = (p.N + BN - 1) / BN;
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -266,6 +259,48 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
             }
         }
     }
+}
+#endif
+
+__device__ __forceinline__ int xcd_remap_b(int b, int nblk) {   // see igemm_f32.hip :: xcd_remap
+    const int q = nblk >> 3, r = nblk & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int BM, int BN, int WM, int WN, int S>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned short lds[S * (BM + BN) * BKH];
+    igemm_bf16_tile<BM, BN, WM, WN, S>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
+#endif
+}
+
+// Grouped launch (see igemm_f32.hip "Grouped launch"): up to MAXG independent bf16 convs in one grid.
+struct GroupArgsB {
+    GemmArgs g[MAXG];
+    int start[MAXG + 1];
+    int tiles[MAXG];
+    int cfg[MAXG];         // 0: 128x64 (S=2), 1: 64x64 (S=3), 2: 128x32 (S=2)
+    int n;
+};
+static constexpr int GROUP_LDS_HALVES = 2 * (128 + 64) * BKH;      // 48 KiB
+
+__global__ __launch_bounds__(256) void igemm_bf16_group_kernel(GroupArgsB ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned short lds[GROUP_LDS_HALVES];
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
+    const int l = b - ga.start[pi];
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int bid = (l & 7) * per_xcd + (l >> 3);
+    if (bid >= ga.tiles[pi]) return;
+    const GemmArgs& p = ga.g[pi];
+    switch (ga.cfg[pi]) {
+        case 0: igemm_bf16_tile<128, 64, 64, 32, 2>(p, bid, lds); break;
+        case 1: igemm_bf16_tile<64, 64, 32, 32, 3>(p, bid, lds); break;
+        default: igemm_bf16_tile<128, 32, 32, 32, 2>(p, bid, lds); break;
+    }
 #endif
 }
 
@@ -284,6 +319,64 @@ const char* gemm_bf16_kernel_name(const GemmArgs& a) {
 }
 
 // bf16 NHWC conv: A / res / out are bf16, Wp bf16 [N][Kpad] (Kpad % 64 == 0), bias fp32.  Cin % 8 == 0, N % 4 == 0.
+static bool bf16_ok(const GemmArgs& a) {
+    return a.conv && a.Kpad % BKH == 0 && a.Cin % 8 == 0 && a.N % 4 == 0 && a.act != ACT_GELU && a.ks * a.ks <= 32 &&
+           a.M > 0 && a.N > 0;
+}
+
+hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s);
+
+static void prep_conv_b(GemmArgs& a) {
+    a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.fd_wo = make_fastdiv((unsigned)a.Wo);
+    a.spread = 0ull;
+    for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+}
+
+bool gemm_bf16_groupable(const GemmArgs& a) { return bf16_ok(a) && a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale; }
+
+hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n == 1) return launch_gemm_bf16(list[0], s);
+    if (n > MAXG) return hipErrorInvalidValue;
+    static const int BMs[3] = {128, 64, 128}, BNs[3] = {64, 64, 32};
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (!gemm_bf16_groupable(list[i])) return hipErrorInvalidValue;
+        total += (double)list[i].M * list[i].N * (list[i].Kpad / BKH) / 4096.0;
+    }
+    const double per_cu = total / 256.0;
+    struct Item { int idx, cfg, tiles; double cost; };
+    Item it[MAXG];
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs& a = list[i];
+        const int chunks = a.Kpad / BKH;
+        int cfg;
+        if (a.N <= 32) cfg = 2;
+        else cfg = (chunks * 2.0 * 3.0 <= 0.8 * per_cu && a.M >= 128) ? 0 : 1;
+        it[i] = Item{i, cfg, ((a.M + BMs[cfg] - 1) / BMs[cfg]) * ((a.N + BNs[cfg] - 1) / BNs[cfg]),
+                     chunks * (BMs[cfg] * BNs[cfg] / 4096.0)};
+    }
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    GroupArgsB ga;
+    ga.n = n;
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs a = list[it[i].idx];
+        prep_conv_b(a);
+        ga.g[i] = a;
+        ga.cfg[i] = it[i].cfg;
+        ga.tiles[i] = it[i].tiles;
+        ga.start[i] = start;
+        start += (it[i].tiles + 7) & ~7;
+    }
+    ga.start[n] = start;
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
+    hipLaunchKernelGGL(igemm_bf16_group_kernel, dim3(start), dim3(256), 0, s, ga);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (!a_in.conv || a_in.Kpad % BKH != 0 || a_in.Cin % 8 != 0 || a_in.N % 4 != 0 || a_in.act == ACT_GELU ||

@@ -62,6 +62,8 @@ hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float
                                  int Kpad, hipStream_t s);
 // bf16 conv (igemm_bf16.hip): A / res / out bf16 NHWC, Wp bf16 [N][Kpad], Kpad % 64 == 0, bias fp32
 hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
+bool gemm_bf16_groupable(const GemmArgs& a);
+hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s);   // bf16 twin of launch_gemm_f32_group
 const char* gemm_bf16_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);
 

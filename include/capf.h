@@ -150,8 +150,8 @@ int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* k
  * fused outputs, the CPN refine cascades) are issued:
  *   0 = everything in program order on the caller's stream;
  *   1 = on library-owned side streams, forked from / joined to the caller's stream with events;
- *   2 = (default) by dependency level on the caller's stream, the fp32 convolutions of a level sharing
- *       ONE grouped launch (bf16 convolutions are launched one by one in this mode).
+ *   2 = (default) by dependency level on the caller's stream, the convolutions of a level sharing ONE
+ *       grouped launch.
  * The results are bit-identical in all three modes. */
 int capf_set_lanes(capf_handle* h, int on);
 

@@ -193,16 +193,17 @@ def test_grouped_conv_launch_is_bit_identical_to_single_launches(gi):
         assert torch.equal(a, b), f"problem {k} of group {gi} differs from its single launch"
 
 
-def test_engine_modes_are_bit_identical():
+@pytest.mark.parametrize("dtype,backbone", [("fp32", "hrnet_32"), ("bf16", "hrnet_32"), ("fp32", "cpn"), ("bf16", "hrnet_48")])
+def test_engine_modes_are_bit_identical(dtype, backbone):
     """capf_set_lanes 0 / 1 / 2 (program order, side streams, grouped launches) give the same bits."""
     import copy, contextlib, io
     from capf import synth
     from mvn.models.conpose import CA_PF
     from mvn.utils.cfg import backbone_preset, config
-    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg = backbone_preset(copy.deepcopy(config), backbone)
     cfg.model.backbone.fix_weights = True
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg).eval()
+        model = CA_PF(cfg, compute_dtype=dtype).eval()
     synth.load_synthetic(model, seed=3, bn_mode="random")
     model = model.cuda()
     img, k2d, kc = synth.synth_inputs(3, 128, 96, seed=5, crop_range=(96, 128))
