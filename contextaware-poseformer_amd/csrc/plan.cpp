@@ -338,7 +338,7 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
     }
     // globalNet.forward (globalNet.py:61-83); res_out = [x4,x3,x2,x1]
     const std::string G = "backbone.global_net";
-    Tensor fms[4], up;
+    Tensor fms[4];
     for (int i = 0; i < 4; ++i) {
         const Tensor& src = c[3 - i];
         const std::string lp = G + ".laterals." + std::to_string(i);

@@ -276,103 +276,94 @@ hipError_t launch_transpose_pad(const float* in, RowMap imap, int M, int C, floa
 }
 
 // ---- backward of the tiny attention (Attention.forward pose_dformer.py:46-59) -----------------------
-// One thread per (group, head, token t): as QUERY t it produces dq_t, as KEY t it produces dk_t and dv_t
-// (probabilities are recomputed from the saved qkv; N <= 17 so the N^2 recompute is a few hundred FMAs).
+// One wave per (group, head): q, k, v and dO of the N <= 17 tokens are staged in LDS (coalesced reads of the
+// d contiguous floats of each token), the N x N probabilities are recomputed from the saved qkv exactly as
+// the forward computes them, and dq / dk / dv go out as d contiguous floats per token.
+//   S = scale q k^T, P = softmax(S), dP = dO v^T, dS = P o (dP - rowsum(P o dP)),
+//   dq = scale dS k, dk = scale dS^T q, dv = P^T dO
 template <int NMAX>
-__global__ void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
-                                     float* __restrict__ dqkv, int groups, int N, int heads, int d, float scale) {
-    const long tt = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    const long total = (long)groups * heads * N;
-    if (tt >= total) return;
-    const int t = (int)(tt % N);
-    const int h = (int)((tt / N) % heads);
-    const long g = tt / ((long)N * heads);
+__global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                           float* __restrict__ dqkv, int N, int heads, int d, float scale) {
+    extern __shared__ float sm[];
+    const int ld = d + 1;                      // padded token stride: rows of different tokens fall in different banks
+    float* q = sm;
+    float* k = q + NMAX * ld;
+    float* v = k + NMAX * ld;
+    float* go = v + NMAX * ld;
+    float* P = go + NMAX * ld;                 // [NMAX][NMAX + 1]
+    float* dS = P + NMAX * (NMAX + 1);
+    const int lane = threadIdx.x;
+    const long g = blockIdx.x / heads;
+    const int h = blockIdx.x - (int)g * heads;
     const int Cq = 3 * heads * d, Co = heads * d;
     const float* qb = qkv + (g * N) * Cq + h * d;
-    const float* kb = qb + heads * d;
-    const float* vb = qb + 2 * heads * d;
     const float* dob = dO + (g * N) * Co + h * d;
-
-    auto dot = [&](const float* a, const float* b) {
-        float s = 0.f;
-        for (int c = 0; c < d; c += 4) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(a + c), y = *reinterpret_cast<const f32x4*>(b + c);
-            s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    const int nd = N * d;
+    for (int idx = lane; idx < nd; idx += 64) {
+        const int t = idx / d, c = idx - t * d;
+        const float* row = qb + (long)t * Cq + c;
+        q[t * ld + c] = row[0];
+        k[t * ld + c] = row[heads * d];
+        v[t * ld + c] = row[2 * heads * d];
+        go[t * ld + c] = dob[(long)t * Co + c];
+    }
+    __syncthreads();
+    for (int idx = lane; idx < N * N; idx += 64) {
+        const int i = idx / N, j = idx - i * N;
+        float s = 0.f, dp = 0.f;
+        for (int c = 0; c < d; ++c) {
+            s += q[i * ld + c] * k[j * ld + c];
+            dp += go[i * ld + c] * v[j * ld + c];
         }
-        return s;
-    };
-    // probabilities / score gradients of row i: p[j], ds[j]
-    auto row = [&](int i, float* p, float* ds) {
+        P[i * (NMAX + 1) + j] = s * scale;
+        dS[i * (NMAX + 1) + j] = dp;
+    }
+    __syncthreads();
+    if (lane < N) {                            // one softmax row per lane
+        float* p = P + lane * (NMAX + 1);
+        float* ds = dS + lane * (NMAX + 1);
         float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            p[j] = (j < N) ? dot(qb + (long)i * Cq, kb + (long)j * Cq) * scale : -INFINITY;
-            mx = fmaxf(mx, p[j]);
-        }
+        for (int j = 0; j < N; ++j) mx = fmaxf(mx, p[j]);
         float den = 0.f;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) { p[j] = (j < N) ? expf(p[j] - mx) : 0.f; den += p[j]; }
+        for (int j = 0; j < N; ++j) { p[j] = expf(p[j] - mx); den += p[j]; }
         float D = 0.f;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            p[j] /= den;
-            ds[j] = (j < N) ? dot(dob + (long)i * Co, vb + (long)j * Cq) : 0.f;    // dp_ij
-            D += p[j] * ds[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) ds[j] = p[j] * (ds[j] - D);
-    };
-
-    float p[NMAX], ds[NMAX];
-    // query role
-    row(t, p, ds);
-    float* dq = dqkv + (g * N + t) * Cq + h * d;
-    for (int c = 0; c < d; ++c) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j)
-            if (j < N) s += ds[j] * kb[(long)j * Cq + c];
-        dq[c] = s * scale;
+        for (int j = 0; j < N; ++j) { p[j] /= den; D += p[j] * ds[j]; }
+        for (int j = 0; j < N; ++j) ds[j] = p[j] * (ds[j] - D);
     }
-    // key role: column t of P and dS
-    float pk[NMAX], dsk[NMAX];
-#pragma unroll
-    for (int i = 0; i < NMAX; ++i) {
-        pk[i] = dsk[i] = 0.f;
-        if (i < N) {
-            row(i, p, ds);
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j)
-                if (j == t) { pk[i] = p[j]; dsk[i] = ds[j]; }
+    __syncthreads();
+    float* dq = dqkv + (g * N) * Cq + h * d;
+    for (int idx = lane; idx < nd; idx += 64) {
+        const int t = idx / d, c = idx - t * d;
+        float sq = 0.f, sk = 0.f, sv = 0.f;
+        for (int j = 0; j < N; ++j) {
+            sq += dS[t * (NMAX + 1) + j] * k[j * ld + c];
+            sk += dS[j * (NMAX + 1) + t] * q[j * ld + c];
+            sv += P[j * (NMAX + 1) + t] * go[j * ld + c];
         }
-    }
-    float* dk = dq + heads * d;
-    float* dv = dq + 2 * heads * d;
-    for (int c = 0; c < d; ++c) {
-        float sk = 0.f, sv = 0.f;
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i)
-            if (i < N) {
-                sk += dsk[i] * qb[(long)i * Cq + c];
-                sv += pk[i] * dob[(long)i * Co + c];
-            }
-        dk[c] = sk * scale;
-        dv[c] = sv;
+        float* o = dq + (long)t * Cq + c;
+        o[0] = sq * scale;
+        o[heads * d] = sk * scale;
+        o[2 * heads * d] = sv;
     }
 }
 
 hipError_t launch_attention_bwd(const float* qkv, const float* dO, float* dqkv, int groups, int N, int heads, int d,
                                 hipStream_t s) {
-    if (d % 4 != 0) return hipErrorInvalidValue;
-    const long total = (long)groups * heads * N;
     const float scale = 1.0f / sqrtf((float)d);
-    dim3 grid((unsigned)((total + 63) / 64)), block(64);
-    if (N <= 5)
-        hipLaunchKernelGGL(attention_bwd_kernel<5>, grid, block, 0, s, qkv, dO, dqkv, groups, N, heads, d, scale);
-    else if (N <= 17)
-        hipLaunchKernelGGL(attention_bwd_kernel<17>, grid, block, 0, s, qkv, dO, dqkv, groups, N, heads, d, scale);
-    else
+    const long pairs = (long)groups * heads;
+    if (pairs <= 0) return hipSuccess;
+    if (pairs > 0x7fffffffL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)pairs), block(64);
+    if (N <= 5) {
+        const size_t lds = (size_t)(4 * 5 * (d + 1) + 2 * 5 * 6) * sizeof(float);
+        hipLaunchKernelGGL(attention_bwd_kernel<5>, grid, block, lds, s, qkv, dO, dqkv, N, heads, d, scale);
+    } else if (N <= 17) {
+        const size_t lds = (size_t)(4 * 17 * (d + 1) + 2 * 17 * 18) * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(attention_bwd_kernel<17>, grid, block, lds, s, qkv, dO, dqkv, N, heads, d, scale);
+    } else {
         return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
