@@ -37,6 +37,19 @@ def main():
         if concurrent == "group":
             for _ in range(a.iters):
                 capf.conv_nhwc_group(group)
+        elif concurrent == "two chains":      # {first, last} and {middle ...} as two grouped chains on two streams
+            sets = [[group[0], group[-1]], group[1:-1]] if len(group) >= 4 else [group[:1], group[1:]]
+            for gs, (_, _, _, s) in zip(sets, probs):
+                s.wait_stream(main_s)
+                with torch.cuda.stream(s):
+                    for _ in range(a.iters):
+                        if len(gs) > 1:
+                            capf.conv_nhwc_group(gs)
+                        else:
+                            x, wp, bias = gs[0][:3]
+                            capf.conv_nhwc(x, wp, bias, 3, 1, act=1)
+            for _, _, _, s in probs[:2]:
+                main_s.wait_stream(s)
         elif concurrent:
             evs = []
             for x, wp, bias, s in probs:
@@ -55,9 +68,10 @@ def main():
         return e0.elapsed_time(e1) * 1e3 / a.iters
 
     for _ in range(2):
-        run(False), run(True), run("group")
+        run(False), run(True), run("group"), run("two chains")
     flops = sum(2.0 * a.batch * r * r * c * c * 9 for c, r in (BRANCHES[b] for b in sel))
-    for name, conc in (("back to back", False), ("one stream per branch", True), ("one grouped launch", "group")):
+    for name, conc in (("back to back", False), ("one stream per branch", True), ("one grouped launch", "group"),
+                       ("two grouped chains", "two chains")):
         us = run(conc)
         print(f"branches {sel}: {name:22s} {us:8.1f} us per level   {flops / us / 1e6:7.2f} TFLOP/s")
 

@@ -71,6 +71,19 @@ def main():
     print(f"  first block start 0.00 us, last block start {r0.max():.2f} us, last block end {end.max():.2f} us")
     hist, edges = np.histogram(r0, bins=12)
     print("  block starts per time bin:", " ".join(f"{edges[i]:.0f}us:{hist[i]}" for i in range(len(hist))))
+    # occupancy curve: resident blocks (and blocks inside their K loop) averaged per time bin, chip-wide
+    nb_bins = 20
+    T = end.max()
+    t1 = r0 + pro / ghz / 1e3
+    t2 = t1 + loop / ghz / 1e3
+    edges2 = np.linspace(0.0, T, nb_bins + 1)
+    res, inloop = [], []
+    for i in range(nb_bins):
+        lo, hi = edges2[i], edges2[i + 1]
+        res.append(np.clip(np.minimum(end, hi) - np.maximum(r0, lo), 0, None).sum() / (hi - lo))
+        inloop.append(np.clip(np.minimum(t2, hi) - np.maximum(t1, lo), 0, None).sum() / (hi - lo))
+    print("  resident blocks per bin :", " ".join(f"{v:5.0f}" for v in res))
+    print("  blocks in their K loop  :", " ".join(f"{v:5.0f}" for v in inloop))
     # concurrency: how many blocks are alive per CU (hw id = se/sh/cu + xcc)
     cu = (t[:, 5] >> 8) & 0xFF
     key = (t[:, 6] & 0xF) * 256 + cu
