@@ -11,7 +11,7 @@ F32, BF16 = 0, 1
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
-    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
+    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
 ]
@@ -454,4 +454,42 @@ def fliptest_fuse(pred2):
     rc = lib.capf_fliptest_fuse(_stream(pred2), _p(pred2.contiguous()), B, _p(out))
     if rc:
         raise CapfError(f"capf_fliptest_fuse failed ({rc})")
+    return out
+
+
+# ---- N3: affine crop (mvn/utils/img.py) ---------------------------------------------------------------
+def affine_from_center_scale(center, scale, output_size):
+    """get_affine_transform(center, scale, 0, output_size) -> 2x3 float64 numpy matrix (host code, no GPU)."""
+    import numpy as np
+    lib = load_library()
+    lib.capf_affine_from_center_scale.argtypes = [POINTER(c_double), POINTER(c_double), c_int, c_int, POINTER(c_double)]
+    c = (c_double * 2)(float(center[0]), float(center[1]))
+    sc = (c_double * 2)(float(scale[0]), float(scale[1]))
+    m = (c_double * 6)()
+    rc = lib.capf_affine_from_center_scale(c, sc, int(output_size[0]), int(output_size[1]), m)
+    if rc:
+        raise CapfError(f"capf_affine_from_center_scale failed ({rc})")
+    return np.array(list(m), dtype=np.float64).reshape(2, 3)
+
+
+def warp_affine(frames, mats, output_size):
+    """frames: list of uint8 CUDA tensors [H_i, W_i, 3] (BGR as cv2.imread gives them); mats: [B, 2, 3] float64
+    forward matrices (numpy or tensor); output_size = (out_w, out_h) -> uint8 CUDA tensor [B, out_h, out_w, 3]."""
+    import numpy as np
+    import torch
+    lib = load_library()
+    lib.capf_warp_affine.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    dev = frames[0].device
+    B = len(frames)
+    for f in frames:
+        if f.dtype != torch.uint8 or f.dim() != 3 or f.shape[2] != 3 or f.stride(2) != 1 or f.stride(1) != 3 or not f.is_cuda:
+            raise ValueError("frames must be uint8 CUDA tensors [H, W, 3] with packed pixels")
+    ptrs = torch.tensor([f.data_ptr() for f in frames], dtype=torch.int64).to(dev)
+    dims = torch.tensor([[f.shape[0], f.shape[1], f.stride(0)] for f in frames], dtype=torch.int32).to(dev)
+    m = torch.as_tensor(np.asarray(mats, dtype=np.float64).reshape(B, 6)).to(dev)
+    out_w, out_h = int(output_size[0]), int(output_size[1])
+    out = torch.empty(B, out_h, out_w, 3, dtype=torch.uint8, device=dev)
+    rc = lib.capf_warp_affine(_stream(out), _p(ptrs), _p(dims), _p(m), B, out_h, out_w, _p(out))
+    if rc:
+        raise CapfError(f"capf_warp_affine failed ({rc})")
     return out

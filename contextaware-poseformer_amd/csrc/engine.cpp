@@ -586,6 +586,18 @@ int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out) 
     return capf::launch_fliptest_fuse(pred2, batch, out, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_affine_from_center_scale(const double center[2], const double scale[2], int out_w, int out_h, double m[6]) {
+    if (!center || !scale || !m || out_w <= 1 || out_h <= 1) return CAPF_ERR_INVALID;
+    return capf::affine_from_center_scale(center, scale, out_w, out_h, m) ? CAPF_OK : CAPF_ERR_INVALID;
+}
+
+int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* dims, const double* m, int batch, int out_h,
+                     int out_w, uint8_t* out) {
+    if (!frames || !dims || !m || !out || batch <= 0 || out_h <= 0 || out_w <= 0) return CAPF_ERR_INVALID;
+    return capf::launch_warp_affine_u8(frames, dims, m, out, batch, out_h, out_w, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_num_ops(const capf_handle* h) { return h ? (int)h->e.ops.size() : CAPF_ERR_INVALID; }
 
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel, double* flops) {

@@ -283,7 +283,7 @@ struct GroupArgsB {
     int cfg[MAXG];         // 0: 128x64 (S=2), 1: 64x64 (S=3), 2: 128x32 (S=2)
     int n;
 };
-static constexpr int GROUP_LDS_HALVES = 2 * (128 + 64) * BKH;      // 48 KiB
+#define GROUP_LDS_HALVES (2 * (128 + 64) * BKH)   // 48 KiB
 
 __global__ __launch_bounds__(256) void igemm_bf16_group_kernel(GroupArgsB ga) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -150,5 +150,9 @@ hipError_t launch_preprocess(const unsigned char* images_bgr, int B, int H, int 
                              int mode, float* images_out, const float* gt_in, float* gt_out, const float* k2d_in,
                              float* k2d_out, const float* kc_in, float* kc_out, hipStream_t s);
 hipError_t launch_fliptest_fuse(const float* pred2, int B, float* out, hipStream_t s);
+// N3 (preprocess.hip): get_affine_transform (host) and cv2.warpAffine INTER_LINEAR for 8-bit BGR frames
+bool affine_from_center_scale(const double center[2], const double scale[2], int out_w, int out_h, double M[6]);
+hipError_t launch_warp_affine_u8(const unsigned char* const* frames, const int* dims, const double* M, unsigned char* out,
+                                 int B, int out_h, int out_w, hipStream_t s);
 
 }  // namespace capf

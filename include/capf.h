@@ -224,6 +224,20 @@ int capf_preprocess(void* stream, const uint8_t* images_bgr, int batch, int heig
                     const float* k2d_in, float* k2d_out, const float* kcrop_in, float* kcrop_out);
 int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out);
 
+/* ---- N3: the per-frame affine crop in front of the prefetcher ------------------------
+ * capf_affine_from_center_scale: get_affine_transform(center, scale, 0, (out_w, out_h)) of
+ *   mvn/utils/img.py:16-48 (rot 0, shift 0): the 2x3 row-major double matrix cv2.getAffineTransform returns
+ *   for the three float32 point pairs.  Host code, no GPU needed.
+ * capf_warp_affine: crop_image (img.py:51-69, called from Human36M.__getitem__ human36m.py:298-300) for a whole
+ *   batch: out[b] = cv2.warpAffine(frame_b, m_b, (out_w, out_h), flags=INTER_LINEAR), constant border 0, 8-bit
+ *   3-channel.  frames: DEVICE array of `batch` device pointers; dims: device int32 [batch][3] = rows, cols,
+ *   row pitch in bytes; m: device double [batch][6] FORWARD matrices; out: uint8 [batch, out_h, out_w, 3].
+ *   OpenCV's fixed-point arithmetic (10-bit coordinates, 5-bit fractions, 15-bit weights) is restated from its
+ *   published algorithm -- OpenCV is absent from the build container, so this row's parity is unpinned. */
+int capf_affine_from_center_scale(const double center[2], const double scale[2], int out_w, int out_h, double m[6]);
+int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* dims, const double* m, int batch,
+                     int out_h, int out_w, uint8_t* out);
+
 /* ---- measurement aids (bench.py roofline line; no reference counterpart) -------------------------
  * capf_op_info: op `index` in launch order: its plan name, the kernel (template instantiation) it
  *   launches at `batch`, and its algorithmic FLOPs at `batch`.
