@@ -336,66 +336,85 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     // register group g = r >> 2, FOUR CONSECUTIVE channels n = 8g + 4*(lane>>5) + (r & 3).  NHWC output
     // therefore goes out as 16-byte stores (4 per 32x32 tile instead of 16 dword stores: the store tail of
     // a short-K tile is issue-bound), bias and residual come in as 16-byte loads, and a row's address is
-    // computed once per lane.  Residuals are loaded for the whole tile before anything is stored (an
-    // in-place residual aliases `out`).
+    // computed once per lane.
     if (ABL == 5 && p.M > 0) return;     // (ablation) no epilogue; the condition is opaque to the compiler, the MFMAs stay
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     const bool vec_ok = (p.N & 3) == 0;
+    // Pass 1: EVERY bias / residual load of the tile is issued before the first store.  vmcnt retires in
+    // order, so a load issued after a store would make its consumer wait for that store's completion too
+    // (~1.5 us per 32x32 sub-tile when loads and stores alternate); it is also what an in-place residual
+    // (res aliases out) needs.
+    long o_row[TM], r_row[TM];
+    bool m_ok[TM];
+    float rs[TM];                     // per-row scale of the branch output (DropPath keep mask / keep_prob)
+    f32x4 bv[TN][4], rv[TM][TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+            bv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (vec_ok) {
+                    if (full || n < p.N) bv[j][g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) bv[j][g][e] = p.bias[n + e];
+                }
+            }
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + (lane & 31);
-        const bool m_ok = full || m < p.M;
-        long o_row = 0, r_row = 0;
-        float rs = 1.0f;            // per-row scale of the branch output (DropPath keep mask / keep_prob)
-        if (m_ok) {
-            if (p.rscale) rs = p.rscale[m / p.rs_div];
-            o_row = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (long)ky * p.split_stride;
-            if (p.res) r_row = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : rowmap(p.rmap, m);
+        m_ok[i] = full || m < p.M;
+        o_row[i] = 0; r_row[i] = 0; rs[i] = 1.0f;
+        if (m_ok[i]) {
+            if (p.rscale) rs[i] = p.rscale[m / p.rs_div];
+            o_row[i] = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (long)ky * p.split_stride;
+            if (p.res) r_row[i] = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : rowmap(p.rmap, m);
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wn0 + j * 32 + 4 * (lane >> 5);
-            f32x4 rv[4], bv[4];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
-                const bool ok = m_ok && (full || n < p.N);
-                rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (vec_ok) {
-                    if (ok && p.bias) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (ok && p.res) rv[g] = *reinterpret_cast<const f32x4*>(p.res + r_row + n);
-                } else {
+                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                rv[i][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.res && m_ok[i]) {
+                    if (vec_ok) {
+                        if (full || n < p.N) rv[i][j][g] = *reinterpret_cast<const f32x4*>(p.res + r_row[i] + n);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (m_ok && n + e < p.N) {
-                            if (p.bias) bv[g][e] = p.bias[n + e];
-                            if (p.res) rv[g][e] = p.res[r_row + n + e];
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) rv[i][j][g][e] = p.res[r_row[i] + n + e];
                     }
                 }
             }
+    }
+    // Pass 2: combine and store.
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
+                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = (acc[i][j][4 * g + e] + bv[g][e]) * rs + rv[g][e];
+                    float t = (acc[i][j][4 * g + e] + bv[j][g][e]) * rs[i] + rv[i][j][g][e];
                     if (GELU) { if (p.act == ACT_GELU) t = gelu_erf(t); }
                     if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
                     v[e] = t;
                 }
                 if (vec_ok) {
-                    if (m_ok && (full || n < p.N)) *reinterpret_cast<f32x4*>(p.out + o_row + n) = v;
+                    if (m_ok[i] && (full || n < p.N)) *reinterpret_cast<f32x4*>(p.out + o_row[i] + n) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (m_ok && n + e < p.N) p.out[o_row + n + e] = v[e];
+                        if (m_ok[i] && n + e < p.N) p.out[o_row[i] + n + e] = v[e];
                 }
             }
-        }
-    }
     if (ABL == 7 && tid == 0 && dbg_block < DBG_BLOCKS && ky == 0) {
         const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();   // stores still in flight
         unsigned long long* d = capf_dbg_timeline + (size_t)dbg_block * 8;
