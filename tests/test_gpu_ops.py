@@ -26,6 +26,7 @@ CONV_CASES = [
     (512, 512, 3, 2, 12, 10, 1, 1, False, False),
     (256, 17, 3, 1, 9, 7, 1, 0, False, False),     # ragged N = 17
     (32, 32, 3, 1, 5, 3, 7, 1, True, False),       # tiny ragged image, M = 105
+    (64, 256, 1, 1, 64, 64, 50, 1, True, True),    # layer1 conv3 + residual at full size (128x128 tiles, M = 204800)
 ]
 
 
