@@ -124,7 +124,8 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* xhat, const float*
                                 RowMap omap, float* second, RowMap smap, int rows, int GRP, int C, hipStream_t s);
 // dst[c*dst_stride] (+)= sum_r A[amap(r)+c] * B(r,c); bmode 0 none, 1 B[bmap(r)+c], 2 B[bmap(r)]; scratch >= 64*C floats
 hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
-                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s);
+                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s,
+                            float* dst2 = nullptr, size_t scratch_elems = 0);   // dst2: plain column sums of A as well
 hipError_t launch_slab_sum(const float* slabs, int nslab, long n, float* dst, hipStream_t s);
 hipError_t launch_gelu_fwd(const float* x, float* y, long n, hipStream_t s);
 hipError_t launch_gelu_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t s);

@@ -101,7 +101,8 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
                          int K, const float* Xin, RowMap xmap, const float* W, float* dX, RowMap dxmap, bool acc_dx,
                          float* gW, float* gb) {
     float* red = tw + L.red;
-    if (gb) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s));
+    const size_t red_elems = (size_t)64 * 3 * cfg.embed_dim_ratio * (cfg.levels + 1);
+    if (gb) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
     if (gW) {
         const int Mp = r32(rows);
         float* tA = tw + L.tA;
@@ -262,6 +263,7 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
     float* gA = tw + L.gA;
     float* gB = tw + L.gB;
     float* red = tw + L.red;
+    const size_t red_elems = (size_t)64 * 3 * cfg.embed_dim_ratio * (cfg.levels + 1);
     auto G = [&](const std::string& n) { return flat + grad_off[param_index.at(n)]; };
     const float* m_ctx = masks;
     const float* m_res = masks ? masks + (size_t)2 * Lv * B : nullptr;
@@ -276,8 +278,8 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
         for (int o = 0; o < 3; ++o)
             HIP_TRY(launch_colreduce(tw + L.yh, row_ld(D), dOut + o, row_ld(3), 2, R, D, G(V + ".head.1.weight") + (size_t)o * D, 1, 0, red, s));
         HIP_TRY(launch_head_dgrad(dOut, P(*this, V + ".head.1.weight"), gA, R, D, 3, s));
-        HIP_TRY(launch_colreduce(gA, row_ld(D), tw + L.xhh, row_ld(D), 1, R, D, G(V + ".head.0.weight"), 1, 0, red, s));
-        HIP_TRY(launch_colreduce(gA, row_ld(D), nullptr, row_ld(0), 0, R, D, G(V + ".head.0.bias"), 1, 0, red, s));
+        HIP_TRY(launch_colreduce(gA, row_ld(D), tw + L.xhh, row_ld(D), 1, R, D, G(V + ".head.0.weight"), 1, 0, red, s,
+                                 G(V + ".head.0.bias"), red_elems));      // d(gamma) and d(beta) in one pass
         HIP_TRY(launch_layernorm_bwd(gA, tw + L.xhh, tw + L.rsh, P(*this, V + ".head.0.weight"), dX, row_ld(D), nullptr, row_ld(0), R, 1, D, s));
     }
 
@@ -299,8 +301,8 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
         rc = t_linear_bwd(s, L, tw, gA, row_ld(2 * dim), R, 2 * dim, dim, tw + y2, row_ld(dim), P(*this, p + ".mlp.fc1.weight"), gB,
                           row_ld(dim), false, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"));
         if (rc) return rc;
-        HIP_TRY(launch_colreduce(gB, row_ld(dim), tw + xh2, row_ld(dim), 1, R, dim, G(p + ".norm2.weight"), 1, 0, red, s));
-        HIP_TRY(launch_colreduce(gB, row_ld(dim), nullptr, row_ld(0), 0, R, dim, G(p + ".norm2.bias"), 1, 0, red, s));
+        HIP_TRY(launch_colreduce(gB, row_ld(dim), tw + xh2, row_ld(dim), 1, R, dim, G(p + ".norm2.weight"), 1, 0, red, s,
+                                 G(p + ".norm2.bias"), red_elems));      // d(gamma) and d(beta) in one pass
         HIP_TRY(launch_layernorm_bwd(gB, tw + xh2, tw + rs2, P(*this, p + ".norm2.weight"), dX, xm, nullptr, row_ld(0), R, 1, dim, s));
         return CAPF_OK;
     };
@@ -330,8 +332,8 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
             rc = t_linear_bwd(s, L, tw, gB, row_ld(3 * dim), R, 3 * dim, dim, tw + a.y1, row_ld(dim), P(*this, p + ".attn.qkv.weight"),
                               gA, row_ld(dim), false, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"));
             if (rc) return rc;
-            HIP_TRY(launch_colreduce(gA, row_ld(dim), tw + a.xh1, row_ld(dim), 1, R, dim, G(p + ".norm1.weight"), 1, 0, red, s));
-            HIP_TRY(launch_colreduce(gA, row_ld(dim), nullptr, row_ld(0), 0, R, dim, G(p + ".norm1.bias"), 1, 0, red, s));
+            HIP_TRY(launch_colreduce(gA, row_ld(dim), tw + a.xh1, row_ld(dim), 1, R, dim, G(p + ".norm1.weight"), 1, 0, red, s,
+                                 G(p + ".norm1.bias"), red_elems));      // d(gamma) and d(beta) in one pass
             HIP_TRY(launch_layernorm_bwd(gA, tw + a.xh1, tw + a.rs1, P(*this, p + ".norm1.weight"), dX, row_ld(dim), nullptr, row_ld(0), R, 1, dim, s));
         }
     }
@@ -380,8 +382,8 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
         HIP_TRY(hipMemcpyAsync(G(p + ".sampling_offsets.weight"), gWcat + (size_t)NA * C, sizeof(float) * NO * C, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(G(p + ".attention_weights.bias"), gbcat, sizeof(float) * NA, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(G(p + ".sampling_offsets.bias"), gbcat + NA, sizeof(float) * NO, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(launch_colreduce(dq, row_ld(C), tw + c.xh1, row_ld(C), 1, R, C, G(p + ".norm1.weight"), 1, 0, red, s));
-        HIP_TRY(launch_colreduce(dq, row_ld(C), nullptr, row_ld(0), 0, R, C, G(p + ".norm1.bias"), 1, 0, red, s));
+        HIP_TRY(launch_colreduce(dq, row_ld(C), tw + c.xh1, row_ld(C), 1, R, C, G(p + ".norm1.weight"), 1, 0, red, s,
+                                 G(p + ".norm1.bias"), red_elems));      // d(gamma) and d(beta) in one pass
         HIP_TRY(launch_layernorm_bwd(dq, tw + c.xh1, tw + c.rs1, P(*this, p + ".norm1.weight"), dX, tok, dX, tok0, R, Lv, C, s));
     }
 

@@ -5,6 +5,7 @@
 // and of the deformable sampler (gradient w.r.t. sampling positions and attention logits only — the
 // feature maps come from the frozen backbone, conpose.py:22-25), MPJPE loss + gradient (loss.py:16-22)
 // and a fused AdamW update (train.py:345).  No atomics: every reduction has a fixed order.
+#include <algorithm>
 #include "kernels.h"
 
 namespace capf {
@@ -155,48 +156,77 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* xhat, const float*
 // B absent -> 1; bmode 1: B[bmap(r) + c]; bmode 2: B[bmap(r)] (one scalar per row).
 // Stage 1: grid (C/64, chunks), 256 threads = 4 row lanes x 64 columns, fixed row order per lane and a
 // fixed 4-way LDS reduce; stage 2 sums the chunk partials in order.  No atomics.
+// `partial2` (optional): the plain column sums of A as a second result of the same pass (LayerNorm: d(gamma) =
+// sum dY * xhat and d(beta) = sum dY read dY once).
 __global__ void colreduce_kernel(const float* __restrict__ A, RowMap amap, const float* __restrict__ Bm, RowMap bmap,
-                                 int bmode, float* __restrict__ partial, int rows, int C, int rows_per_chunk) {
-    __shared__ float red[4][64];
+                                 int bmode, float* __restrict__ partial, float* __restrict__ partial2, int rows, int C,
+                                 int rows_per_chunk) {
+    __shared__ float red[2][4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
-    float acc = 0.f;
+    float acc = 0.f, acc2 = 0.f;
     if (col < C) {
         for (int r = r0 + rl; r < r1; r += 4) {
-            float v = A[rowmap_t(amap, r) + col];
+            const float a = A[rowmap_t(amap, r) + col];
+            float v = a;
             if (bmode == 1) v *= Bm[rowmap_t(bmap, r) + col];
             else if (bmode == 2) v *= Bm[rowmap_t(bmap, r)];
             acc += v;
+            acc2 += a;
         }
     }
-    red[rl][threadIdx.x & 63] = acc;
+    red[0][rl][threadIdx.x & 63] = acc;
+    red[1][rl][threadIdx.x & 63] = acc2;
     __syncthreads();
-    if (rl == 0 && col < C)
-        partial[(long)blockIdx.y * C + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rl == 0 && col < C) {
+        partial[(long)blockIdx.y * C + col] = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+        if (partial2)
+            partial2[(long)blockIdx.y * C + col] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    }
 }
 
-__global__ void colreduce_final_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dst,
-                                       long dst_stride, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(long)k * C + c];
-    float* d = dst + (long)c * dst_stride;
-    *d = accumulate ? *d + s : s;
+// stage 2: 64 columns x 4 chunk lanes per block; each lane sums every 4th chunk partial in order, then a fixed
+// 4-way LDS reduce
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int chunks, int C,
+                                                              float* __restrict__ dst, long dst_stride, int accumulate,
+                                                              const float* __restrict__ partial2, float* __restrict__ dst2) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+    float s = 0.f, s2 = 0.f;
+    if (c < C) {
+        for (int k = kl; k < chunks; k += 4) s += partial[(long)k * C + c];
+        if (dst2)
+            for (int k = kl; k < chunks; k += 4) s2 += partial2[(long)k * C + c];
+    }
+    red[0][kl][threadIdx.x & 63] = s;
+    red[1][kl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        const float t = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+        float* d = dst + (long)c * dst_stride;
+        *d = accumulate ? *d + t : t;
+        if (dst2) dst2[c] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    }
 }
 
+// scratch must hold (dst2 ? 2 : 1) * chunks * C floats; chunks is chosen so that the first stage has ~1024 blocks
 hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
-                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s) {
-    int chunks = (rows + 511) / 512;
-    if (chunks > 64) chunks = 64;
-    if (chunks < 1) chunks = 1;
+                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s, float* dst2,
+                            size_t scratch_elems) {
+    const int colblocks = (C + 63) / 64, nout = dst2 ? 2 : 1;
+    int chunks = (1024 + colblocks - 1) / colblocks;
+    chunks = std::min(std::min(chunks, 128), std::max(1, rows / 32));
+    if (scratch_elems) chunks = std::min<long>(chunks, std::max<long>(1, (long)(scratch_elems / ((size_t)C * nout))));
+    else chunks = std::min(chunks, 64);
     const int rpc = (rows + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, A, amap, Bm, bmap, bmode, scratch,
-                       rows, C, rpc);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, chunks, C, dst, dst_stride,
-                       accumulate);
+    chunks = (rows + rpc - 1) / rpc;
+    float* p2 = dst2 ? scratch + (size_t)chunks * C : nullptr;
+    hipLaunchKernelGGL(colreduce_kernel, dim3(colblocks, chunks), dim3(256), 0, s, A, amap, Bm, bmap, bmode, scratch, p2, rows, C,
+                       rpc);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3(colblocks), dim3(256), 0, s, scratch, chunks, C, dst, dst_stride,
+                       accumulate, p2, dst2);
     return hipGetLastError();
 }
 
