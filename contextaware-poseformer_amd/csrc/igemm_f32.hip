@@ -625,20 +625,34 @@ FastDiv make_fastdiv(unsigned d) {
 enum TileCfg { W4_128x64 = 0, W4_64x64, W4_128x128, W4_256x32, X_128x64_S3, X_128x32_S3, X_256x32_S3, X_64x64_S2, X_128x128_S3, N_TILES };
 static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32", "x,128x64,s3", "x,128x32,s3", "x,256x32,s3", "x,64x64,s2", "x,128x128,s3"};
 
-// N decides the column tile, M how tall it can be while the grid still fills 256 CUs several times over.
-// CAPF_TILE=<index> forces a tile (micro-benchmark tuning only).
+// Tile choice by a small cost model fitted to the per-block timelines (tools/timeline.py), in units of one
+// 64x64x32 tile-chunk (1024 MFMA cycles of a CU): a CU gets tpc = ceil(tiles / 256) tiles, up to `occ` of them
+// co-resident; its K loops run at 78 / 83 / 88 % of the MFMA rate with 1 / 2 / 3 co-resident blocks, and every
+// round of co-resident blocks pays ~14 units of exposed first-load wait + store drain.  What this captures
+// that "biggest tile that still gives >= 256 blocks" does not: 270 tiles of 128x64 take TWO rounds on 256 CUs
+// (the lifter's M = 17 * 64 GEMMs), 510 tiles of 64x64 take one.  CAPF_TILE=<index> forces a tile (tuning only).
 static TileCfg pick_tile(const GemmArgs& a) {
     static const int forced = [] { const char* e = getenv("CAPF_TILE"); return e ? atoi(e) : -1; }();
     if (forced >= 0 && forced < N_TILES) return (TileCfg)forced;
-    // measured on MI355X (tools/bench_conv.py, batch 64): N <= 32 -> 256x32 (69 TF on 32->32@64^2 vs 45-55 for
-    // the others); N <= 64 -> 128x64 for big M (95 TF on 64->64@64^2), 64x64 otherwise; single-wave
-    // blocks (private LDS ring, no barrier) lost 15-25 % to their extra L2->LDS traffic and were dropped.
-    if (a.N <= 32) return ((long)a.M >= 256L * 512) ? W4_256x32 : W4_64x64;
-    if (a.N <= 64) return ((long)a.M >= 128L * 512) ? W4_128x64 : W4_64x64;
-    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tiles128 >= 512) return W4_128x128;
-    if ((long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 256) return W4_128x64;
-    return W4_64x64;
+    struct Cand { TileCfg cfg; int bm, bn, unit, occ; };
+    static const Cand cands[4] = {{W4_256x32, 256, 32, 2, 2}, {W4_128x128, 128, 128, 4, 2}, {W4_128x64, 128, 64, 2, 3},
+                                  {W4_64x64, 64, 64, 1, 3}};
+    const int chunks = a.splits > 1 ? a.cps : a.Kpad / BK;
+    const int ksplit = a.splits > 1 ? a.splits : 1;
+    double best = 0.0;
+    TileCfg pick = W4_64x64;
+    for (const Cand& c : cands) {
+        if (c.cfg == W4_256x32 && a.N > 32) continue;          // tall tile: only for one narrow column tile
+        if (c.cfg == W4_128x128 && a.N <= 64) continue;
+        if (c.cfg == W4_128x64 && a.N <= 32) continue;         // would multiply zero columns half of the time
+        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn) * ksplit;
+        const long tpc = (tiles + 255) / 256;
+        const long res = tpc < c.occ ? tpc : c.occ;
+        const double eff = res >= 3 ? 0.88 : (res == 2 ? 0.83 : 0.78);
+        const double cost = (double)tpc * c.unit * chunks / eff + 14.0 * (double)((tpc + c.occ - 1) / c.occ);
+        if (best == 0.0 || cost < best) { best = cost; pick = c.cfg; }
+    }
+    return pick;
 }
 
 const char* gemm_f32_kernel_name(const GemmArgs& a) {
