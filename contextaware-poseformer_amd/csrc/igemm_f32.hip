@@ -288,21 +288,38 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
             // range or point at data nobody reads: branch-free, harmless
             if (step == 2) prepare(c + S);
             constexpr bool NO_DMA = ABL == 1 || ABL == 6, NO_LDS = ABL == 3 || ABL == 6, NO_SYNC = ABL == 4 || ABL == 6;
-            if (step < 3) {
-                if (!NO_LDS) read_frags(st_read, step + 1, (step + 1) & 1);
-            } else if (NO_SYNC) {
-                if (!NO_LDS) read_frags(st_next, 0, 0);
-            } else {
+            if (step == 3 && !NO_SYNC) {
                 // chunk boundary: chunk c+1 has landed (all but the S-2 youngest chunks), every wave's
                 // fragment reads of chunk c have returned (lgkmcnt) -> after the barrier stage st_read may
                 // be overwritten by the loads fired in iteration c+1
                 wait_vmcnt<(S - 2) * NLOAD>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (!NO_LDS) read_frags(st_next, 0, 0);
             }
+            // The memory instructions of this step -- the TM + TN fragment reads of the NEXT k-step (double
+            // buffered registers) and, in steps 0-1, this step's share of the chunk's DMA loads -- are spread
+            // EVENLY between the step's MFMAs, one per 64-cycle MFMA slot, and pinned there with scheduling
+            // barriers: left alone the compiler batches them (3 ds_read + 3 buffer_load in a row), and with one
+            // wave per SIMD the matrix pipe then idles behind their issue cycles.
+            const int rd_stage = step < 3 ? st_read : st_next;
+            const int rd_step = step < 3 ? step + 1 : 0, rd_buf = (step + 1) & 1;
+            const float* rAs = lds + rd_stage * STAGE;
+            const float* rBs = rAs + BM * BK;
+            const int rq = ((rd_step * 2) + fhalf) ^ fsw;
+            constexpr int NM = 4 * TM * TN;                                   // MFMAs of a step
+            const int n_mem = (TM + TN) + (step < 2 ? PER_STEP : 0);
+            auto mem_op = [&](int k) {
+                if (k < TM) {
+                    if (!NO_LDS) af[rd_buf][k] = *reinterpret_cast<const f32x4*>(&rAs[(wm0 + k * 32 + frow) * BK + rq * 4]);
+                } else if (k < TM + TN) {
+                    if (!NO_LDS) bf[rd_buf][k - TM] = *reinterpret_cast<const f32x4*>(&rBs[(wn0 + (k - TM) * 32 + frow) * BK + rq * 4]);
+                } else {
+                    const int idx = step * PER_STEP + (k - TM - TN);
+                    if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
+                }
+            };
             const int fb = step & 1;
-            int fired = 0;
+            int issued = 0, slot = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -311,19 +328,16 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                     for (int j = 0; j < TN; ++j) {
                         if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fb][j][e], af[fb][i][e], acc[i][j], 0, 0, 0);
                         else { acc[i][j][e] += af[fb][i][e] * bf[fb][j][e]; }   // (ablation only)
-                        if (step < 2 && fired < PER_STEP) {
-                            const int idx = step * PER_STEP + fired;
-                            if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
-                            ++fired;
-                        }
-                    }
-            if (step < 2) {   // tiles with fewer MFMAs per step than loads: fire the rest here
+                        ++slot;
+                        // after MFMA #slot: keep issued / n_mem in step with slot / NM
 #pragma unroll
-                for (int f = TM * TN * 4; f < PER_STEP; ++f) {
-                    const int idx = step * PER_STEP + f;
-                    if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
-                }
-            }
+                        for (int k = 0; k < TM + TN + PER_STEP; ++k)
+                            if (k == issued && k < n_mem && issued * NM < slot * n_mem) { mem_op(k); ++issued; }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+            for (int k = 0; k < TM + TN + PER_STEP; ++k)      // (never more memory ops than slots x their share; safety)
+                if (k >= issued && k < n_mem) mem_op(k);
         }
         st_read = st_next;
         st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
