@@ -329,10 +329,11 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                         if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fb][j][e], af[fb][i][e], acc[i][j], 0, 0, 0);
                         else { acc[i][j][e] += af[fb][i][e] * bf[fb][j][e]; }   // (ablation only)
                         ++slot;
-                        // after MFMA #slot: keep issued / n_mem in step with slot / NM
+                        // after MFMA #slot: the next memory op -- fragment reads first (they are needed at the next
+                        // k-step), then the DMA loads; the last slot takes whatever is left
 #pragma unroll
                         for (int k = 0; k < TM + TN + PER_STEP; ++k)
-                            if (k == issued && k < n_mem && issued * NM < slot * n_mem) { mem_op(k); ++issued; }
+                            if (k == issued && k < n_mem && (issued < slot || slot == NM)) { mem_op(k); ++issued; }
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
