@@ -288,14 +288,6 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
             // range or point at data nobody reads: branch-free, harmless
             if (step == 2) prepare(c + S);
             constexpr bool NO_DMA = ABL == 1 || ABL == 6, NO_LDS = ABL == 3 || ABL == 6, NO_SYNC = ABL == 4 || ABL == 6;
-            if (step == 3 && !NO_SYNC) {
-                // chunk boundary: chunk c+1 has landed (all but the S-2 youngest chunks), every wave's
-                // fragment reads of chunk c have returned (lgkmcnt) -> after the barrier stage st_read may
-                // be overwritten by the loads fired in iteration c+1
-                wait_vmcnt<(S - 2) * NLOAD>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
             // The memory instructions of this step -- the TM + TN fragment reads of the NEXT k-step (double
             // buffered registers) and, in steps 0-1, this step's share of the chunk's DMA loads -- are spread
             // EVENLY between the step's MFMAs, one per 64-cycle MFMA slot, and pinned there with scheduling
@@ -318,6 +310,11 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                     if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
                 }
             };
+            // Chunk boundary (k-step 3): chunk c+1 has landed (all but the S-2 youngest chunks) and every wave's
+            // fragment reads of chunk c have returned (lgkmcnt) -> after the barrier, stage st_read may be
+            // overwritten by the loads fired in iteration c+1.  It sits after the first half of the step's MFMAs
+            // (more time for the DMA to land); the next chunk's first fragments are read in the slots after it.
+            constexpr int BSLOT = NM / 2;
             const int fb = step & 1;
             int issued = 0, slot = 0;
 #pragma unroll
@@ -329,11 +326,16 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                         if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[fb][j][e], af[fb][i][e], acc[i][j], 0, 0, 0);
                         else { acc[i][j][e] += af[fb][i][e] * bf[fb][j][e]; }   // (ablation only)
                         ++slot;
+                        if (step == 3 && slot == BSLOT && !NO_SYNC) {
+                            wait_vmcnt<(S - 2) * NLOAD>();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
                         // after MFMA #slot: the next memory op -- fragment reads first (they are needed at the next
                         // k-step), then the DMA loads; the last slot takes whatever is left
 #pragma unroll
                         for (int k = 0; k < TM + TN + PER_STEP; ++k)
-                            if (k == issued && k < n_mem && (issued < slot || slot == NM)) { mem_op(k); ++issued; }
+                            if (k == issued && k < n_mem && ((issued < slot && (step < 3 || slot >= BSLOT)) || slot == NM)) { mem_op(k); ++issued; }
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
