@@ -333,9 +333,14 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                         }
                         // after MFMA #slot: the next memory op -- fragment reads first (they are needed at the next
                         // k-step), then the DMA loads; the last slot takes whatever is left
+                        bool took = false;                     // one per slot (the last slot takes the rest)
 #pragma unroll
                         for (int k = 0; k < TM + TN + PER_STEP; ++k)
-                            if (k == issued && k < n_mem && ((issued < slot && (step < 3 || slot >= BSLOT)) || slot == NM)) { mem_op(k); ++issued; }
+                            if (k == issued && k < n_mem && ((!took && (step < 3 || slot >= BSLOT)) || slot == NM)) {
+                                mem_op(k);
+                                ++issued;
+                                took = true;
+                            }
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
