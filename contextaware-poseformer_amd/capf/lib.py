@@ -4,7 +4,8 @@ import ctypes
 import os
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
+# CAPF_LIB: an alternative build of the same ABI (A/B timing of kernel variants on one GPU box; tools only)
+LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
 
