@@ -189,27 +189,42 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
     }
     int st_read = 0, st_fill = S - 1;
     prepare(S - 1);
-    for (int c = 0; c < nchunks; ++c) {
-        wait_vmcnt_b<(S - 2) * NLOAD>();
-        __builtin_amdgcn_s_barrier();
-        const unsigned short* As = lds + st_read * STAGE;
+    // fragments are double buffered: the reads of k-step s+1 (or, at the chunk boundary, of the next chunk's
+    // step 0) are issued before the MFMAs of step s
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto read_frags = [&](int stage, int step, int buf) {
+        const unsigned short* As = lds + stage * STAGE;
         const unsigned short* Bs = As + BM * BKH;
+        const int q = ((step * 2) + fhalf) ^ fsw;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[buf][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BKH + q * 8]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bfr[buf][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BKH + q * 8]));
+    };
+    wait_vmcnt_b<(S - 2) * NLOAD>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int st_next = (st_read + 1 == S) ? 0 : st_read + 1;
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             if (step == 2) prepare(c + S);
-            const int q = ((step * 2) + fhalf) ^ fsw;
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BKH + q * 8]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BKH + q * 8]));
+            if (step < 3) {
+                read_frags(st_read, step + 1, (step + 1) & 1);
+            } else {
+                wait_vmcnt_b<(S - 2) * NLOAD>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                read_frags(st_next, 0, 0);
+            }
+            const int fb = step & 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fb][j], af[fb][i], acc[i][j], 0, 0, 0);
             if (step < 2) {
 #pragma unroll
                 for (int f = 0; f < PER_STEP; ++f) {
@@ -218,47 +233,57 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                 }
             }
         }
-        st_read = (st_read + 1 == S) ? 0 : st_read + 1;
+        st_read = st_next;
         st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
     }
     wait_vmcnt_b<0>();
 
-    // ---- epilogue (transposed accumulator: lane = one row m, register group g = 4 consecutive channels)
+    // ---- epilogue (transposed accumulator: lane = one row m, register group g = 4 consecutive channels).
+    // Every bias / residual load of the tile is issued before the first store (vmcnt retires in order).
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    long o_row[TM];
+    bool m_ok[TM];
+    f32x4 bv[TN][4];
+    u16x4 rv[TM][TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+            bv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && (full || n < p.N)) bv[j][g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + (lane & 31);
-        const bool m_ok = full || m < p.M;
-        const long o_row = (long)m * p.omap.S1 + p.omap.off;
+        m_ok[i] = full || m < p.M;
+        o_row[i] = (long)m * p.omap.S1 + p.omap.off;
         const long r_row = (long)m * p.rmap.S1 + p.rmap.off;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wn0 + j * 32 + 4 * (lane >> 5);
-            u16x4 rv[4];
-            f32x4 bv[4];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
-                const bool ok = m_ok && (full || n < p.N);
-                rv[g] = u16x4{0, 0, 0, 0};
-                bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok && p.bias) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (ok && Rs) rv[g] = *reinterpret_cast<const u16x4*>(Rs + r_row + n);
+                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                rv[i][j][g] = u16x4{0, 0, 0, 0};
+                if (Rs && m_ok[i] && (full || n < p.N)) rv[i][j][g] = *reinterpret_cast<const u16x4*>(Rs + r_row + n);
             }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nb + 8 * g;
+                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
                 u16x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] + bv[g][e] + bf2f(rv[g][e]);
+                    float t = acc[i][j][4 * g + e] + bv[j][g][e] + bf2f(rv[i][j][g][e]);
                     if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
                     v[e] = f2bf(t);
                 }
-                if (m_ok && (full || n < p.N)) *reinterpret_cast<u16x4*>(Out + o_row + n) = v;
+                if (m_ok[i] && (full || n < p.N)) *reinterpret_cast<u16x4*>(Out + o_row[i] + n) = v;
             }
-        }
-    }
 }
 #endif
 
