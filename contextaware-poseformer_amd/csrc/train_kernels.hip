@@ -306,13 +306,13 @@ hipError_t launch_transpose_pad(const float* in, RowMap imap, int M, int C, floa
 }
 
 // ---- backward of the tiny attention (Attention.forward pose_dformer.py:46-59) -----------------------
-// One wave per (group, head): q, k, v and dO of the N <= 17 tokens are staged in LDS (coalesced reads of the
+// One block (256 threads for 17 tokens, one wave for 5) per (group, head): q, k, v and dO of the N <= 17 tokens are staged in LDS (coalesced reads of the
 // d contiguous floats of each token), the N x N probabilities are recomputed from the saved qkv exactly as
 // the forward computes them, and dq / dk / dv go out as d contiguous floats per token.
 //   S = scale q k^T, P = softmax(S), dP = dO v^T, dS = P o (dP - rowsum(P o dP)),
 //   dq = scale dS k, dk = scale dS^T q, dv = P^T dO
 template <int NMAX>
-__global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                            float* __restrict__ dqkv, int N, int heads, int d, float scale) {
     extern __shared__ float sm[];
     const int ld = d + 1;                      // padded token stride: rows of different tokens fall in different banks
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restri
     const float* qb = qkv + (g * N) * Cq + h * d;
     const float* dob = dO + (g * N) * Co + h * d;
     const int nd = N * d;
-    for (int idx = lane; idx < nd; idx += 64) {
+    for (int idx = lane; idx < nd; idx += blockDim.x) {
         const int t = idx / d, c = idx - t * d;
         const float* row = qb + (long)t * Cq + c;
         q[t * ld + c] = row[0];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restri
         go[t * ld + c] = dob[(long)t * Co + c];
     }
     __syncthreads();
-    for (int idx = lane; idx < N * N; idx += 64) {
+    for (int idx = lane; idx < N * N; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
         float s = 0.f, dp = 0.f;
         for (int c = 0; c < d; ++c) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(const float* __restri
     }
     __syncthreads();
     float* dq = dqkv + (g * N) * Cq + h * d;
-    for (int idx = lane; idx < nd; idx += 64) {
+    for (int idx = lane; idx < nd; idx += blockDim.x) {
         const int t = idx / d, c = idx - t * d;
         float sq = 0.f, sk = 0.f, sv = 0.f;
         for (int j = 0; j < N; ++j) {
@@ -383,7 +383,7 @@ hipError_t launch_attention_bwd(const float* qkv, const float* dO, float* dqkv, 
     const long pairs = (long)groups * heads;
     if (pairs <= 0) return hipSuccess;
     if (pairs > 0x7fffffffL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)pairs), block(64);
+    dim3 grid((unsigned)pairs), block(N <= 5 ? 64 : 256);
     if (N <= 5) {
         const size_t lds = (size_t)(4 * 5 * (d + 1) + 2 * 5 * 6) * sizeof(float);
         hipLaunchKernelGGL(attention_bwd_kernel<5>, grid, block, lds, s, qkv, dO, dqkv, N, heads, d, scale);
