@@ -137,3 +137,19 @@ def test_region_schedule_is_a_valid_topological_order(backbone):
                         assert not (set(sched[x][4]) & (set(sched[y][3]) | set(sched[y][4])))
                         assert not (set(sched[y][4]) & set(sched[x][3]))
     assert widest >= 4          # e.g. the four branches of a stage-4 module / the CPN refine cascades
+
+
+def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
+    """Static plan, no GPU: the cost model behind pick_tile (igemm_f32.hip) must not give the lifter's
+    M = 17 * 64 = 1088-row GEMMs 128-row tiles (9 x 30 = 270 tiles = two rounds on 256 CUs); the 32-channel
+    64x64 branch keeps its tall 256x32 tile when it is launched on its own."""
+    from capf import Engine
+    from mvn.models import _native
+    eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
+    table = {name: kern for name, kern, _ in eng.op_table(64)}
+    assert table["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
+    assert table["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
+    assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32<w4,256x32,conv>"
+    assert table["backbone.layer1.0.conv3"] == "igemm_f32<w4,128x128,conv>"
+    big = {name: kern for name, kern, _ in eng.op_table(512)}
+    assert big["joint0.qkv"] in ("igemm_f32<w4,128x128,rows>", "igemm_f32<w4,128x64,rows>")
