@@ -69,7 +69,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// NW waves per block (1 or 4), block tile BM x BN, wave tile WM x WN, S LDS stages.
+// NW waves per block (4), block tile BM x BN, wave tile WM x WN, S LDS stages.
 // PLAIN: out / res rows are addressed with a plain leading dimension (every conv, most linears);
 // otherwise the (G, S1, S2) row maps of the lifter's strided token views are evaluated per row.
 // ABL: ablation for diagnosis only (0 = product kernel; 1 = no DMA inside the K loop; 2 = no MFMA)
@@ -95,7 +95,7 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     if (ABL == 7) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int nbn = (p.N + BN - 1) / BN;
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
@@ -644,8 +644,8 @@ FastDiv make_fastdiv(unsigned d) {
     return f;
 }
 
-enum TileCfg { W4_128x64 = 0, W4_64x64, W4_128x128, W4_256x32, X_128x64_S3, X_128x32_S3, X_256x32_S3, X_64x64_S2, X_128x128_S3, N_TILES };
-static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32", "x,128x64,s3", "x,128x32,s3", "x,256x32,s3", "x,64x64,s2", "x,128x128,s3"};
+enum TileCfg { W4_128x64 = 0, W4_64x64, W4_128x128, W4_256x32, N_TILES };
+static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128", "w4,256x32"};
 
 // Tile choice by a small cost model fitted to the per-block timelines (tools/timeline.py), in units of one
 // 64x64x32 tile-chunk (1024 MFMA cycles of a CU): a CU gets tpc = ceil(tiles / 256) tiles, up to `occ` of them
@@ -819,11 +819,6 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
         case W4_64x64: return launch_cfg<4, 64, 64, 32, 32, 3>(a, s);
         case W4_128x128: return launch_cfg<4, 128, 128, 64, 64, 2>(a, s);
         case W4_256x32: return launch_cfg<4, 256, 32, 64, 32, 2>(a, s);
-        case X_128x64_S3: return launch_cfg<4, 128, 64, 64, 32, 3>(a, s);
-        case X_128x32_S3: return launch_cfg<4, 128, 32, 32, 32, 3>(a, s);
-        case X_256x32_S3: return launch_cfg<4, 256, 32, 64, 32, 3>(a, s);
-        case X_64x64_S2: return launch_cfg<4, 64, 64, 32, 32, 2>(a, s);
-        case X_128x128_S3: return launch_cfg<4, 128, 128, 64, 64, 3>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
