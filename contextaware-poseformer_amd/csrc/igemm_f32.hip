@@ -806,6 +806,11 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     // the epilogue's fast path addresses out / res with 32-bit element offsets from their bases
     if (a.omap.G == 1 && (double)a.M * (double)a.omap.S1 >= 4.0e9) return hipErrorInvalidValue;
     if (a.res && a.rmap.G == 1 && (double)a.M * (double)a.rmap.S1 >= 4.0e9) return hipErrorInvalidValue;
+    if (!a.conv) {   // rows mode addresses A with absolute 32-bit byte offsets from its base (buffer descriptor)
+        const double g = a.amap.G > 0 ? a.amap.G : 1;
+        const double span = ((double)a.M / g + 1.0) * (double)a.amap.S1 + g * (double)a.amap.S2 + (double)a.amap.off + a.Kpad;
+        if (span * 4.0 >= 4.0e9) return hipErrorInvalidValue;
+    }
     if (a.conv) {
         if (!prep_conv(a)) return hipErrorInvalidValue;
         if (a.Cin % 4 != 0) {
