@@ -153,3 +153,24 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     assert table["backbone.layer1.0.conv3"] == "igemm_f32<w4,128x128,conv>"
     big = {name: kern for name, kern, _ in eng.op_table(512)}
     assert big["joint0.qkv"] in ("igemm_f32<w4,128x128,rows>", "igemm_f32<w4,128x64,rows>")
+
+
+def test_conv_group_rejects_bad_arguments_without_a_gpu():
+    """capf_op_conv_group validates before it launches: the error paths need no device."""
+    import ctypes
+    import capf
+    from capf.lib import ConvDesc
+    lib = capf.load_library()
+    lib.capf_op_conv_group.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ConvDesc)]
+    lib.capf_op_conv_group.restype = ctypes.c_int
+    d = (ConvDesc * 9)()
+    for i in range(9):
+        d[i].x = d[i].w_packed = d[i].bias = d[i].y = 4096          # never dereferenced on these paths
+        d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].Cout, d[i].ks, d[i].stride, d[i].act = 1, 8, 8, 32, 32, 3, 1, 0
+    assert lib.capf_op_conv_group(None, 0, d) != 0                  # empty group
+    assert lib.capf_op_conv_group(None, 9, d) != 0                  # more than MAXG = 8 problems
+    assert lib.capf_op_conv_group(None, 2, None) != 0
+    d[1].Cin = 3                                                    # the small-Cin stem kernel cannot be grouped
+    assert lib.capf_op_conv_group(None, 2, d) != 0
+    d[1].Cin, d[1].ks = 32, 7                                       # 49 taps do not fit the 32-bit tap mask
+    assert lib.capf_op_conv_group(None, 2, d) != 0

@@ -215,3 +215,29 @@ def test_engine_modes_are_bit_identical(dtype, backbone):
             model.engine_for(img).set_lanes(mode)
             outs.append(model(img, k2d, kc.clone()).clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
+    """The engine's bf16 grouped launch (igemm_bf16_group_kernel) against single bf16 launches: run the
+    backbone of a bf16 model with capf_set_lanes 0 and 2 and compare the four context maps bit for bit."""
+    import copy, contextlib, io
+    from capf import synth
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = CA_PF(cfg, compute_dtype="bf16").eval()
+    synth.load_synthetic(model, seed=4, bn_mode="random")
+    model = model.cuda()
+    img, k2d, kc = synth.synth_inputs(2, 256, 192, seed=6)
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    maps = []
+    with torch.no_grad():
+        for mode in (0, 2):
+            eng = model.engine_for(img)
+            eng.set_lanes(mode)
+            model(img, k2d, kc.clone())
+            maps.append([eng.tensor(f"feat{l}").clone() for l in range(4)])
+    for a, b in zip(*maps):
+        assert torch.equal(a, b)
