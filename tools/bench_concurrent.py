@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=16)
     ap.add_argument("--branches", type=str, default="0,1,2,3")
+    ap.add_argument("--only-grouped", action="store_true", help="run only the grouped launch (PMC collection)")
     a = ap.parse_args()
     sel = [int(x) for x in a.branches.split(",")]
     probs = []
@@ -67,6 +68,10 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / a.iters
 
+    if a.only_grouped:
+        us = run("group")
+        print(f"branches {sel}: one grouped launch {us:8.1f} us per level")
+        return
     for _ in range(2):
         run(False), run(True), run("group"), run("two chains")
     flops = sum(2.0 * a.batch * r * r * c * c * 9 for c, r in (BRANCHES[b] for b in sel))
