@@ -72,7 +72,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NW waves per block (4), block tile BM x BN, wave tile WM x WN, S LDS stages.
 // PLAIN: out / res rows are addressed with a plain leading dimension (every conv, most linears);
 // otherwise the (G, S1, S2) row maps of the lifter's strided token views are evaluated per row.
-// ABL: ablation for diagnosis only (0 = product kernel; 1 = no DMA inside the K loop; 2 = no MFMA)
+// ABL: ablation for diagnosis only, instantiated by `make DIAG=1` (0 = product kernel; 1 = no DMA inside the K loop;
+// 2 = no MFMA; 3 = no LDS fragment reads; 4 = no vmcnt / barrier; 5 = no epilogue; 6 = 1+3+4; 7 = block timeline)
 //
 // igemm_tile computes ONE output tile (logical tile id `bid`, split-K slice `ky`) with the calling block;
 // `lds` is the block's ring (S stages).  It is the body of both the one-problem kernel and the grouped kernel.
@@ -697,6 +698,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     const bool plain = a.omap.G == 1 && (!a.res || a.rmap.G == 1);
     if (a.conv) {
         if (!plain) return hipErrorInvalidValue;
+#ifdef CAPF_DIAG      // ablation / timeline instantiations (make DIAG=1; tools/ablate.sh, tools/timeline.py)
         static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
         if (abl == 1)
             hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 1>), grid, block, 0, s, a);
@@ -713,6 +715,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
         else if (abl == 2)
             hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 2>), grid, block, 0, s, a);
         else
+#endif
         hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true>), grid, block, 0, s, a);
     } else if (a.act == ACT_GELU) {
         if (!plain) return hipErrorInvalidValue;
@@ -790,9 +793,12 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
+#ifdef CAPF_DIAG
     static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
     if (abl == 7) hipLaunchKernelGGL((igemm_f32_group_kernel<7>), dim3(start), dim3(256), 0, s, ga);
-    else hipLaunchKernelGGL((igemm_f32_group_kernel<0>), dim3(start), dim3(256), 0, s, ga);
+    else
+#endif
+    hipLaunchKernelGGL((igemm_f32_group_kernel<0>), dim3(start), dim3(256), 0, s, ga);
     return hipGetLastError();
 }
 
@@ -830,8 +836,10 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
 
 }  // namespace capf
 
-// (diagnosis only, not part of include/capf.h) copy the CAPF_ABLATE=7 block timeline to the host
+#ifdef CAPF_DIAG
+// (diagnosis build only, not part of include/capf.h) copy the CAPF_ABLATE=7 block timeline to the host
 extern "C" int capf_debug_timeline(unsigned long long* dst, int blocks) {
     if (blocks > capf::DBG_BLOCKS) blocks = capf::DBG_BLOCKS;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_dbg_timeline), (size_t)blocks * 64);
 }
+#endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-block timeline of one fp32 conv launch (diagnosis; needs CAPF_ABLATE=7, GPU box).
+"""Per-block timeline of one fp32 conv launch (diagnosis; needs a `make DIAG=1` build and CAPF_ABLATE=7, GPU box).
 Usage: CAPF_ABLATE=7 python tools/timeline.py --shape 5 [--batch 64]"""
 import argparse
 import ctypes
