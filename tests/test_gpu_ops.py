@@ -241,3 +241,73 @@ def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
             maps.append([eng.tensor(f"feat{l}").clone() for l in range(4)])
     for a, b in zip(*maps):
         assert torch.equal(a, b)
+
+
+def test_conv_fuzz_against_torch():
+    """Seeded random conv shapes (ragged M and N, odd image sizes, stride 1 / 2, 1x1 / 3x3 / 5x5, channel counts
+    that are and are not multiples of 32, with and without bias / residual / ReLU) against PyTorch on the CPU, and
+    the same problems again as grouped launches (bit-identical to the single launches)."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(20260928)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    probs, singles = [], []
+    for case in range(36):
+        ci = 4 * ri(1, 40)
+        co = 4 * ri(1, 40) if case % 5 else ri(1, 67)          # every fifth case: N not a multiple of 4
+        ks = (1, 3, 3, 5)[ri(0, 3)]
+        st = ri(1, 2)
+        H, W, B = ri(1, 23), ri(1, 19), ri(1, 6)
+        act, res = ri(0, 1), bool(ri(0, 1))
+        x = torch.randn(B, ci, H, W, generator=rng)
+        w = torch.randn(co, ci, ks, ks, generator=rng) / (ci * ks * ks) ** 0.5
+        bn = (torch.rand(co, generator=rng) + 0.5, torch.randn(co, generator=rng) * 0.1,
+              torch.randn(co, generator=rng) * 0.1, torch.rand(co, generator=rng) * 0.4 + 0.8)
+        want = F.batch_norm(F.conv2d(x, w, None, st, ks // 2), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+        r = torch.randn_like(want) if res else None
+        if res:
+            want = want + r
+        if act:
+            want = F.relu(want)
+        wp, bias = capf.pack_conv(w.cuda(), tuple(t.cuda() for t in bn))
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        rd = r.permute(0, 2, 3, 1).contiguous().cuda() if res else None
+        got = capf.conv_nhwc(xd, wp, bias, ks, st, act, rd)
+        err = (got.cpu().permute(0, 3, 1, 2) - want).abs().max().item()
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), (case, ci, co, ks, st, H, W, B, err)
+        if co % 4 == 0:
+            probs.append((xd, wp, bias, ks, st, act, rd))
+            singles.append(got)
+    for i in range(0, len(probs), 8):
+        outs = capf.conv_nhwc_group(probs[i:i + 8])
+        for a, b in zip(outs, singles[i:i + 8]):
+            assert torch.equal(a, b)
+
+
+def test_linear_fuzz_against_torch():
+    """Seeded random (M, N, K) with K % 32 == 0, ragged M / N, bias / residual / ReLU / GELU against PyTorch (CPU)."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(777)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    for case in range(24):
+        M, N, K = ri(1, 700), ri(1, 300), 32 * ri(1, 20)
+        act, res, has_b = ri(0, 2), bool(ri(0, 1)), bool(ri(0, 1))
+        x = torch.randn(M, K, generator=rng)
+        w = torch.randn(N, K, generator=rng) / K ** 0.5
+        b = torch.randn(N, generator=rng) if has_b else None
+        r = torch.randn(M, N, generator=rng) if res else None
+        want = F.linear(x, w, b)
+        if res:
+            want = want + r                      # epilogue order of the kernel: + bias, + residual, activation
+        if act == 2:
+            want = F.gelu(want)
+        if act == 1:
+            want = F.relu(want)
+        got = capf.linear(x.cuda(), w.cuda(), b.cuda() if has_b else None, act=act, residual=r.cuda() if res else None).cpu()
+        err = (got - want).abs().max().item()
+        assert err < 3e-5 * max(1.0, want.abs().max().item()), (case, M, N, K, act, res, has_b, err)
