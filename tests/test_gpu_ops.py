@@ -311,3 +311,48 @@ def test_linear_fuzz_against_torch():
         got = capf.linear(x.cuda(), w.cuda(), b.cuda() if has_b else None, act=act, residual=r.cuda() if res else None).cpu()
         err = (got - want).abs().max().item()
         assert err < 3e-5 * max(1.0, want.abs().max().item()), (case, M, N, K, act, res, has_b, err)
+
+
+def test_abi_error_codes_on_a_device_handle():
+    """Every failure is a negative status + capf_last_error text, never an exception across the ABI or a crash:
+    forward before the parameters were packed, batch outside 1..max_batch, workspace too small, unknown
+    parameter name, parameter shape mismatch."""
+    import copy, ctypes
+    from capf import CapfError, Engine
+    from mvn.models import _native
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    c = _native.make_capf_config(cfg, 128, 96)
+    c.max_batch = 4
+    eng = Engine(c, device=0)
+    lib, h = eng.lib, eng.h
+    img = torch.zeros(2, 128, 96, 3, device="cuda")
+    k2d = torch.zeros(2, 17, 2, device="cuda")
+    kc = torch.zeros(2, 17, 2, device="cuda")
+    out = torch.zeros(2, 1, 17, 3, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    fwd = lambda b: lib.capf_forward(h, None, P(img), P(k2d), P(kc), b, P(out))
+    assert fwd(2) < 0 and b"capf_params_changed" in lib.capf_last_error(h)         # nothing bound / packed yet
+    shp = (ctypes.c_int64 * 4)(3, 3, 3, 3)
+    assert lib.capf_set_param(h, b"backbone.no_such.weight", P(img), shp, 4) < 0
+    assert b"unknown parameter" in lib.capf_last_error(h)
+    assert lib.capf_set_param(h, b"backbone.conv1.weight", P(img), shp, 4) < 0      # [64, 3, 3, 3] expected
+    assert b"shape mismatch" in lib.capf_last_error(h)
+    # a fully bound model: batch range and workspace checks
+    import contextlib, io
+    from capf import synth
+    from mvn.models.conpose import CA_PF
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = CA_PF(cfg).eval()
+    synth.load_synthetic(model, seed=5, bn_mode="random")
+    model = model.cuda()
+    with torch.no_grad():
+        model(img, k2d, kc.clone())
+    e2 = model.engine_for(img)
+    f2 = lambda b: e2.lib.capf_forward(e2.h, None, P(img), P(k2d), P(kc), b, P(out))
+    assert f2(0) < 0 and f2(10 ** 6) < 0 and b"batch out of range" in e2.lib.capf_last_error(e2.h)
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    assert e2.lib.capf_set_workspace(e2.h, P(small), small.numel()) == 0
+    assert f2(2) < 0 and b"workspace" in e2.lib.capf_last_error(e2.h)
+    with pytest.raises(CapfError):
+        e2._check(f2(2), "forward")
