@@ -15,6 +15,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
+    "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss",
 ]
 
 
@@ -91,6 +92,9 @@ def load_library():
     lib.capf_fliptest_fuse.argtypes = [P, P, c_int, P]
     lib.capf_op_pack_conv_bf16.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 8
+    lib.capf_pose_errors.argtypes = [P, P, P, c_int, c_int, P, P]
+    lib.capf_segment_sums.argtypes = [P, P, P, P, c_int, c_int, P, P]
+    lib.capf_keypoints_loss.argtypes = [P, c_int, P, P, P, c_int, c_int, c_float, P, P]
     _lib = lib
     return lib
 
@@ -494,3 +498,46 @@ def warp_affine(frames, mats, output_size):
     if rc:
         raise CapfError(f"capf_warp_affine failed ({rc})")
     return out
+
+
+# ---- N2: evaluation metrics (mvn/models/loss.py:25-101, datasets/human36m.py:358-417) ---------------------------
+def pose_errors(pred, gt, prev=None):
+    """pred / gt: CUDA fp32 [n, J, 3]; prev: CUDA int32 [n] or None (= i-1).  -> CUDA fp32 [n, 4] =
+    per-pose {MPJPE, P_MPJPE, N_MPJPE, velocity error}."""
+    import torch
+    lib = load_library()
+    n, J, _ = pred.shape
+    err = torch.empty(n, 4, dtype=torch.float32, device=pred.device)
+    rc = lib.capf_pose_errors(_stream(pred), _p(pred.contiguous()), _p(gt.contiguous()), n, J, _p(prev), _p(err))
+    if rc:
+        raise CapfError(f"capf_pose_errors failed ({rc})")
+    return err
+
+
+def segment_sums(err, segment=None, prev=None, n_segments=1):
+    """-> (sums float64 [n_segments, 4], counts int32 [n_segments, 2]) on the device."""
+    import torch
+    lib = load_library()
+    n = err.shape[0]
+    sums = torch.empty(n_segments, 4, dtype=torch.float64, device=err.device)
+    counts = torch.empty(n_segments, 2, dtype=torch.int32, device=err.device)
+    rc = lib.capf_segment_sums(_stream(err), _p(err), _p(segment), _p(prev), n, n_segments, _p(sums), _p(counts))
+    if rc:
+        raise CapfError(f"capf_segment_sums failed ({rc})")
+    return sums, counts
+
+
+def keypoints_loss(mode, pred, gt, validity, threshold=0.0, want_grad=False):
+    """mode 0 MSE, 1 MSESmooth, 2 MAE (loss.py:104-137).  pred / gt [..., D], validity [..., 1] -> (loss[1], dpred | None)."""
+    import torch
+    lib = load_library()
+    D = pred.shape[-1]
+    rows = pred.numel() // D
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred, memory_format=torch.contiguous_format) if want_grad else None
+    v = validity.to(torch.float32).expand(*pred.shape[:-1], 1).contiguous()
+    rc = lib.capf_keypoints_loss(_stream(pred), int(mode), _p(pred.contiguous()), _p(gt.contiguous()), _p(v), rows, D,
+                                 float(threshold), _p(loss), _p(dpred))
+    if rc:
+        raise CapfError(f"capf_keypoints_loss failed ({rc})")
+    return loss, dpred

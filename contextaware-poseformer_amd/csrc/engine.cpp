@@ -598,6 +598,26 @@ int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* 
                ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_pose_errors(void* stream, const float* pred, const float* gt, int n, int joints, const int32_t* prev, float* err) {
+    if (!pred || !gt || !err || n <= 0 || joints <= 0) return CAPF_ERR_INVALID;
+    hipError_t r = capf::launch_pose_errors(pred, gt, n, joints, prev, err, static_cast<hipStream_t>(stream));
+    return r == hipSuccess ? CAPF_OK : (r == hipErrorInvalidValue ? CAPF_ERR_UNSUPPORTED : CAPF_ERR_HIP);
+}
+
+int capf_segment_sums(void* stream, const float* err, const int32_t* segment, const int32_t* prev, int n, int n_segments,
+                      double* sums, int32_t* counts) {
+    if (!err || !sums || !counts || n <= 0 || n_segments <= 0 || (n_segments > 1 && !segment)) return CAPF_ERR_INVALID;
+    return capf::launch_segment_sums(err, segment, prev, n, n_segments, sums, counts, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_keypoints_loss(void* stream, int mode, const float* pred, const float* gt, const float* validity, int rows, int dim,
+                        float threshold, float* loss, float* dpred) {
+    if (!pred || !gt || !validity || !loss || rows <= 0 || dim <= 0 || mode < 0 || mode > 2) return CAPF_ERR_INVALID;
+    return capf::launch_keypoints_loss(pred, gt, validity, rows, dim, mode, threshold, loss, dpred,
+                                       static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_num_ops(const capf_handle* h) { return h ? (int)h->e.ops.size() : CAPF_ERR_INVALID; }
 
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel, double* flops) {

@@ -156,4 +156,11 @@ bool affine_from_center_scale(const double center[2], const double scale[2], int
 hipError_t launch_warp_affine_u8(const unsigned char* const* frames, const int* dims, const double* M, unsigned char* out,
                                  int B, int out_h, int out_w, hipStream_t s);
 
+// ---- evaluation metrics (metrics.hip): N2 -------------------------------------------------------------------
+hipError_t launch_pose_errors(const float* pred, const float* gt, int n, int J, const int* prev, float* err, hipStream_t s);
+hipError_t launch_segment_sums(const float* err, const int* seg, const int* prev, int n, int n_seg, double* sums, int* counts,
+                               hipStream_t s);
+hipError_t launch_keypoints_loss(const float* pred, const float* gt, const float* validity, int rows, int D, int mode, float thr,
+                                 float* loss, float* dpred, hipStream_t s);
+
 }  // namespace capf

@@ -65,10 +65,31 @@ def make_capf_config(config, height=256, width=192, context_blocks=True, compute
 
 
 class Container(nn.Module):
-    """Plain named container; numeric children index like an nn.ModuleList."""
+    """Plain named container.  Numeric children behave like an nn.ModuleList (the reference keeps its block lists
+    in nn.ModuleList, pose_dformer.py:189-203): integer and negative indices, slices, iteration, len."""
+
+    def _numeric(self):
+        return all(k.isdigit() for k in self._modules)
 
     def __getitem__(self, i):
+        if isinstance(i, slice):
+            out = Container()
+            for k, m in list(self._modules.items())[i]:
+                out.add_module(k, m)
+            return out
+        if isinstance(i, int):
+            n = len(self._modules)
+            if not -n <= i < n:
+                raise IndexError("index {} is out of range".format(i))
+            if i < 0:
+                i += n
+            if str(i) in self._modules:
+                return self._modules[str(i)]
+            return list(self._modules.values())[i]
         return self._modules[str(i)]
+
+    def __iter__(self):
+        return iter(self._modules.values())
 
     def __len__(self):
         return len(self._modules)

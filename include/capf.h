@@ -224,6 +224,25 @@ int capf_preprocess(void* stream, const uint8_t* images_bgr, int batch, int heig
                     const float* k2d_in, float* k2d_out, const float* kcrop_in, float* kcrop_out);
 int capf_fliptest_fuse(void* stream, const float* pred2, int batch, float* out);
 
+/* ---- N2, second half: evaluation metrics over gathered predictions (train.py:381-436) -----------------
+ * capf_pose_errors: per pose i of pred / gt [n, joints, 3] (joints <= 32), err[i] = {e_MPJPE, e_P_MPJPE, e_N_MPJPE,
+ *   e_velocity}, each the mean over joints:  MPJPE loss.py:16-22;  P_MPJPE loss.py:25-68 (similarity Procrustes; the
+ *   host numpy SVD of :48-60 is replaced by Horn's quaternion closed form, fp64 Jacobi per thread);  N_MPJPE
+ *   loss.py:71-84;  velocity = |(pred_i - pred_prev) - (gt_i - gt_prev)| with prev = prev[i] (the previous pose of the
+ *   same evaluated subset, i.e. np.diff over the masked rows, loss.py:87-101); prev == NULL means i-1; prev[i] < 0: 0.
+ * capf_segment_sums: per-action aggregation of evaluate_using_pred (datasets/human36m.py:358-417): sums[a] =
+ *   {sum e_MPJPE, sum e_P_MPJPE, sum e_N_MPJPE, sum e_velocity} over poses with segment[i] == a (fp64, fixed order:
+ *   deterministic), counts[a] = {poses, poses with a predecessor}.  segment == NULL with n_segments == 1: all poses.
+ *   The reference's numbers are then MPJPE_a = sums[a][0]/counts[a][0], MPJVE_a = sums[a][3]/counts[a][1], ...
+ * capf_keypoints_loss: KeypointsMSELoss (mode 0) / KeypointsMSESmoothLoss (1, `threshold`) / KeypointsMAELoss (2),
+ *   loss.py:104-137: pred / gt [rows, dim], validity [rows] (the reference's [...,1] mask); writes the scalar loss and,
+ *   if dpred != NULL, dloss/dpred.                                                                              */
+int capf_pose_errors(void* stream, const float* pred, const float* gt, int n, int joints, const int32_t* prev, float* err);
+int capf_segment_sums(void* stream, const float* err, const int32_t* segment, const int32_t* prev, int n, int n_segments,
+                      double* sums, int32_t* counts);
+int capf_keypoints_loss(void* stream, int mode, const float* pred, const float* gt, const float* validity, int rows, int dim,
+                        float threshold, float* loss, float* dpred);
+
 /* ---- N3: the per-frame affine crop in front of the prefetcher ------------------------
  * capf_affine_from_center_scale: get_affine_transform(center, scale, 0, (out_w, out_h)) of
  *   mvn/utils/img.py:16-48 (rot 0, shift 0): the 2x3 row-major double matrix cv2.getAffineTransform returns

@@ -16,7 +16,7 @@ REFERENCE_ROOT = "/root/reference/ContextPose"
 
 
 def install():
-    """Install the shims and put the reference on sys.path.  Never writes into /root/reference."""
+    """Install the timm / easydict shims.  Never writes into /root/reference."""
     sys.dont_write_bytecode = True
     import torch
     from torch import nn
@@ -87,16 +87,50 @@ def install():
         mod.EasyDict = EasyDict
         sys.modules["easydict"] = mod
 
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
 
 
-def reference_config(backbone="hrnet_32", embed_dim_ratio=128):
-    """Fresh copy of the reference's default config patched exactly as train.py:266-277 does."""
-    install()
-    import copy
-    from mvn.utils import cfg as refcfg
-    c = copy.deepcopy(refcfg.config)
+BUILD_PKG_MARK = "contextaware-poseformer_amd"
+
+
+class reference_imports:
+    """Context manager: inside it, `import mvn...` resolves to /root/reference/ContextPose/mvn and to nothing else.
+
+    The reference's `mvn/` has no __init__.py (a namespace package) while the build's host mirror
+    `contextaware-poseformer_amd/mvn/` is a regular package, and a regular package wins over a namespace package
+    whatever the order of sys.path.  So for the duration of the block the build's package root is taken OFF
+    sys.path and every `mvn*` module is purged from sys.modules; on exit the reference's `mvn*` modules are purged
+    again and the previous ones restored (objects already built from the reference's classes keep working).
+    `check()` asserts the origin of what was imported: a golden can never be produced from the mirror by accident."""
+
+    def __init__(self, root=REFERENCE_ROOT, packages=("mvn",)):
+        self.root, self.packages = root, tuple(packages)
+
+    def _mine(self, k):
+        return any(k == p or k.startswith(p + ".") for p in self.packages)
+
+    def __enter__(self):
+        install()
+        self.saved_path = list(sys.path)
+        self.saved_mods = {k: v for k, v in sys.modules.items() if self._mine(k)}
+        for k in self.saved_mods:
+            del sys.modules[k]
+        sys.path[:] = [self.root] + [p for p in sys.path if BUILD_PKG_MARK not in p and p != self.root]
+        return self
+
+    def check(self, *module_names):
+        for n in module_names:
+            f = getattr(sys.modules[n], "__file__", None) or ""
+            assert f.startswith(self.root + "/"), f"{n} was imported from {f!r}, not from the reference ({self.root})"
+
+    def __exit__(self, *exc):
+        for k in [k for k in sys.modules if self._mine(k)]:
+            del sys.modules[k]
+        sys.modules.update(self.saved_mods)
+        sys.path[:] = self.saved_path
+        return False
+
+
+def _patch_config(c, backbone, embed_dim_ratio):
     c.model.backbone.type = backbone
     c.model.backbone.fix_weights = True           # human36m.yaml:21
     c.model.poseformer.embed_dim_ratio = embed_dim_ratio
@@ -110,14 +144,36 @@ def reference_config(backbone="hrnet_32", embed_dim_ratio=128):
     return c
 
 
+def reference_config(backbone="hrnet_32", embed_dim_ratio=128):
+    """Fresh copy of the reference's default config patched exactly as train.py:266-277 does."""
+    import copy
+    with reference_imports() as ri:
+        from mvn.utils import cfg as refcfg
+        ri.check("mvn.utils.cfg")
+        return _patch_config(copy.deepcopy(refcfg.config), backbone, embed_dim_ratio)
+
+
 def build_reference(backbone="hrnet_32", embed_dim_ratio=128):
-    install()
-    import contextlib, io
-    from mvn.models.conpose import CA_PF
-    c = reference_config(backbone, embed_dim_ratio)
-    with contextlib.redirect_stdout(io.StringIO()):
-        m = CA_PF(c, device="cpu")
+    """The REAL reference CA_PF (ContextPose/mvn/models/conpose.py:10-42) on CPU, eval mode."""
+    import contextlib, copy, io
+    with reference_imports() as ri:
+        from mvn.utils import cfg as refcfg
+        from mvn.models.conpose import CA_PF
+        ri.check("mvn.utils.cfg", "mvn.models.conpose", "mvn.models.pose_dformer", "mvn.models.pose_hrnet")
+        c = _patch_config(copy.deepcopy(refcfg.config), backbone, embed_dim_ratio)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = CA_PF(c, device="cpu")
+    assert type(m).__module__ == "mvn.models.conpose" and type(m.volume_net).__name__ == "PoseTransformer"
     return m.eval(), c
+
+
+def reference_losses():
+    """The reference's mvn/models/loss.py module object (MPJPE, P_MPJPE, N_MPJPE, MPJVE, Keypoints*Loss)."""
+    with reference_imports() as ri:
+        import importlib
+        mod = importlib.import_module("mvn.models.loss")
+        ri.check("mvn.models.loss")
+    return mod
 
 
 MPI_ROOT = "/root/reference/ContextPose_mpi"
@@ -125,27 +181,19 @@ MPI_ROOT = "/root/reference/ContextPose_mpi"
 
 def build_reference_mpi(backbone="hrnet_32"):
     """The sibling app's model (ContextPose_mpi/model/conpose.py) with run_3dhp.py:219-235's config patch.
-    Its packages are called `model` / `common`; they are imported under a clean sys.path entry."""
-    install()
+    Its packages are called `model` / `common` (the build's own mirror package is also called `model`)."""
     import contextlib, copy, importlib, io
-    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "common" or k.startswith("common.")]:
-        del sys.modules[k]          # the build's own mirror package is also called `model`
-    # a regular package (the build's model/ has an __init__.py) beats the reference's namespace package no
-    # matter the path order, so the build's source root is taken off sys.path for the duration of the import
-    saved_path = list(sys.path)
-    sys.path[:] = [MPI_ROOT] + [p for p in sys.path if "contextaware-poseformer_amd" not in p]
-    cfgmod = importlib.import_module("common.cfg")
-    c = copy.deepcopy(cfgmod.config)
-    if backbone == "hrnet_32":
-        c.model.backbone.STAGE2.NUM_CHANNELS = [32, 64]
-        c.model.backbone.STAGE3.NUM_CHANNELS = [32, 64, 128]
-        c.model.backbone.STAGE4.NUM_CHANNELS = [32, 64, 128, 256]
-        c.model.poseformer.base_dim = 32
-        c.model.poseformer.embed_dim_ratio = 64
-    net = importlib.import_module("model.conpose").VolumetricTriangulationNet
-    with contextlib.redirect_stdout(io.StringIO()):
-        m = net(c)
-    sys.path[:] = saved_path
-    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "common" or k.startswith("common.")]:
-        del sys.modules[k]
+    with reference_imports(MPI_ROOT, ("model", "common")) as ri:
+        cfgmod = importlib.import_module("common.cfg")
+        c = copy.deepcopy(cfgmod.config)
+        if backbone == "hrnet_32":
+            c.model.backbone.STAGE2.NUM_CHANNELS = [32, 64]
+            c.model.backbone.STAGE3.NUM_CHANNELS = [32, 64, 128]
+            c.model.backbone.STAGE4.NUM_CHANNELS = [32, 64, 128, 256]
+            c.model.poseformer.base_dim = 32
+            c.model.poseformer.embed_dim_ratio = 64
+        net = importlib.import_module("model.conpose").VolumetricTriangulationNet
+        ri.check("common.cfg", "model.conpose")
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = net(c)
     return m.eval(), c

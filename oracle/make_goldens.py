@@ -85,7 +85,7 @@ def run_case(name, case):
 
     if name == "w32_256x256_b2":
         # training step vectors, DropPath off (drop_prob forced to 0) — SURVEY.md §7 "Hard parts"
-        from mvn.models.loss import MPJPE
+        MPJPE = _refshim.reference_losses().MPJPE
         model.train(); model.backbone.eval()
         for m in model.modules():
             if type(m).__name__ == "DropPath":
@@ -105,30 +105,103 @@ def run_case(name, case):
     return rec
 
 
-def dump_schemas(outdir):
-    """state_dict names + shapes of the reference model per backbone (the drop-in boundary,
-    SURVEY.md §8b) -> tests/golden/schema_<backbone>.json."""
+def loss_case():
+    """N2 metrics, from the reference's own mvn/models/loss.py (:16-22 MPJPE, :25-68 P_MPJPE, :71-84 N_MPJPE,
+    :87-101 MPJVE, :104-137 Keypoints{MSE,MSESmooth,MAE}Loss) on seeded poses.  Inputs are regenerated from the seed by
+    tests/golden_cases.metric_inputs; per-action sums follow evaluate_using_pred (datasets/human36m.py:358-417)."""
+    from golden_cases import metric_inputs
+    L = _refshim.reference_losses()
+    pred, gt, action_idx, validity = metric_inputs()
+    rec = {}
+    tp, tg = torch.from_numpy(pred), torch.from_numpy(gt)
+    rec["mpjpe"] = np.array(L.MPJPE()(tp, tg).item(), np.float64)
+    rec["n_mpjpe"] = np.array(L.N_MPJPE()(tp, tg).item(), np.float64)
+    sq_p, sq_g = pred.squeeze(), gt.squeeze()                      # what human36m.py:374,376 hands to the numpy metrics
+    rec["p_mpjpe"] = np.array(L.P_MPJPE()(sq_p.copy(), sq_g.copy()), np.float64)
+    rec["mpjve"] = np.array(L.MPJVE()(sq_p.copy(), sq_g.copy()), np.float64)
+    # per-pose Procrustes error (one pose at a time through the reference class)
+    rec["p_mpjpe_per_pose"] = np.array([L.P_MPJPE()(sq_p[i:i + 1].copy(), sq_g[i:i + 1].copy()) for i in range(len(sq_p))], np.float64)
+    na = int(action_idx.max()) + 1
+    per = np.zeros((na, 4), np.float64)
+    for a in range(na):
+        m = action_idx == a
+        n = np.count_nonzero(m)
+        per[a] = [n * L.MPJPE()(tp[m], tg[m]).item(), n * L.P_MPJPE()(sq_p[m].copy(), sq_g[m].copy()),
+                  n * L.MPJVE()(sq_p[m].copy(), sq_g[m].copy()), n]
+    rec["per_action"] = per
+    v = torch.from_numpy(validity)
+    p3, g3 = tp[:, 0], tg[:, 0]
+    rec["kp_mse"] = np.array(L.KeypointsMSELoss()(p3, g3, v).item(), np.float64)
+    rec["kp_mse_smooth"] = np.array(L.KeypointsMSESmoothLoss(threshold=0.05)(p3.clone(), g3.clone(), v).item(), np.float64)
+    rec["kp_mae"] = np.array(L.KeypointsMAELoss()(p3, g3, v).item(), np.float64)
+    return rec
+
+
+def schemas():
     import json
+    out = {}
     for bb in ("hrnet_32", "hrnet_48", "cpn"):
         model, _ = _refshim.build_reference(bb)
-        sd = model.state_dict()
-        with open(os.path.join(outdir, f"schema_{bb}.json"), "w") as f:
-            json.dump({k: list(v.shape) for k, v in sd.items()}, f, separators=(",", ":"))
+        out[bb] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    return out
+
+
+def compare(name, rec, path):
+    """rec (just regenerated from the reference) against the committed fixture: every key, exact."""
+    old = np.load(path, allow_pickle=False)
+    bad = []
+    if set(old.files) != set(rec):
+        bad.append(f"key sets differ: {sorted(set(old.files) ^ set(rec))}")
+    for k in sorted(set(old.files) & set(rec)):
+        a, b = np.asarray(rec[k]), old[k]
+        if a.shape != b.shape or a.dtype.kind != b.dtype.kind:
+            bad.append(f"{k}: shape/dtype {a.shape}{a.dtype} vs {b.shape}{b.dtype}")
+        elif a.dtype.kind in "fc":
+            d = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+            # bitwise on this container's torch build; 1e-6 relative slack for a different CPU's oneDNN dispatch
+            if d > 1e-6 * max(1.0, float(np.max(np.abs(b))) if b.size else 1.0):
+                bad.append(f"{k}: max |regenerated - committed| = {d:.3e}")
+        elif not np.array_equal(a, b):
+            bad.append(f"{k}: differs")
+    print(f"check {name}: {'OK' if not bad else 'MISMATCH'} ({len(rec)} keys)")
+    for b in bad:
+        print("   ", b)
+    return not bad
 
 
 def main():
+    """python oracle/make_goldens.py [--check] [case ... | schema | losses]
+    --check: regenerate in memory from the reference and compare with the committed fixtures (exit 1 on mismatch)."""
+    import json
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    only = sys.argv[1:]
+    args = sys.argv[1:]
+    check = "--check" in args
+    only = [a for a in args if a != "--check"]
+    ok = True
     if not only or "schema" in only:
-        dump_schemas(outdir)
-    for name, case in CASES.items():
+        for bb, sch in schemas().items():
+            path = os.path.join(outdir, f"schema_{bb}.json")
+            if check:
+                same = json.load(open(path)) == sch
+                print(f"check schema_{bb}: {'OK' if same else 'MISMATCH'}")
+                ok &= same
+            else:
+                with open(path, "w") as f:
+                    json.dump(sch, f, separators=(",", ":"))
+    todo = [(n, lambda n=n, c=c: run_case(n, c)) for n, c in CASES.items()] + [("losses", loss_case)]
+    for name, fn in todo:
         if only and name not in only:
             continue
-        rec = run_case(name, case)
+        rec = fn()
         path = os.path.join(outdir, name + ".npz")
+        if check:
+            ok &= compare(name, rec, path)
+            continue
         np.savez_compressed(path, **rec)
-        print(f"{name}: out absmax {np.abs(rec['out']).max():.4f}  -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+        print(f"{name}: -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    if check and not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -23,3 +23,24 @@ def case_inputs(case):
     if case["crop"] == "adv":
         kc = synth.adversarial_crop_keypoints(case["B"], seed=case["iseed"])
     return img, k2d, kc
+
+
+def metric_inputs(n=96, seed=77):
+    """Seeded evaluation-shaped data for the N2 metrics: pred / gt [n,1,17,3] fp32 (metres, root-relative-ish),
+    action_idx [n] (6 actions in interleaved runs, so masks are NOT contiguous), validity [n,17,1]."""
+    import numpy as np
+    rng = np.random.Generator(np.random.Philox(key=[seed, 20260928]))
+    gt = (rng.standard_normal((n, 1, 17, 3)) * 0.3).astype(np.float32)
+    gt[:, :, 0] = 0
+    # prediction = rotated, scaled, shifted, noisy ground truth (so Procrustes alignment has something to undo)
+    ang = rng.uniform(-0.4, 0.4, size=(n, 3))
+    pred = np.empty_like(gt)
+    for i in range(n):
+        cx, cy, cz = np.cos(ang[i]); sx, sy, sz = np.sin(ang[i])
+        R = np.array([[cy * cz, -cy * sz, sy], [sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy],
+                      [-cx * sy * cz + sx * sz, cx * sy * sz + sx * cz, cx * cy]])
+        pred[i, 0] = (gt[i, 0].astype(np.float64) @ R * rng.uniform(0.8, 1.2) + rng.standard_normal(3) * 0.05
+                      + rng.standard_normal((17, 3)) * 0.02).astype(np.float32)
+    action_idx = ((np.arange(n) // 5) % 6).astype(np.int32)
+    validity = (rng.uniform(size=(n, 17, 1)) > 0.2).astype(np.float32)
+    return pred, gt, action_idx, validity

@@ -117,3 +117,18 @@ def test_prefetch_preprocess_hand_computed():
     pf = p.clone(); pf[..., 0] *= -1
     pf[:, :, oracle.JOINTS_LEFT + oracle.JOINTS_RIGHT] = pf[:, :, oracle.JOINTS_RIGHT + oracle.JOINTS_LEFT]
     assert torch.allclose(oracle.fliptest_fuse(p, pf), p, atol=0)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/ContextPose/mvn"),
+                    reason="the reference only exists in the build container")
+def test_golden_recipe_regenerates_committed_fixtures():
+    """Guards the pin itself: oracle/make_goldens.py --check re-imports the REAL reference (asserting that
+    `mvn.models.conpose` resolves under /root/reference, not to this repo's mirror), regenerates every fixture
+    in memory and compares all keys with the committed .npz files."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_goldens.py"), "--check"], cwd="/tmp", env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": OK") >= len(CASES) + 4
