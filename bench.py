@@ -1,68 +1,132 @@
 #!/usr/bin/env python
 """Headline benchmark: frames/sec of the Context-Aware PoseFormer hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the hot path (CA_PF.forward through the C ABI: HRNet backbone -> joint-context
-sampling -> lifting transformer) over one batch of synthetic input that is already resident in HBM.
-Workload at every N: BASELINE.json configs[1] — batch 64 per GPU, HRNet-32, 256x256, fp32 (weak
-scaling: frames are independent, ranks share nothing, no data-path collective — SURVEY.md §8e).
-Rank 0 prints ONE JSON line with the whole-job frames/s plus
-  roofline     — for the dominant kernel: algorithmic FLOPs of its launches / their summed duration,
-                 measured with HIP event pairs on the launch stream (capf_forward_profile), against
-                 the dense fp32-MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
-  cpu_baseline — the CPU oracle (a port of the reference forward to functional PyTorch-CPU) timed
-                 on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+N > 1: one process per GPU over RCCL.  Either the driver launches the ranks (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) or,
+when WORLD_SIZE is not set, this script re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.
+
+A "step" is ONE pass of the hot path (CA_PF.forward through the C ABI: backbone -> joint-context sampling -> lifting
+transformer; with --train also MPJPE, the lifter backward, the flat-gradient all-reduce and fused AdamW) over one
+batch of synthetic input already resident in HBM.  Default workload = BASELINE.json configs[1]: batch 64 per GPU,
+HRNet-32, 256x256, fp32.  The other configurations are selected with --config 0..4 (or spelled out with --backbone /
+--batch / --height / --width / --dtype / --train); frames are independent, so N ranks share nothing on the data path
+(weak scaling, no collective) except the one gradient all-reduce of the training configuration.
+
+Rank 0 prints ONE JSON line: whole-job frames/s plus
+  roofline     — for the dominant kernel: algorithmic FLOPs (and algorithmic HBM bytes) of its launches / their summed
+                 duration, measured with HIP event pairs on the launch stream (capf_forward_profile_launches), against
+                 the dense MFMA peak for the dtype and the 8 TB/s HBM peak (MI355X_MICROARCH.md); `bound` names the
+                 roof the kernel sits closer to, `other_roof` carries the second one; `traffic` = measured HBM bytes
+                 per launch from the offline rocprofv3 FETCH_SIZE / WRITE_SIZE passes of the same command
+                 (profiles/r02_hbm_traffic.json, keyed by configuration), null if not collected;
+  cpu_baseline — the CPU oracle (a port of the reference forward to functional PyTorch-CPU) timed on this box's host
+                 cores on bounded samples of the same workload (rank 0, N=1 only): batch 1 and batch 16.
 """
 import argparse
 import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "contextaware-poseformer_amd"))
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}          # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (fp32-input matrix = vector rate)
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json configs[i] -> arguments (batch is per GPU)
+CONFIGS = {
+    0: dict(backbone="hrnet_32", batch=1, height=256, width=256, dtype="f32", train=False),
+    1: dict(backbone="hrnet_32", batch=64, height=256, width=256, dtype="f32", train=False),
+    2: dict(backbone="hrnet_48", batch=256, height=256, width=256, dtype="bf16", train=False),
+    3: dict(backbone="hrnet_32", batch=512, height=256, width=256, dtype="f32", train=True),
+    4: dict(backbone="cpn", batch=128, height=384, width=288, dtype="bf16", train=False),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json configs[i]; explicit flags override")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 64; 512 with --train)")
-    ap.add_argument("--train", action="store_true", help="BASELINE.json configs[3]: training step (frozen backbone forward, "
+    ap.add_argument("--train", action="store_true", default=None, help="configs[3]: training step (frozen backbone forward, "
                     "lifter forward+backward, MPJPE, gradient all-reduce, fused AdamW) instead of inference")
-    ap.add_argument("--backbone", default="hrnet_32", choices=["hrnet_32", "hrnet_48", "cpn"])
-    ap.add_argument("--height", type=int, default=256)
-    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--backbone", default=None, choices=["hrnet_32", "hrnet_48", "cpn"])
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="bf16: backbone convs + lifter GEMM operands on bf16 MFMA")
+    ap.add_argument("--embed", type=int, default=128, help="poseformer.embed_dim_ratio (128 = the reference default; 256 = the "
+                    "labelled extra point for BASELINE's 'dim=256')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: backbone convs on bf16 MFMA (configs[2]/[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
     ap.add_argument("--lanes", type=int, default=-1,
                     help="independent backbone branches: 2 grouped launches (default), 1 side streams, 0 program order")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous, sharding, barriers, max-over-ranks and the JSON line "
+                    "with a sleep instead of the GPU step (CPU smoke test of the N>1 flow)")
+    a = ap.parse_args(argv)
+    base = dict(CONFIGS[a.config if a.config is not None else 1])
+    if a.train and a.config is None:
+        base.update(batch=512, train=True)
+    for k in ("backbone", "batch", "height", "width", "dtype", "train"):
+        if getattr(a, k) is None:
+            setattr(a, k, base[k])
+    return a
 
 
-def cpu_baseline(backbone, H, W, sd_cpu, budget_s=15.0):
-    """Time the CPU oracle on a bounded sample of the workload (batch-8 forwards, <= ~budget_s of CPU
-    work).  Thread count: oneDNN convs stop scaling (and can collapse) far below the core count of a
-    256-core host, so 16/32/64 threads are tried in turn while they keep paying; `cores` in the result
-    is the thread count actually used for the reported number."""
+def config_tag(a):
+    """Which BASELINE.json configuration the arguments spell, if any."""
+    cur = dict(backbone=a.backbone, batch=a.batch, height=a.height, width=a.width, dtype=a.dtype, train=bool(a.train))
+    for i, c in CONFIGS.items():
+        if c == cur and a.embed == 128:
+            return i
+    return None
+
+
+def workload_string(a, tag):
+    head = f"configs[{tag}]" if tag is not None else "custom (not a BASELINE.json configuration)"
+    arith = "fp32 MFMA" if a.dtype == "f32" else "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)"
+    if a.train:
+        return (f"{head}: TRAINING step, batch {a.batch}/GPU {a.backbone} {a.height}x{a.width} (frozen backbone forward, lifter "
+                f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), lifter embed {a.embed} levels 4, {arith}")
+    return (f"{head}: batch {a.batch}/GPU {a.backbone} {a.height}x{a.width} image + 17 kpts -> 17x3, PoseFormer lifter embed "
+            f"{a.embed} levels 4, {arith}, inference")
+
+
+def respawn_under_torchrun(a):
+    """--gpus N without a launcher: run N ranks of this same command under torch.distributed.run on 127.0.0.1."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(backbone, H, W, sd_cpu, budget_s=24.0):
+    """Time the CPU oracle on bounded samples of the workload: batch 1 (latency) and batch 16 (throughput), as SURVEY.md
+    §8(d) plans.  oneDNN convolutions stop scaling (and can collapse) far below the core count of a 256-core host, so
+    for batch 16 the thread count is swept 16/32/64/all while it keeps paying; `cores` is the thread count of the reported
+    number, `host_cores` what the box has.  `value` is the best batch-16 rate."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import capf_oracle as oracle
     from capf import synth
     host = os.cpu_count() or 1
-    B = 8
-    img, k2d, kc = synth.synth_inputs(B, H, W, seed=101)
+    t_start = time.perf_counter()
 
-    def run(threads, reps):
+    def run(B, threads, reps):
+        img, k2d, kc = synth.synth_inputs(B, H, W, seed=101)
         torch.set_num_threads(threads)
         ts = []
         with torch.no_grad():
@@ -72,36 +136,64 @@ def cpu_baseline(backbone, H, W, sd_cpu, budget_s=15.0):
                 ts.append(time.perf_counter() - t0)
         return ts
 
-    t_start = time.perf_counter()
+    points = []
     best_threads, best = None, None
-    for threads in [t for t in (16, 32, 64) if t <= host] or [host]:
-        ts = run(threads, 2)                       # first call doubles as warm-up
-        t = min(ts)
+    for threads in sorted({t for t in (16, 32, 64, host) if t <= host}):
+        t = min(run(16, threads, 2))                      # first call doubles as warm-up
+        points.append({"batch": 16, "threads": threads, "frames_per_s": round(16 / t, 2)})
         if best is None or t < best:
             best_threads, best = threads, t
-        if t > 1.25 * best or time.perf_counter() - t_start > budget_s / 2:
+        if t > 1.25 * best or time.perf_counter() - t_start > budget_s * 0.5:
             break
-    times = run(best_threads, 1)
-    while time.perf_counter() - t_start < budget_s and len(times) < 30:
-        times += run(best_threads, 1)
+    times = run(16, best_threads, 1)
+    while time.perf_counter() - t_start < budget_s * 0.75 and len(times) < 20:
+        times += run(16, best_threads, 1)
     times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 2), "unit": "frames/s", "cores": best_threads, "host_cores": host, "kind": "port",
-            "sample": f"{len(times)} x batch-{B} {backbone} {H}x{W} fp32 forwards of oracle/capf_oracle.py "
-                      f"(functional PyTorch-CPU/oneDNN, {best_threads} threads), median"}
+    med16 = times[len(times) // 2]
+    t1 = run(1, min(best_threads, host), 4)[1:]
+    t1.sort()
+    points.append({"batch": 1, "threads": best_threads, "frames_per_s": round(1 / t1[len(t1) // 2], 2)})
+    return {"value": round(16 / med16, 2), "unit": "frames/s", "cores": best_threads, "host_cores": host, "kind": "port",
+            "points": points,
+            "sample": f"{len(times)} x batch-16 and {len(t1)} x batch-1 {backbone} {H}x{W} fp32 forwards of oracle/capf_oracle.py "
+                      f"(functional PyTorch-CPU/oneDNN; value = median batch-16 rate at {best_threads} threads, the best of the sweep in `points`)"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(a))
     import torch
     import torch.distributed as dist
+    from capf import dist as cdist
+    rank, world, local = cdist.init_from_env(a.backend)    # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    tag = config_tag(a)
+    B, H, W = a.batch, a.height, a.width
+
+    if a.dry_run:
+        lo, hi = cdist.shard_bounds(B * world, rank, world)
+        cdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            time.sleep(0.002 * (1 + rank))
+        cdist.barrier()
+        elapsed = cdist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+        if rank == 0:
+            print(json.dumps({"metric": "frames/sec", "value": round(B * world * a.steps / elapsed, 2), "unit": "frames/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "none",
+                              "dry_run": True, "config": {"workload": workload_string(a, tag), "frames_per_step": B * world,
+                                                          "shard_of_rank0": [lo, hi]}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     from capf import synth
     from mvn.models.conpose import CA_PF
     from mvn.utils.cfg import backbone_preset, config
-
-    from capf import dist as cdist
-    rank, world, local = cdist.init_from_env(a.backend)    # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if os.environ.get("CAPF_BENCH_SINGLE_DEVICE"):         # smoke-testing the N>1 flow on a 1-GPU box (gloo only)
         local = 0
     torch.cuda.set_device(local)
@@ -109,13 +201,13 @@ def main():
 
     cfg = backbone_preset(copy.deepcopy(config), a.backbone)
     cfg.model.backbone.fix_weights = True
+    cfg.model.poseformer.embed_dim_ratio = a.embed
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32").eval()
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
 
-    B, H, W = a.batch or (512 if a.train else 64), a.height, a.width
     img, k2d, kc, gt = synth.synth_inputs(B, H, W, seed=1000 + rank, crop_range=(192, 256), with_gt=True)
     img, k2d, kc0, gt = img.to(dev), k2d.to(dev), kc.to(dev), gt.to(dev)
     kc_work = kc0.clone()
@@ -171,8 +263,10 @@ def main():
     result = None
     if rank == 0:
         eng = model.engine_for(img)
-        # ---- per-kernel event timing on the launch stream (separate, untimed passes)
+        # ---- per-kernel event timing on the launch stream (separate, untimed passes over the FORWARD schedule; in
+        # the training configuration the frozen-backbone forward is 90 % of the step and owns the dominant kernel)
         table = eng.op_table(B)
+        obytes = eng.op_bytes(B)
         acc = {}
         out_buf = torch.empty_like(out)
         with torch.no_grad():
@@ -185,53 +279,63 @@ def main():
                     if l >= 0:
                         members.setdefault(l, []).append(i)
                 for l, ops_ in members.items():
-                    kern = table[l][1] if len(ops_) == 1 else ("igemm_bf16_group" if table[l][1].startswith("igemm_bf16") else "igemm_f32_group")
+                    kern = table[l][1]
+                    if len(ops_) > 1 and kern.startswith("igemm"):
+                        kern = "igemm_bf16_group" if kern.startswith("igemm_bf16") else "igemm_f32_group"
                     if not kern or table[l][0].startswith("copy."):
                         continue
-                    e = acc.setdefault(kern, [0.0, 0.0, 0])
-                    e[0] += ms[l]; e[1] += sum(table[i][2] for i in ops_); e[2] += 1
+                    e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0])
+                    e[0] += ms[l]; e[1] += sum(table[i][2] for i in ops_); e[2] += 1; e[3] += sum(obytes[i] for i in ops_)
                 n_launches = len(members)
+        nprof = max(1, a.profile_steps)
         total_ms = sum(e[0] for e in acc.values())
-        dom = max(acc.items(), key=lambda kv: kv[1][0])
-        dname, (dms, dflops, dn) = dom
-        achieved = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        dname, (dms, dflops, dn, dbytes) = max(acc.items(), key=lambda kv: kv[1][0])
+        tflops = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        gbs = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
         gemm_ms = sum(e[0] for k, e in acc.items() if k.startswith("igemm"))
         gemm_fl = sum(e[1] for k, e in acc.items() if k.startswith("igemm"))
+        gemm_by = sum(e[3] for k, e in acc.items() if k.startswith("igemm"))
         peak = PEAK_TFLOPS[a.dtype]
-        # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and
-        # WRITE_SIZE in separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tfile) and (a.backbone, B, H, W, a.train) == ("hrnet_32", 64, 256, 256, False):
-            traffic = json.load(open(tfile)).get(dname, {}).get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
-                    "algorithmic_flops_per_launch": round(dflops / dn, 1),
-                    "launches_per_step": dn // max(1, a.profile_steps),
-                    "avg_launch_us": round(dms / dn * 1e3, 2),
-                    "share_of_step": round(dms / total_ms, 4),
-                    "all_mfma_kernels": {"achieved": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
-                                         "frac": round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, 4),
-                                         "share_of_step": round(gemm_ms / total_ms, 4)}}
+        # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
+        # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
+        traffic, tsrc = None, None
+        for tfile, key in ((os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"), f"cfg{tag}"),
+                           (os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"), None)):
+            if traffic is None and tag is not None and os.path.exists(tfile):
+                data = json.load(open(tfile))
+                data = data.get(key, {}) if key else (data if tag == 1 else {})
+                traffic = data.get(dname, {}).get("hbm_bytes_per_launch")
+                tsrc = os.path.relpath(tfile, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None
+        mfma = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)}
+        hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        first, second = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
+        roofline = dict(first)
+        roofline.update({
+            "kernel": dname, "traffic": traffic, "traffic_source": tsrc, "other_roof": second,
+            "algorithmic_flops_per_launch": round(dflops / dn, 1), "algorithmic_bytes_per_launch": round(dbytes / dn, 1),
+            "launches_per_step": dn // nprof, "avg_launch_us": round(dms / dn * 1e3, 2),
+            "share_of_forward": round(dms / total_ms, 4),
+            "measured_hbm_gbs": round(traffic / (dms / dn * 1e-3) / 1e9, 1) if traffic else None,
+            "all_mfma_kernels": {"tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
+                                 "mfma_frac": round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                                 "algorithmic_gbs": round(gemm_by / (gemm_ms * 1e-3) / 1e9, 1),
+                                 "share_of_forward": round(gemm_ms / total_ms, 4)},
+            "forward_ms_by_events": round(total_ms / nprof, 3)})
         if a.kernel_table:
             for k, e in sorted(acc.items(), key=lambda kv: -kv[1][0]):
-                n = e[2] // max(1, a.profile_steps)
                 tf = e[1] / (e[0] * 1e-3) / 1e12 if e[0] > 0 else 0
-                print(f"  {k:34s} {n:4d} launches/step {e[0] / max(1, a.profile_steps):9.3f} ms/step {tf:7.2f} TFLOP/s",
+                gb = e[3] / (e[0] * 1e-3) / 1e9 if e[0] > 0 else 0
+                print(f"  {k:34s} {e[2] // nprof:4d} launches/step {e[0] / nprof:9.3f} ms/step {tf:8.2f} TFLOP/s {gb:8.1f} GB/s(alg)",
                       file=sys.stderr)
         launches, flops = eng.stats(B)
+        par = f"dp{world} (independent frames, " + ("one flat-gradient all-reduce per step)" if a.train else "no collective)")
         result = {
             "metric": "frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (f"configs[3]: TRAINING step, batch {B}/GPU {a.backbone} {H}x{W} (frozen backbone forward, lifter "
-                                    f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), fp32" if a.train else
-                                    f"configs[1]: batch {B}/GPU {a.backbone} {H}x{W} image + 17 kpts -> 17x3, "
-                                    f"PoseFormer lifter embed 128 levels 4, fp32 inference"),
-                       "frames_per_step": B * world, "parallelism": f"dp{world} (independent frames, no collective)",
-                       "launches_per_step": n_launches, "gflop_per_frame": round(flops / B / 1e9, 3)},
-            "end_to_end_tflops": round(fps * flops / B / 1e12, 2),
+            "config": {"workload": workload_string(a, tag), "baseline_config": tag, "frames_per_step": B * world,
+                       "parallelism": par, "launches_per_forward": n_launches, "forward_gflop_per_frame": round(flops / B / 1e9, 3)},
+            "end_to_end_forward_tflops": round(fps * flops / B / 1e12, 2),
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:

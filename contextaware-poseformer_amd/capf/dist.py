@@ -56,7 +56,12 @@ def allreduce_mean_(flat):
     """In-place average of one flat fp32 gradient buffer over ranks (one collective for all 14 M lifter
     gradients instead of DDP's three 25 MB buckets)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":        # CPU-staged (smoke tests of the N>1 flow on one GPU)
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(dist.get_world_size())
     return flat
 

@@ -15,7 +15,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
-    "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss",
+    "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes",
 ]
 
 
@@ -73,6 +73,7 @@ def load_library():
     lib.capf_forward_stats.argtypes = [H, c_int, POINTER(c_int64), POINTER(c_double)]
     lib.capf_num_ops.argtypes = [H]
     lib.capf_op_info.argtypes = [H, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double)]
+    lib.capf_op_bytes.argtypes = [H, c_int, c_int, POINTER(c_double)]
     lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          POINTER(c_float), c_int]
     lib.capf_forward_profile_launches.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -80,6 +81,9 @@ def load_library():
     P = c_void_p
     lib.capf_forward_train.argtypes = [H, P, P, P, P, c_int, P, P]
     lib.capf_backward.argtypes = [H, P, P, c_int, P, P]
+    lib.capf_train_generation.argtypes = [H]
+    lib.capf_train_generation.restype = c_int64
+    lib.capf_max_batch.argtypes = [H]
     lib.capf_grad_elems.argtypes = [H]
     lib.capf_grad_elems.restype = c_int64
     lib.capf_grad_info.argtypes = [H, c_int, POINTER(c_int64)]
@@ -211,6 +215,12 @@ class Engine:
                                                 c_void_p(masks.data_ptr()) if masks is not None else c_void_p(0)),
                     "forward_train")
 
+    def train_generation(self):
+        return self.lib.capf_train_generation(self.h)
+
+    def max_batch(self):
+        return self.lib.capf_max_batch(self.h)
+
     def backward(self, grad_out, flat_grad, stream, masks=None):
         B = grad_out.shape[0]
         self._check(self.lib.capf_backward(self.h, c_void_p(stream), c_void_p(grad_out.data_ptr()), B,
@@ -260,6 +270,14 @@ class Engine:
         for i in range(self.lib.capf_num_ops(self.h)):
             self._check(self.lib.capf_op_info(self.h, i, batch, byref(name), byref(kern), byref(fl)), "op_info")
             out.append((name.value.decode(), kern.value.decode(), fl.value))
+        return out
+
+    def op_bytes(self, batch):
+        """algorithmic HBM bytes per op at `batch` (capf_op_bytes), in launch order"""
+        b, out = c_double(), []
+        for i in range(self.lib.capf_num_ops(self.h)):
+            self._check(self.lib.capf_op_bytes(self.h, i, batch, byref(b)), "op_bytes")
+            out.append(b.value)
         return out
 
     def forward_profile(self, images, k2d, kcrop, out, stream):

@@ -10,6 +10,9 @@ import torch
 
 
 def flatten_(module):
+    """Moves parameter STORAGE (`p.data = view of the flat buffer`).  CA_PF notices on its next forward — it
+    fingerprints the data pointers of volume_net's parameters per call (mvn/models/conpose.py::_engine) — and
+    re-borrows every pointer, so this may be called before or after the first forward."""
     params = list(module.parameters())
     flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
     off = 0

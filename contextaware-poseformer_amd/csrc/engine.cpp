@@ -304,6 +304,8 @@ void capf_destroy(capf_handle* h) {
     delete h;
 }
 
+int capf_max_batch(const capf_handle* h) { return h ? (h->e.batch_limit < h->e.cfg.max_batch ? h->e.batch_limit : h->e.cfg.max_batch) : CAPF_ERR_INVALID; }
+
 int capf_num_params(const capf_handle* h) { return h ? (int)h->e.params.size() : CAPF_ERR_INVALID; }
 
 int capf_param_info(const capf_handle* h, int index, const char** name, int64_t shape[4], int* ndim, int* kind) {
@@ -365,6 +367,7 @@ int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes) {
     if (!h) return CAPF_ERR_INVALID;
     h->e.ws = static_cast<float*>(dev_ptr);
     h->e.ws_bytes = bytes;
+    h->e.invalidate_train();
     return CAPF_OK;
 }
 
@@ -396,6 +399,11 @@ static int check_run(Engine& e, int batch) {
         e.err = "batch out of range (1..max_batch)";
         return CAPF_ERR_INVALID;
     }
+    if (batch > e.batch_limit) {
+        e.err = "batch too large for this input size: the kernels address one activation tensor with 32-bit offsets (limit " +
+                std::to_string(e.batch_limit) + " frames)";
+        return CAPF_ERR_UNSUPPORTED;
+    }
     if (!e.packed) {
         e.err = "capf_params_changed has not been called since the last capf_set_param";
         return CAPF_ERR_STATE;
@@ -415,6 +423,7 @@ int capf_forward(capf_handle* h, void* stream, const float* images_nhwc, const f
     if (rc) return rc;
     e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
     e.last_batch = batch;
+    e.invalidate_train();
     return e.run(static_cast<hipStream_t>(stream), batch, 0, (int)e.ops.size());
 }
 
@@ -425,6 +434,7 @@ int capf_backbone_forward(capf_handle* h, void* stream, const float* images_nhwc
     if (rc) return rc;
     e.images = images_nhwc;
     e.last_batch = batch;
+    e.invalidate_train();
     return e.run(static_cast<hipStream_t>(stream), batch, 0, e.n_backbone_ops);
 }
 
@@ -441,6 +451,7 @@ int capf_forward_train(capf_handle* h, void* stream, const float* images_nhwc, c
     e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
     e.last_batch = batch;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    e.invalidate_train();
     rc = e.run(s, batch, 0, e.n_backbone_ops);
     if (rc) return rc;
     return e.forward_train(s, batch, drop_masks);
@@ -450,6 +461,8 @@ int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch
     if (!h || !grad_out || !flat_grad) return CAPF_ERR_INVALID;
     return h->e.backward(static_cast<hipStream_t>(stream), batch, grad_out, flat_grad, drop_masks);
 }
+
+int64_t capf_train_generation(const capf_handle* h) { return h ? h->e.train_generation : -1; }
 
 int64_t capf_grad_elems(const capf_handle* h) { return h ? h->e.grad_elems : -1; }
 
@@ -479,6 +492,7 @@ int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* k
     if (rc) return rc;
     e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
     e.last_batch = batch;
+    e.invalidate_train();
     return e.run(static_cast<hipStream_t>(stream), batch, e.n_backbone_ops, (int)e.ops.size());
 }
 
@@ -632,6 +646,59 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     return CAPF_OK;
 }
 
+// Algorithmic (compulsory) HBM bytes of one op at `batch`: every operand read once, the result written once.
+int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes) {
+    if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0 || !bytes) return CAPF_ERR_INVALID;
+    const capf::Engine& e = h->e;
+    const capf::Op& op = e.ops[index];
+    const double B = batch, act = op.bf16 ? 2.0 : 4.0;
+    double b = 0.0;
+    switch (op.kind) {
+        case capf::OP_GEMM: {
+            const capf::Pack& pk = e.packs[op.pack];
+            const double M = (double)op.rows_per_frame * B;
+            const double in_elems = op.conv ? B * op.H * op.W * op.Cin : M * op.K;
+            b = in_elems * (op.conv && !op.bf16 ? 4.0 : act)                    // fp32 stem reads the fp32 image
+                + (double)pk.N * pk.K * (pk.bf16 ? 2.0 : 4.0) + (double)pk.N * 4.0
+                + M * op.N * (op.out_bf16 ? 2.0 : act)
+                + ((op.aux >= 0 || op.res_param >= 0) ? M * op.N * act : 0.0);
+            break;
+        }
+        case capf::OP_FUSE: {
+            const double out = B * op.H * op.W * op.C;
+            b = out * act;
+            for (int i = 0; i < op.n_in; ++i) b += out * act / (double)(1 << (2 * op.shift[i]));
+            break;
+        }
+        case capf::OP_MAXPOOL:
+        case capf::OP_RESIZE:
+            b = B * op.C * act * ((double)op.H * op.W + (double)op.Ho * op.Wo);
+            break;
+        case capf::OP_LAYERNORM:
+            b = (double)op.rows_per_frame * B * op.C * 4.0 * (op.aux >= 0 ? 3.0 : 2.0);
+            break;
+        case capf::OP_ATTENTION:
+            b = (double)op.i0 * B * op.i1 * op.i2 * op.i3 * 4.0 * 4.0;          // q, k, v in; o out
+            break;
+        case capf::OP_SAMPLE_REF:
+            b = B * op.i0 * op.C * (4.0 * act + 4.0);                           // 4 corners per joint + the sampled row
+            break;
+        case capf::OP_DEFORM:
+            for (int l = 0; l < op.i1; ++l) b += B * op.i0 * op.i2 * op.lvlC[l] * (4.0 * op.i3 * act + 4.0);
+            b += B * op.i0 * op.i1 * 3.0 * op.i2 * op.i3 * 4.0;
+            break;
+        case capf::OP_HEAD:
+            b = (double)op.rows_per_frame * B * (op.C + 3.0) * 4.0;
+            break;
+        case capf::OP_PREP_EMBED:
+            b = B * op.i0 * (op.C + 4.0) * 4.0;
+            break;
+        default: break;
+    }
+    *bytes = b;
+    return CAPF_OK;
+}
+
 int capf_op_schedule(const capf_handle* h, int index, int32_t* region, int32_t* level, int32_t* lane, int32_t* reads,
                      int32_t* writes) {
     if (!h || index < 0 || index >= (int)h->e.ops.size()) return CAPF_ERR_INVALID;
@@ -671,6 +738,7 @@ int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc,
     if (rc) return rc;
     e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
     e.last_batch = batch;
+    e.invalidate_train();
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& x : ev)
         if (hipEventCreate(&x) != hipSuccess) return CAPF_ERR_HIP;
@@ -693,6 +761,7 @@ int capf_forward_profile_launches(capf_handle* h, void* stream, const float* ima
     if (rc) return rc;
     e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
     e.last_batch = batch;
+    e.invalidate_train();
     capf::LaunchLog log;
     log.op_leader.assign(n, -1);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -185,7 +185,10 @@ struct Engine {
     std::vector<int> ctx_ao_pack;        // pack index of [attention_weights | sampling_offsets] per context block
     std::vector<long> grad_off;          // per parameter: offset in the flat lifter gradient, -1 for the backbone
     long grad_elems = 0;
-    int train_batch = 0;
+    int train_batch = 0;                 // batch of the forward_train whose activations are still in the workspace (0: none)
+    int64_t train_generation = 0;        // bumped by every run that (over)writes the workspace
+    void invalidate_train() { train_batch = 0; ++train_generation; }
+    int batch_limit = 0;                 // largest batch the 32-bit tensor addressing of the kernels allows (build())
     void train_layout(int B, TrainLayout& L) const;
     size_t train_elems(int B) const;
     int forward_train(hipStream_t s, int B, const float* masks);

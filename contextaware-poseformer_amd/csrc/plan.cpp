@@ -792,6 +792,18 @@ bool Engine::build() {
         }
     assign_offsets();
     schedule_regions();
+    // the GEMM kernels address a whole activation tensor (and a conv's input window) with 32-bit offsets
+    // (launch_gemm_f32: M * ld < 4e9 elements of out / res, < 4e9 bytes of a rows-mode operand)
+    {
+        double worst = 1.0;          // largest per-frame tensor, in elements
+        for (const Op& op : ops)
+            if (op.kind == OP_GEMM) {
+                worst = std::max(worst, (double)op.rows_per_frame * (double)std::max(op.omap.S1, (long)op.N));
+                if (op.conv) worst = std::max(worst, (double)op.H * op.W * op.Cin);
+                else worst = std::max(worst, (double)op.rows_per_frame * (double)std::max(op.amap.S1, (long)op.K) * 4.0 / (op.amap.G > 0 ? op.amap.G : 1));
+            }
+        batch_limit = (int)std::min(2.0e9, 3.9e9 / worst);
+    }
     // pack arena layout
     size_t off = 0;
     for (Pack& pk : packs) {

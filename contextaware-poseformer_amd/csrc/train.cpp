@@ -250,7 +250,8 @@ int Engine::forward_train(hipStream_t s, int B, const float* masks) {
 // ---------------------------------------------------------------------------------------------------
 int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const float* masks) {
     if (B != train_batch) {
-        err = "capf_backward: no matching capf_forward_train for this batch";
+        err = "capf_backward: the activations of the matching capf_forward_train are gone (no such call, another batch size, or "
+              "a later forward / workspace change overwrote them)";
         return CAPF_ERR_STATE;
     }
     const std::string V = "volume_net";

@@ -27,6 +27,7 @@ class _LifterStep(torch.autograd.Function):
         out = torch.empty(images.shape[0], 1, owner.num_joints, 3, dtype=torch.float32, device=images.device)
         stream = torch.cuda.current_stream(images.device).cuda_stream
         eng.forward_train(images, k2d, kcrop, out, stream, masks)
+        ctx.token = eng.train_generation()
         ctx.eng, ctx.masks, ctx.names, ctx.owner = eng, masks, names, owner
         ctx.keep = (k2d, kcrop)     # capf_backward re-reads the keypoints / normalised ref: keep them alive
         ctx.shapes = [p.shape for p in params]
@@ -35,6 +36,10 @@ class _LifterStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         eng = ctx.eng
+        if eng.train_generation() != ctx.token:
+            raise CapfError("backward of a CA_PF forward whose saved activations were overwritten by a later forward on the "
+                            "same engine (the native step keeps ONE set of activations in its workspace): call backward "
+                            "before the next forward of this model")
         layout, total = eng.grad_layout_cached()
         flat = torch.empty(total, dtype=torch.float32, device=grad_out.device)
         stream = torch.cuda.current_stream(grad_out.device).cuda_stream
@@ -73,25 +78,34 @@ class CA_PF(nn.Module):
         self.drop_path_rate = 0.2   # PoseTransformer(drop_path_rate=0.2), dpr = linspace(0, rate, levels) (pose_dformer.py:147,187)
         self.last_flat_grad = None  # flat fp32 gradient of volume_net.* written by the last backward
         self._engines = {}          # (device index, H, W) -> Engine
-        self._dirty = True          # parameters (re)loaded / moved since the last pack
-        self._lifter_versions = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+        # Parameter-change tracking.  `_generation` counts events that may have replaced parameter STORAGE or frozen
+        # (backbone) VALUES: load_state_dict on the model or either child, .to()/._apply, params_changed().  Every engine
+        # remembers the generation it last bound at (one shared flag would be cleared by the first engine that rebinds
+        # and leave the engines of other input resolutions stale).  volume_net parameters are additionally fingerprinted
+        # per call by (data_ptr, _version): optimizer steps bump versions, capf.optim.flatten_ / `p.data = ...` move
+        # storage without bumping anything else.
+        self._generation = 0
+        hook = lambda module, incompatible: self._mark_dirty()
+        self.register_load_state_dict_post_hook(hook)
+        self.backbone.register_load_state_dict_post_hook(hook)
+        self.volume_net.register_load_state_dict_post_hook(hook)
 
     # ---- parameter-change tracking -----------------------------------------------------------
     def _mark_dirty(self):
-        self._dirty = True
+        self._generation += 1
 
     def _apply(self, fn, *args, **kwargs):
-        self._dirty = True
+        self._generation += 1
         return super()._apply(fn, *args, **kwargs)
 
     def params_changed(self):
-        """Tell the engine that parameter VALUES changed in place (optimizer.step on backbone
-        weights, manual .data edits).  volume_net parameters are tracked automatically."""
-        self._dirty = True
+        """Tell the engine that parameter VALUES changed in place where torch cannot see it (manual .data edits
+        of backbone weights, an optimizer stepping backbone parameters).  volume_net parameters, load_state_dict and
+        .to() are tracked automatically."""
+        self._generation += 1
 
     def lifter_params_changed(self):
-        """Call after an update of volume_net parameters that torch cannot see (capf.optim.FusedAdamW writes
+        """Call after an in-place update of volume_net VALUES that torch cannot see (capf.optim.FusedAdamW writes
         them from its own kernel); torch optimizers bump tensor versions and are picked up automatically."""
         stream = torch.cuda.current_stream().cuda_stream
         for eng in self._engines.values():
@@ -110,45 +124,64 @@ class CA_PF(nn.Module):
         if eng is None:
             eng = Engine(_native.make_capf_config(self._config, H, W, context_blocks=self.context_blocks,
                                                   compute_dtype=self.compute_dtype), device=dev.index)
-            eng._packed_versions = None
+            eng._bound_generation = None
+            eng._lifter_print = None
             self._engines[key] = eng
-        lifter_versions = tuple(p._version for p in self.volume_net.parameters())
-        if self._dirty or eng._packed_versions != lifter_versions or not eng._bound:
+        lifter = list(self.volume_net.parameters())
+        ptrs = tuple(p.data_ptr() for p in lifter)
+        versions = tuple(p._version for p in lifter)
+        moved = eng._lifter_print is None or eng._lifter_print[0] != ptrs
+        if eng._bound_generation != self._generation or moved or not eng._bound:
+            # storage may have moved (or frozen values changed): borrow every pointer again, fold + pack everything
             if self.backbone.training and any(p.requires_grad for p in self.backbone.parameters()):
                 raise NotImplementedError("training-mode BatchNorm / backbone gradients are outside the hot "
                                           "path: freeze the backbone (fix_weights) and call backbone.eval()")
             state = self.state_dict(keep_vars=True)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            if self._dirty or not eng._bound:
-                eng._bound = {}
-                eng.bind_state({k: v.data for k, v in state.items()}, stream)
-            else:
-                eng.lifter_params_changed(stream)      # only volume_net values moved (optimizer step)
-            eng._packed_versions = lifter_versions
-            if all(e._packed_versions == lifter_versions and e._bound for e in self._engines.values()):
-                self._dirty = False
+            eng._bound = {}
+            eng.bind_state({k: v.data for k, v in state.items()}, torch.cuda.current_stream(dev).cuda_stream)
+            eng._bound_generation = self._generation
+            eng._lifter_print = (ptrs, versions)
+            eng.rebinds = getattr(eng, "rebinds", 0) + 1
+        elif eng._lifter_print[1] != versions:
+            eng.lifter_params_changed(torch.cuda.current_stream(dev).cuda_stream)      # only volume_net values moved (optimizer step)
+            eng._lifter_print = (ptrs, versions)
         return eng
 
     # ---- conpose.py:30-42 --------------------------------------------------------------------
     def forward(self, images, keypoints_2d_cpn, keypoints_2d_cpn_crop):
         if images.dtype != torch.float32:
             raise TypeError("images must be float32")
+        if images.device.type != "cuda":
+            raise CapfError("CA_PF runs on an MI355X only: inputs are on {} (no CPU fallback)".format(images.device))
         images = images.contiguous()
-        eng = self._engine(images)
-        k2d = keypoints_2d_cpn.contiguous()
-        if not keypoints_2d_cpn_crop.is_contiguous():
-            raise ValueError("keypoints_2d_cpn_crop is normalised in place and must be contiguous")
         B = images.shape[0]
-        out = torch.empty(B, 1, self.num_joints, 3, dtype=torch.float32, device=images.device)
-        stream = torch.cuda.current_stream(images.device).cuda_stream
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.volume_net.parameters()):
-            named = [(n, p) for n, p in self.volume_net.named_parameters()]
-            if not all(p.requires_grad for _, p in named):
-                raise NotImplementedError("partially frozen volume_net is not supported by the native backward")
-            names = tuple("volume_net." + n for n, _ in named)
-            return _LifterStep.apply(self, eng, images, k2d, keypoints_2d_cpn_crop, self._drop_masks(B, images.device),
-                                     names, *[p for _, p in named])
-        eng.forward(images, k2d, keypoints_2d_cpn_crop, out, stream)
+        for name, t in (("keypoints_2d_cpn", keypoints_2d_cpn), ("keypoints_2d_cpn_crop", keypoints_2d_cpn_crop)):
+            if t.dtype != torch.float32:
+                raise TypeError("{} must be float32, got {}".format(name, t.dtype))
+            if t.device != images.device:
+                raise ValueError("{} is on {} but images are on {}".format(name, t.device, images.device))
+            if tuple(t.shape) != (B, self.num_joints, 2):
+                raise ValueError("{} must have shape ({}, {}, 2), got {}".format(name, B, self.num_joints, tuple(t.shape)))
+        with torch.cuda.device(images.device):
+            eng = self._engine(images)
+            k2d = keypoints_2d_cpn.contiguous()
+            # the third argument is normalised IN PLACE (conpose.py:34-35); a non-contiguous view (which the reference
+            # accepts) goes through a contiguous staging copy that is written back
+            kcrop = keypoints_2d_cpn_crop if keypoints_2d_cpn_crop.is_contiguous() else keypoints_2d_cpn_crop.contiguous()
+            stream = torch.cuda.current_stream(images.device).cuda_stream
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.volume_net.parameters()):
+                named = [(n, p) for n, p in self.volume_net.named_parameters()]
+                if not all(p.requires_grad for _, p in named):
+                    raise NotImplementedError("partially frozen volume_net is not supported by the native backward")
+                names = tuple("volume_net." + n for n, _ in named)
+                out = _LifterStep.apply(self, eng, images, k2d, kcrop, self._drop_masks(B, images.device),
+                                        names, *[p for _, p in named])
+            else:
+                out = torch.empty(B, 1, self.num_joints, 3, dtype=torch.float32, device=images.device)
+                eng.forward(images, k2d, kcrop, out, stream)
+            if kcrop is not keypoints_2d_cpn_crop:
+                with torch.no_grad():
+                    keypoints_2d_cpn_crop.copy_(kcrop)
         return out
 
     def _drop_masks(self, B, device):

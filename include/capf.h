@@ -78,6 +78,9 @@ typedef struct capf_config {
  * device < 0: "plan only" — no HIP call is made; schema / workspace queries work (CPU tests).   */
 int capf_create(const capf_config* cfg, int device, capf_handle** out);
 void capf_destroy(capf_handle* h);
+/* Largest batch one call accepts: min(cfg.max_batch, what the kernels' 32-bit tensor addressing allows at this input
+ * size — about 3800 frames for HRNet at 256x256).  Larger batches return CAPF_ERR_UNSUPPORTED with a clear message. */
+int capf_max_batch(const capf_handle* h);
 const char* capf_last_error(const capf_handle* h);  /* h may be NULL: last create error */
 const char* capf_version(void);
 
@@ -133,6 +136,11 @@ int capf_forward_train(capf_handle* h, void* stream, const float* images_nhwc, c
                        float* kcrop_inout, int batch, float* out, const float* drop_masks);
 int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch, float* flat_grad,
                   const float* drop_masks);
+/* Saved activations live in the workspace: ANY later capf_forward* / capf_backbone_forward / capf_lifter_forward /
+ * capf_set_workspace invalidates them, and capf_backward then returns CAPF_ERR_STATE instead of differentiating the
+ * wrong step.  capf_train_generation changes with every such run: a host autograd node records it after its
+ * capf_forward_train and compares before capf_backward (two forwards followed by one combined backward).       */
+int64_t capf_train_generation(const capf_handle* h);
 int64_t capf_grad_elems(const capf_handle* h);
 int capf_grad_info(const capf_handle* h, int param_index, int64_t* offset);   /* -1: not a lifter parameter */
 int capf_mpjpe(void* stream, const float* pred, const float* gt, int rows, float* loss, float* dpred,
@@ -270,6 +278,9 @@ int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* 
 int capf_num_ops(const capf_handle* h);
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel,
                  double* flops);
+/* Algorithmic (compulsory) HBM bytes of op `index` at `batch`: each operand read once, the result written once
+ * (bf16 tensors 2 B/element).  bench.py's HBM-side roofline divides these by the measured launch durations. */
+int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes);
 /* capf_op_schedule: where op `index` sits in the launch schedule: its fork/join region (-1 outside / control op),
  *   its dependency level inside the region (capf_set_lanes mode 2 issues a region level by level), its lane
  *   (mode 1: side stream), and the workspace buffer ids it reads (5 slots) and writes (6 slots), -1 = unused,

@@ -32,12 +32,18 @@ def install():
 
             def forward(self, x):
                 if self.drop_prob == 0.0 or not self.training:
+                    if DropPath.record is not None and self.training:
+                        DropPath.record.append(torch.ones(x.shape[0]))
                     return x
                 keep = 1.0 - self.drop_prob
                 mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
                 if keep > 0.0 and self.scale_by_keep:
                     mask.div_(keep)
+                if DropPath.record is not None:          # golden generation: keep the multipliers that were drawn
+                    DropPath.record.append(mask.detach().clone().reshape(-1))
                 return x * mask
+
+        DropPath.record = None
 
         timm = types.ModuleType("timm")
         models = types.ModuleType("timm.models")

@@ -294,14 +294,31 @@ def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False,
     return torch.cat([x0, xr], dim=1), pos
 
 
+def split_drop_masks(masks, B, J=17, levels=4):
+    """The flat DropPath multiplier buffer of the C ABI (include/capf.h, capf_forward_train:
+    ctx[i]{m1[B],m2[B]} | res[i]{m1[B*J],m2[B*J]} | joint[i]{m1[B],m2[B]}) -> per-block (mask1, mask2) pairs shaped to
+    broadcast over the tensors timm's DropPath sees (pose_dformer.py:71,101: one draw per element of dim 0, which is
+    the frame for context / joint blocks and the (frame, joint) pair for the level blocks, :231-234)."""
+    out = {"ctx": [], "res": [], "joint": []}
+    off = 0
+    for group, per, shape in (("ctx", B, (B, 1, 1, 1)), ("res", B * J, (B * J, 1, 1)), ("joint", B, (B, 1, 1))):
+        for _ in range(levels):
+            m1 = masks[off:off + per].view(shape); off += per
+            m2 = masks[off:off + per].view(shape); off += per
+            out[group].append((m1, m2))
+    assert off == masks.numel()
+    return out
+
+
 def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=False, taps=None,
-                   context_blocks=True):
+                   context_blocks=True, drop_masks=None):
     """PoseTransformer.forward pose_dformer.py:210-241.
 
     k2d [B,17,2], ref [B,17,2] (already normalised), feats: 4 NCHW maps -> [B,1,17,3].
     taps: optional dict that receives intermediates for stage-level parity tests.
     """
     b, p, _ = k2d.shape
+    keep = split_drop_masks(drop_masks, b, p, levels) if drop_masks is not None else None
     x = _linear(P, pre + ".coord_embed", k2d)                               # :214
     toks = []
     for f in feats:                                                         # :216-218 (padding zeros)
@@ -317,7 +334,8 @@ def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=Fals
         taps["tokens0"] = x
     if context_blocks:
         for i in range(levels):                                             # :228-229 (depth = levels, :169)
-            x, pos = _deformable_block(P, f"{pre}.context_blocks.{i}", x, ref, feats, explicit=explicit)
+            x, pos = _deformable_block(P, f"{pre}.context_blocks.{i}", x, ref, feats, explicit=explicit,
+                                       keep=keep["ctx"][i] if keep else None)
             if taps is not None:
                 taps.setdefault("ctx_pos", []).append(pos)
         if taps is not None:
@@ -325,12 +343,12 @@ def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=Fals
     L = x.shape[1]
     x = x.permute(0, 2, 1, 3).reshape(b * p, L, -1)                          # 'b l p c -> (b p) l c' :231
     for i in range(levels):
-        x = _attn_block(P, f"{pre}.res_blocks.{i}", x, 8)                   # :233-234
+        x = _attn_block(P, f"{pre}.res_blocks.{i}", x, 8, keep=keep["res"][i] if keep else None)   # :233-234
     x = x.reshape(b, p, -1)                                                 # '(b p) l c -> b p (l c)' :235
     if taps is not None:
         taps["tokens_res"] = x
     for i in range(levels):
-        x = _attn_block(P, f"{pre}.joint_blocks.{i}", x, 8)                 # :237-238
+        x = _attn_block(P, f"{pre}.joint_blocks.{i}", x, 8, keep=keep["joint"][i] if keep else None)   # :237-238
     if taps is not None:
         taps["tokens_joint"] = x
     x = _linear(P, pre + ".head.1", _ln(P, pre + ".head.0", x, 1e-5))       # :240
@@ -347,15 +365,16 @@ def normalise_crop_keypoints_(kcrop):
     return kcrop
 
 
-def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit=False, taps=None):
-    """CA_PF.forward conpose.py:30-42.  images [B,H,W,3] NHWC fp32; mutates kcrop in place."""
+def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit=False, taps=None, drop_masks=None):
+    """CA_PF.forward conpose.py:30-42.  images [B,H,W,3] NHWC fp32; mutates kcrop in place.
+    drop_masks: training-mode DropPath multipliers (see split_drop_masks), None = eval / no drop."""
     x = images.permute(0, 3, 1, 2).contiguous()
     ref = normalise_crop_keypoints_(kcrop)
     feats = cpn_forward(P, x) if backbone == "cpn" else hrnet_forward(P, x)
     if taps is not None:
         taps["ref"] = ref.clone()
         taps["features"] = feats
-    return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps)
+    return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps, drop_masks=drop_masks)
 
 
 def mpjpe(pred, gt):

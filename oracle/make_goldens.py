@@ -87,21 +87,48 @@ def run_case(name, case):
         # training step vectors, DropPath off (drop_prob forced to 0) — SURVEY.md §7 "Hard parts"
         MPJPE = _refshim.reference_losses().MPJPE
         model.train(); model.backbone.eval()
-        for m in model.modules():
-            if type(m).__name__ == "DropPath":
-                m.drop_prob = 0.0
+        drop = [m for m in model.modules() if type(m).__name__ == "DropPath"]
+        rates = [m.drop_prob for m in drop]
+        for m in drop:
+            m.drop_prob = 0.0
         _, _, _, gt = synth.synth_inputs(case["B"], case["H"], case["W"], seed=case["iseed"],
                                          crop_range=case["crop"], with_gt=True)
-        model.zero_grad()
-        pred = model(img, k2d, kc.clone())
-        loss = MPJPE()(pred, gt)
-        loss.backward()
-        rec["train_loss"] = np.array(loss.item(), np.float32)
-        named = dict(model.named_parameters())
-        for k in GRAD_KEYS:
-            rec["grad:" + k] = named[k].grad.numpy()
-        rec["gradnorm_names"] = np.array([k for k, p in named.items() if p.grad is not None])
-        rec["gradnorms"] = np.array([p.grad.double().norm().item() for k, p in named.items() if p.grad is not None])
+
+        def step(prefix):
+            model.zero_grad()
+            pred = model(img, k2d, kc.clone())
+            loss = MPJPE()(pred, gt)
+            loss.backward()
+            rec[prefix + "train_loss"] = np.array(loss.item(), np.float32)
+            named = dict(model.named_parameters())
+            for k in GRAD_KEYS:
+                rec[prefix + "grad:" + k] = named[k].grad.numpy().copy()
+            rec[prefix + "gradnorm_names"] = np.array([k for k, p in named.items() if p.grad is not None])
+            rec[prefix + "gradnorms"] = np.array([p.grad.double().norm().item() for k, p in named.items() if p.grad is not None])
+            return pred
+
+        step("")
+        # the same step with DropPath ON (pose_dformer.py:71,76-79,101,137-138; rates linspace(0, 0.2, 4), :187): the
+        # multipliers the reference drew are recorded in call order, which IS the C ABI's drop_masks layout
+        for m, r in zip(drop, rates):
+            m.drop_prob = r
+        DP = type(drop[0])
+        DP.record = []
+        torch.manual_seed(20260928)
+        pred = step("dp_")
+        # blocks whose rate is 0 hold nn.Identity instead of DropPath (pose_dformer.py:71,101) and draw nothing: their
+        # multipliers are 1 in the ABI layout ctx[i]{m1[B],m2[B]} | res[i]{m1[B*17],m2[B*17]} | joint[i]{m1[B],m2[B]}
+        drawn, flat = list(DP.record), []
+        Bc = case["B"]
+        for group, per in (("context_blocks", Bc), ("res_blocks", Bc * 17), ("joint_blocks", Bc)):
+            for blk in getattr(model.volume_net, group):
+                for _ in range(2):
+                    flat.append(drawn.pop(0) if type(blk.drop_path).__name__ == "DropPath" else torch.ones(per))
+                    assert flat[-1].numel() == per
+        assert not drawn
+        rec["dp_masks"] = torch.cat(flat).numpy()
+        rec["dp_out"] = pred.detach().numpy()
+        DP.record = None
     return rec
 
 

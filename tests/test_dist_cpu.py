@@ -52,6 +52,43 @@ def _worker(rank, world, port, q):
     flat_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     ok_grad = torch.allclose(flat, flat_ref, atol=1e-6)
 
+    # ---- the same with the REAL lifter (oracle restatement of pose_dformer.py) and the flat gradient buffer laid out
+    # exactly as capf_backward writes it (capf_grad_info order), on small context maps: 2 ranks x 2 frames
+    import copy
+    from capf import synth
+    from capf.lib import Engine
+    from mvn.models import _native
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    plan = Engine(_native.make_capf_config(cfg, 256, 192), device=None)
+    layout, total = plan.grad_layout()
+    shapes = {n: s for n, s, k in plan.schema() if n in layout}
+    plan.close()
+    P = {n: synth.synth_tensor(n, shp, 5, shapes) for n, shp in shapes.items()}
+    P = {n: (torch.from_numpy(v) if not torch.is_tensor(v) else v).clone().requires_grad_(True) for n, v in P.items()}
+    g = torch.Generator().manual_seed(3)
+    Bt = 4
+    feats = [torch.randn(Bt, c, 16 >> i, 12 >> i, generator=g) for i, c in enumerate((32, 64, 128, 256))]
+    k2d = torch.rand(Bt, 17, 2, generator=g) * 2 - 1
+    ref_pts = torch.rand(Bt, 17, 2, generator=g) * 2 - 1
+    gt3 = torch.randn(Bt, 1, 17, 3, generator=g) * 0.3
+
+    def flat_grad(lo_, hi_):
+        for v in P.values():
+            v.grad = None
+        pred = oracle.lifter_forward(P, k2d[lo_:hi_], ref_pts[lo_:hi_], [f[lo_:hi_] for f in feats])
+        oracle.mpjpe(pred, gt3[lo_:hi_]).backward()
+        buf = torch.zeros(total)
+        for n, (off, cnt) in layout.items():
+            buf[off:off + cnt] = P[n].grad.reshape(-1)
+        return buf
+
+    a2, b2 = cd.shard_bounds(Bt, rank, world)
+    mine = flat_grad(a2, b2)
+    cd.allreduce_mean_(mine)                      # ONE collective over the 14.09 M-element buffer
+    whole = flat_grad(0, Bt)
+    ok_grad = ok_grad and total == 14094147 and torch.allclose(mine, whole, atol=2e-6, rtol=1e-4)
+
     t = cd.max_over_ranks(1.0 + rank, torch.device("cpu"))
     cd.barrier()
     q.put((rank, ok_gather, ok_grad, t))
@@ -83,3 +120,39 @@ def test_shard_bounds_cover_everything():
             spans = [cd.shard_bounds(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_bench_self_spawns_two_ranks_dry_run():
+    """`python bench.py --gpus 2` WITHOUT a launcher re-executes itself under torch.distributed.run (two ranks on
+    127.0.0.1); --dry-run replaces the GPU step by a sleep, everything else (rendezvous, barriers, max-over-ranks, one
+    JSON line from rank 0) is bench.py's own N>1 code path."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run",
+                        "--backend", "gloo", "--config", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] and j["config"]["frames_per_step"] == 1024 and j["scaling"] == "weak"
+    assert j["ms_per_step"] >= 4.0            # max over ranks: rank 1 sleeps 4 ms per step
+    assert j["config"]["workload"].startswith("configs[3]: TRAINING")
+
+
+def test_bench_labels_follow_the_arguments():
+    import importlib.util, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse([])
+    assert bench.config_tag(a) == 1 and "configs[1]" in bench.workload_string(a, 1) and a.dtype == "f32"
+    a = bench.parse(["--backbone", "hrnet_48", "--batch", "256", "--dtype", "bf16"])
+    assert bench.config_tag(a) == 2 and "bf16" in bench.workload_string(a, 2)
+    a = bench.parse(["--train"])
+    assert bench.config_tag(a) == 3 and a.batch == 512
+    a = bench.parse(["--config", "4"])
+    assert (a.backbone, a.height, a.width, a.dtype, a.batch) == ("cpn", 384, 288, "bf16", 128)
+    a = bench.parse(["--batch", "32"])
+    assert bench.config_tag(a) is None and bench.workload_string(a, None).startswith("custom")

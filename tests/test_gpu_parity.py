@@ -119,11 +119,18 @@ def test_bf16_backbone_path_tracks_the_fp32_oracle(backbone, B, H, W):
         ref = taps["features"][l]
         rel = (f - ref).norm().item() / ref.norm().item()
         print(f"{backbone} feat{l}: relative L2 error {rel:.3e}")
-        assert rel < 3e-2
+        assert rel < BF16_MAP_REL[backbone]
     err = (got - want).abs().max().item()
     mpj = (got - want).norm(dim=-1).mean().item()
     print(f"{backbone} bf16: max|joint delta| {err:.3e}, mean joint distance {mpj:.3e}")
-    assert err < 8e-2 and mpj < 3e-2
+    assert err < BF16_JOINT_MAX[backbone] and mpj < BF16_JOINT_MEAN[backbone]
+
+
+# bounds = 2x what this build measures on the MI355X for these seeds (printed by the test); bf16 operands with fp32
+# accumulation through ~300 conv layers against the fp32 oracle
+BF16_MAP_REL = {"hrnet_32": 1.6e-2, "hrnet_48": 1.6e-2, "cpn": 0.8e-2}
+BF16_JOINT_MAX = {"hrnet_32": 1.4e-2, "hrnet_48": 1.4e-2, "cpn": 0.4e-2}
+BF16_JOINT_MEAN = {"hrnet_32": 5e-3, "hrnet_48": 5e-3, "cpn": 1.5e-3}
 
 
 def test_mpi_variant_matches_reference_golden():

@@ -132,3 +132,28 @@ def test_golden_recipe_regenerates_committed_fixtures():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(": OK") >= len(CASES) + 4
+
+
+def test_oracle_droppath_training_step_matches_reference():
+    """Training mode with DropPath ON: the multipliers the reference drew (recorded by make_goldens.py in the C ABI's
+    drop_masks layout) injected into the oracle's keep= path reproduce the reference's prediction, loss and gradients
+    (pose_dformer.py:71,76-79,101,137-138)."""
+    from capf import synth
+    name = "w32_256x256_b2"
+    case, g = CASES[name], load_golden(name)
+    _, sd = make_model(case["backbone"], wseed=case["wseed"], bn=case["bn"])
+    img, k2d, kc = case_inputs(case)
+    _, _, _, gt = synth.synth_inputs(case["B"], case["H"], case["W"], seed=case["iseed"], crop_range=case["crop"], with_gt=True)
+    keys = [k[len("dp_grad:"):] for k in g.files if k.startswith("dp_grad:")]
+    P = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    masks = torch.from_numpy(g["dp_masks"])
+    assert masks.numel() == 2 * 4 * (2 + 2 * 17 + 2) and (masks == 0).any()
+    pred = oracle.ca_pf_forward(P, img, k2d, kc, backbone=case["backbone"], drop_masks=masks)
+    loss = oracle.mpjpe(pred, gt)
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().numpy(), g["dp_out"], atol=TOL)
+    assert abs(loss.item() - float(g["dp_train_loss"])) < 1e-6
+    assert abs(float(g["dp_train_loss"]) - float(g["train_loss"])) > 1e-3        # the drop really changed the step
+    for k in keys:
+        want = g["dp_grad:" + k]
+        assert np.abs(P[k].grad.numpy() - want).max() <= 1e-5 * max(1e-6, np.abs(want).max()) + 1e-9, k
