@@ -75,6 +75,11 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
     a.act = op.act;
     a.out_bf16 = op.out_bf16;
+    if (op.ln_w >= 0) {
+        a.ln_g = params[op.ln_w].ptr;
+        a.ln_b = params[op.ln_b].ptr;
+        a.ln_eps = op.eps;
+    }
     return a;
 }
 
@@ -135,6 +140,40 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             a.B = batch; a.J = op.i0; a.L = op.i1; a.NH = op.i2; a.NS = op.i3;
             a.feat_bf16 = op.bf16;
             HIP_TRY(launch_deform_sample(a, s));
+            break;
+        }
+        case OP_EMBED: {
+            EmbedArgs a{};
+            a.kcrop = kcrop; a.k2d = k2d;
+            a.cw = params[op.p0].ptr; a.cb = params[op.p1].ptr; a.pos = params[op.p2].ptr;
+            for (int l = 0; l < op.i1; ++l) {
+                a.feat[l] = ptr(op.in[l]);
+                a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.Cl[l] = op.lvlC[l];
+                a.fw[l] = params[op.pw[l]].ptr; a.fb[l] = params[op.pb[l]].ptr;
+                a.sampled[l] = ptr(op.outs[l]);
+                a.idx[l] = reinterpret_cast<int*>(ptr(op.idxs[l]));
+            }
+            a.X = ptr(op.out);
+            a.BJ = batch * op.i0; a.J = op.i0; a.L = op.i1; a.L1 = op.i2; a.C = op.C;
+            a.feat_bf16 = op.bf16;
+            HIP_TRY(launch_embed(a, s));
+            break;
+        }
+        case OP_CTX_ATTN: {
+            CtxAttnArgs a{};
+            const Pack& pk = packs[op.pack];
+            for (int l = 0; l < op.i1; ++l) {
+                a.feat[l] = ptr(op.in[l]);
+                a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.Cl[l] = op.lvlC[l];
+                a.Wp[l] = params[op.pw[l]].ptr; a.bp[l] = params[op.pb[l]].ptr;
+            }
+            a.Wao = pack_arena + pk.w_off; a.bao = pack_arena + pk.b_off; a.ldw = pk.Kpad;
+            a.ln_g = params[op.p0].ptr; a.ln_b = params[op.p1].ptr; a.eps = op.eps;
+            a.ref = kcrop;
+            a.X = ptr(op.out);
+            a.BJ = batch * op.i0; a.J = op.i0; a.L = op.i1; a.L1 = op.i1 + 1; a.C = op.C; a.NH = op.i2; a.NS = op.i3;
+            a.feat_bf16 = op.bf16;
+            HIP_TRY(launch_ctx_attn(a, s));
             break;
         }
         case OP_ATTENTION:
@@ -638,7 +677,7 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0) return CAPF_ERR_INVALID;
     const capf::Op& op = h->e.ops[index];
     static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
-                               "layernorm", "deform_sample", "attention", "head", "", ""};
+                               "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn"};
     if (name) *name = op.name.c_str();
     if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
                                                                               : capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)));
@@ -692,6 +731,15 @@ int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes) {
             break;
         case capf::OP_PREP_EMBED:
             b = B * op.i0 * (op.C + 4.0) * 4.0;
+            break;
+        case capf::OP_EMBED:
+            b = B * op.i0 * (op.i2 * op.C + 4.0) * 4.0;                          // tokens written
+            for (int l = 0; l < op.i1; ++l) b += B * op.i0 * op.lvlC[l] * 4.0 * act + (double)op.C * op.lvlC[l] * 4.0;
+            break;
+        case capf::OP_CTX_ATTN:
+            for (int l = 0; l < op.i1; ++l)
+                b += B * op.i0 * op.i2 * op.i3 * op.lvlC[l] * 4.0 * act + (double)(op.C / op.i2) * op.lvlC[l] * 4.0;
+            b += B * op.i0 * (op.i1 + 1 + op.i1) * op.C * 4.0;                    // tokens read, tokens 1..L written
             break;
         default: break;
     }

@@ -55,7 +55,7 @@ struct Pack {
 
 enum OpKind {
     OP_GEMM = 0, OP_FUSE, OP_MAXPOOL, OP_RESIZE, OP_PREP_EMBED, OP_SAMPLE_REF, OP_LAYERNORM, OP_DEFORM,
-    OP_ATTENTION, OP_HEAD, OP_FORK, OP_JOIN
+    OP_ATTENTION, OP_HEAD, OP_FORK, OP_JOIN, OP_EMBED, OP_CTX_ATTN
 };
 
 struct Op {
@@ -81,6 +81,9 @@ struct Op {
     int i0 = 0, i1 = 0, i2 = 0, i3 = 0;      // small ints (meaning depends on kind)
     int lvlH[4] = {0, 0, 0, 0}, lvlW[4] = {0, 0, 0, 0}, lvlC[4] = {0, 0, 0, 0};
     int outs[4] = {-1, -1, -1, -1};
+    int idxs[4] = {-1, -1, -1, -1};          // OP_EMBED: corner-index tap buffers
+    int pw[4] = {-1, -1, -1, -1}, pb[4] = {-1, -1, -1, -1};   // per-level linear parameters (OP_EMBED feat_embed, OP_CTX_ATTN embed_proj)
+    int ln_w = -1, ln_b = -1;                // OP_GEMM rows mode: LayerNorm the A rows on the fly (parameter indices), eps in `eps`
     double flops_per_frame = 0.0;
     int bf16 = 0;                 // tensors of this op are bf16 (conv: bf16 MFMA kernel)
     int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
@@ -153,6 +156,7 @@ struct Engine {
     size_t ws_bytes = 0;
     bool packed = false;
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
+    bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)
     int lanes = 2;                 // fork/join regions: 0 in program order, 1 on side streams, 2 as grouped launches (capf_set_lanes)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> events;

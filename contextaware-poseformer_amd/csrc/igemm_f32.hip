@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int BK = 32;      // K chunk (floats) = 128 B per tile row
+static constexpr int LNK = 1280;   // largest K of a LayerNorm'ed-A launch (gamma, beta: 2 * LNK floats of LDS behind the ring)
 
 enum { AMODE_ROWS = 0, AMODE_CONV = 1 };
 
@@ -78,7 +79,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // igemm_tile computes ONE output tile (logical tile id `bid`, split-K slice `ky`) with the calling block;
 // `lds` is the block's ring (S stages).  It is the body of both the one-problem kernel and the grouped kernel.
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist on the device side only
-template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL>
+// LNA (rows mode): the A operand is LayerNorm'ed on the fly — out = act(LN(A) . W^T + bias (+ res)) with
+// LN(x) = (x - mean) * rstd * gamma + beta over the K columns of a row (pose_dformer.py:77-78: the norm1 -> qkv and
+// norm2 -> fc1 pairs).  Row statistics are computed by the block for its own BM rows before the pipeline starts
+// (two passes over rows that are about to be streamed anyway), gamma / beta sit in LDS behind the ring, and the
+// normalisation is applied to the A fragments between the LDS read and the MFMA: 12 VALU instructions per
+// fragment, no normalised copy of the activations in HBM and no LayerNorm launch.
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL, bool LNA = false>
 __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, const int ky, float* __restrict__ lds,
                                            const int dbg_block) {
     constexpr int NT = 64 * NW;
@@ -247,6 +254,60 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     const int fsw = (frow >> KEYSH) & 7;      // swizzle key of this lane's fragment row (tile offsets are multiples of 32)
     const int fhalf = lane >> 5;              // which 4-wide k half of an 8-wide step this lane feeds
 
+    // ---- LNA prologue: gamma / beta -> LDS, mean / rstd of the tile's rows -> LDS -> registers
+    float* const ln_g = lds + S * STAGE;           // [LNK]
+    float* const ln_b = ln_g + LNK;                // [LNK]
+    float mu_f[TM], rs_f[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { mu_f[i] = 0.f; rs_f[i] = 1.f; }
+    if (LNA) {
+        float* const st_mu = ln_b + LNK;           // [BM]
+        float* const st_rs = st_mu + BM;           // [BM]
+        for (int k = tid * 4; k < p.K; k += NT * 4) {
+            *reinterpret_cast<f32x4*>(ln_g + k) = *reinterpret_cast<const f32x4*>(p.ln_g + k);
+            *reinterpret_cast<f32x4*>(ln_b + k) = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+        }
+        constexpr int TPR = NT / BM >= 1 ? NT / BM : 1;          // threads per row (adjacent lanes)
+        constexpr int RPP = BM / (NT / TPR);                      // row passes (1 unless BM > NT)
+#pragma unroll
+        for (int rp = 0; rp < RPP; ++rp) {
+            const int r = rp * (NT / TPR) + tid / TPR, part = tid % TPR;
+            const int m = m0 + r;
+            const bool ok = m < p.M;
+            const float* x = p.A + (ok ? rowmap(p.amap, m) : 0);
+            float sum = 0.f;
+            if (ok)
+                for (int k = part * 4; k < p.K; k += TPR * 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + k);
+                    sum += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float mean = sum / (float)p.K;
+            float sq = 0.f;
+            if (ok)
+                for (int k = part * 4; k < p.K; k += TPR * 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + k);
+                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            if (part == 0) {
+                st_mu[r] = ok ? mean : 0.f;
+                st_rs[r] = ok ? 1.0f / sqrtf(sq / (float)p.K + p.ln_eps) : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            mu_f[i] = st_mu[wm0 + i * 32 + frow];
+            rs_f[i] = st_rs[wm0 + i * 32 + frow];
+        }
+    }
+    f32x4 gq[2], bq[2];                            // gamma / beta quads of the fragments in af[0], af[1]
+    gq[0] = gq[1] = bq[0] = bq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     // Pipeline.  Chunks c+1 .. c+S-2 are in flight at the top of iteration c; chunk c+S-1 is fired into
     // the stage that iteration c-1 read, AFTER the barrier that closed iteration c-1 (every wave of the
     // block has then finished reading it), between the MFMAs of the first two k-steps.
@@ -279,6 +340,10 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     wait_vmcnt<(S - 2) * NLOAD>();
     __builtin_amdgcn_s_barrier();
     read_frags(0, 0, 0);
+    if (LNA) {
+        gq[0] = *reinterpret_cast<const f32x4*>(ln_g + c_begin * BK + fhalf * 4);
+        bq[0] = *reinterpret_cast<const f32x4*>(ln_b + c_begin * BK + fhalf * 4);
+    }
     if (ABL == 7) dbg_t1 = __builtin_amdgcn_s_memtime();
     for (int c = c_begin; c < c_end; ++c) {
         const int st_next = (st_read + 1 == S) ? 0 : st_read + 1;
@@ -300,14 +365,19 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
             const float* rBs = rAs + BM * BK;
             const int rq = ((rd_step * 2) + fhalf) ^ fsw;
             constexpr int NM = 4 * TM * TN;                                   // MFMAs of a step
-            const int n_mem = (TM + TN) + (step < 2 ? PER_STEP : 0);
+            constexpr int NLN = LNA ? 2 : 0;                                  // gamma / beta quads of the next fragments
+            const int n_mem = (TM + TN + NLN) + (step < 2 ? PER_STEP : 0);
+            const int ln_k = ((step < 3 ? c : c + 1) * BK) + (rd_step * 2 + fhalf) * 4;   // k of the fragments being read
             auto mem_op = [&](int k) {
                 if (k < TM) {
                     if (!NO_LDS) af[rd_buf][k] = *reinterpret_cast<const f32x4*>(&rAs[(wm0 + k * 32 + frow) * BK + rq * 4]);
                 } else if (k < TM + TN) {
                     if (!NO_LDS) bf[rd_buf][k - TM] = *reinterpret_cast<const f32x4*>(&rBs[(wn0 + (k - TM) * 32 + frow) * BK + rq * 4]);
+                } else if (k < TM + TN + NLN) {
+                    if (k == TM + TN) gq[rd_buf] = *reinterpret_cast<const f32x4*>(ln_g + ln_k);
+                    else bq[rd_buf] = *reinterpret_cast<const f32x4*>(ln_b + ln_k);
                 } else {
-                    const int idx = step * PER_STEP + (k - TM - TN);
+                    const int idx = step * PER_STEP + (k - TM - TN - NLN);
                     if (idx < NLOAD && !NO_DMA) fire(idx, st_fill);
                 }
             };
@@ -317,6 +387,12 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
             // (more time for the DMA to land); the next chunk's first fragments are read in the slots after it.
             constexpr int BSLOT = NM / 2;
             const int fb = step & 1;
+            if (LNA) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[fb][i][e] = ((af[fb][i][e] - mu_f[i]) * rs_f[i]) * gq[fb][e] + bq[fb][e];
+            }
             int issued = 0, slot = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -336,7 +412,7 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                         // k-step), then the DMA loads; the last slot takes whatever is left
                         bool took = false;                     // one per slot (the last slot takes the rest)
 #pragma unroll
-                        for (int k = 0; k < TM + TN + PER_STEP; ++k)
+                        for (int k = 0; k < TM + TN + NLN + PER_STEP; ++k)
                             if (k == issued && k < n_mem && ((!took && (step < 3 || slot >= BSLOT)) || slot == NM)) {
                                 mem_op(k);
                                 ++issued;
@@ -345,7 +421,7 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-            for (int k = 0; k < TM + TN + PER_STEP; ++k)      // (never more memory ops than slots x their share; safety)
+            for (int k = 0; k < TM + TN + NLN + PER_STEP; ++k)      // (never more memory ops than slots x their share; safety)
                 if (k >= issued && k < n_mem) mem_op(k);
         }
         st_read = st_next;
@@ -457,12 +533,12 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL = 0>
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL = 0, bool LNA = false>
 __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float lds[S * (BM + BN) * BK];
-    igemm_tile<NW, BM, BN, WM, WN, S, AMODE, GELU, PLAIN, ABL>(p, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, lds,
-                                                                blockIdx.x);
+    __shared__ __attribute__((aligned(16))) float lds[S * (BM + BN) * BK + (LNA ? 2 * LNK + 2 * BM : 0)];
+    igemm_tile<NW, BM, BN, WM, WN, S, AMODE, GELU, PLAIN, ABL, LNA>(p, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, lds,
+                                                                     blockIdx.x);
 #endif
 }
 
@@ -717,6 +793,13 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
         else
 #endif
         hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true>), grid, block, 0, s, a);
+    } else if (a.ln_g) {
+        // LayerNorm'ed A operand: plain output, K columns == the normalised width, no split-K
+        if (!plain || a.Kpad != a.K || a.K > LNK || (a.K & 3) || a.splits > 1 || !a.ln_b) return hipErrorInvalidValue;
+        if (a.act == ACT_GELU)
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_ROWS, true, true, 0, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_ROWS, false, true, 0, true>), grid, block, 0, s, a);
     } else if (a.act == ACT_GELU) {
         if (!plain) return hipErrorInvalidValue;
         hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_ROWS, true, true>), grid, block, 0, s, a);

@@ -41,6 +41,9 @@ struct GemmArgs {
     int splits, cps;        // split-K (rows mode): grid.y slices of `cps` chunks, slab s at out + s*split_stride
     long split_stride;
     int out_bf16;           // small-Cin stem kernel only: fp32 image in, bf16 activations out
+    const float* ln_g;      // rows mode: LayerNorm the A rows over their K columns on the fly (gamma, beta [K]); nullptr = off
+    const float* ln_b;
+    float ln_eps;
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
@@ -110,6 +113,36 @@ struct DeformArgs {
     const float* dU[4];      // backward only: gradient w.r.t. U[l]
 };
 hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s);
+// ---- fused front half of the lifter (lifter_fused.hip) -----------------------------------------------------------
+// crop-keypoint normalisation (in place) + coord_embed + reference-point sampling (padding zeros) + feat_embed + pos
+struct EmbedArgs {
+    float* kcrop;                // [BJ, 2] in: crop pixels, out: ref
+    const float* k2d;            // [BJ, 2]
+    const float* cw; const float* cb;       // coord_embed weight [C, 2], bias [C]
+    const float* pos;            // Spatial_pos_embed [1, L1, J, C]
+    const float* feat[4]; int H[4], W[4], Cl[4];
+    const float* fw[4]; const float* fb[4]; // feat_embed[l] weight [C, Cl], bias [C]
+    float* sampled[4];           // optional taps: sampled rows [BJ, Cl]
+    int* idx[4];                 // optional taps: NW corner (x0, y0) per (b, p)
+    float* X;                    // tokens [B, J, L1, C]
+    int BJ, J, L, L1, C;
+    int feat_bf16;
+};
+hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
+// DeformableBlock attention half (LayerNorm + logits / offsets + sampling + embed_proj + residual), see lifter_fused.hip
+struct CtxAttnArgs {
+    const float* feat[4]; int H[4], W[4], Cl[4];
+    const float* Wp[4]; const float* bp[4]; // embed_proj[l] weight [C/NH, Cl], bias [C/NH]
+    const float* Wao; const float* bao;     // [attention_weights | sampling_offsets] rows [3*NH*NS][ldw], bias
+    int ldw;
+    const float* ln_g; const float* ln_b; float eps;
+    const float* ref;            // [BJ, 2]
+    float* X;                    // tokens [B, J, L1, C], updated in place (tokens 1..L)
+    int BJ, J, L, L1, C, NH, NS;
+    int feat_bf16;
+    int woff[4];                 // per-wave LDS section offsets (floats), filled by the launcher
+};
+hipError_t launch_ctx_attn(const CtxAttnArgs& a, hipStream_t s);
 // tiny multi-head attention: QKV [G*N, 3*heads*d] -> O [G*N, heads*d]; N tokens per group
 hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int heads, int d, hipStream_t s);
 // head (pose_dformer.py:240): out[r, 0..2] = Linear(LN(X[r,:]))

@@ -7,6 +7,7 @@
 // and registers every state_dict entry under the reference's name, so that
 // released checkpoints load strict=True into the host module built from this schema.
 #include <limits.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -385,6 +386,8 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
 // ---------------------------------------------------------------------------------------------------
 // lifter (pose_dformer.py)
 // ---------------------------------------------------------------------------------------------------
+static int pidx(Engine& e, const std::string& n) { return e.param_index.at(n); }
+
 struct LinearRef {
     int w, b, N, K;
 };
@@ -402,8 +405,6 @@ static void reg_ln(Engine& e, const std::string& p, int C) {
     e.add_param(p + ".weight", CAPF_P_LN_W, {C});
     e.add_param(p + ".bias", CAPF_P_LN_B, {C});
 }
-
-static int pidx(Engine& e, const std::string& n) { return e.param_index.at(n); }
 
 static int make_linear_pack(Engine& e, const std::vector<std::string>& names) {
     Pack pk;
@@ -426,7 +427,8 @@ static int make_linear_pack(Engine& e, const std::vector<std::string>& names) {
 
 // rows-mode GEMM:  out[omap(m) + n] = act(A[amap(m)] . W[n] + b[n] + res[rmap(m) + n])
 static void gemm_rows(Engine& e, const std::string& name, int pack, int a_buf, RowMap amap, long rows_pf, int out_buf,
-                      RowMap omap, int act, int res_buf, RowMap rmap, int res_param = -1) {
+                      RowMap omap, int act, int res_buf, RowMap rmap, int res_param = -1, const std::string& ln = "",
+                      float ln_eps = 0.f) {
     const Pack& pk = e.packs[pack];
     Op op;
     op.kind = OP_GEMM;
@@ -442,6 +444,11 @@ static void gemm_rows(Engine& e, const std::string& name, int pack, int a_buf, R
     op.aux = res_buf;
     op.rmap = rmap;
     op.res_param = res_param;
+    if (!ln.empty()) {                       // LayerNorm(A rows) folded into the GEMM's fragment path (igemm_f32.hip, LNA)
+        op.ln_w = pidx(e, ln + ".weight");
+        op.ln_b = pidx(e, ln + ".bias");
+        op.eps = ln_eps;
+    }
     op.flops_per_frame = 2.0 * rows_pf * (double)pk.N * pk.K;
     e.use(a_buf);
     e.use(res_buf);
@@ -529,6 +536,38 @@ void Engine::build_lifter(const Tensor feats[4]) {
     keep(*this, X); keep(*this, Q); keep(*this, Hb); keep(*this, QKV); keep(*this, O);
 
     // ---- embedding + reference-point sampling (pose_dformer.py:214-226)
+    // LayerNorm folded into the following GEMM (igemm_f32.hip, LNA) where the normalised width is small: every block
+    // recomputes the statistics of its own rows, which is free at K = 128 (norm + GEMM 22.7 -> 18.3 us at batch 64) and
+    // a loss at K = 640, where 30 column tiles would each re-read 160 KB of rows (29 + 9.5 -> 44 us): the joint
+    // blocks keep their LayerNorm launch
+    auto ln_fold_ok = [&](int dim) { return fused_lifter && dim <= 256; };
+    const bool ln_fold = ln_fold_ok(C);
+    if (fused_lifter) {
+        Op op;
+        op.kind = OP_EMBED;
+        op.name = "embed";
+        op.out = X;
+        op.p0 = pidx(*this, V + ".coord_embed.weight");
+        op.p1 = pidx(*this, V + ".coord_embed.bias");
+        op.p2 = pos;
+        op.i0 = J; op.i1 = L; op.i2 = L1; op.C = C;
+        op.bf16 = bf16() ? 1 : 0;
+        use(X);
+        for (int l = 0; l < L; ++l) {
+            const std::string ls = std::to_string(l);
+            op.in[l] = feats[l].buf;
+            op.lvlH[l] = feats[l].H; op.lvlW[l] = feats[l].W; op.lvlC[l] = Cl[l];
+            use(feats[l].buf);
+            op.pw[l] = pidx(*this, V + ".feat_embed." + ls + ".weight");
+            op.pb[l] = pidx(*this, V + ".feat_embed." + ls + ".bias");
+            op.outs[l] = new_buffer((size_t)J * Cl[l], "sampled" + ls);
+            op.idxs[l] = new_buffer((size_t)J * 2, "idx" + ls);
+            name_tensor(*this, "sampled" + ls, op.outs[l], {-1, J, Cl[l]});
+            name_tensor(*this, "idx" + ls, op.idxs[l], {-1, J, 2}, 1);
+            op.flops_per_frame += 2.0 * J * (double)C * Cl[l];
+        }
+        push(op);
+    } else {
     {
         Op op;
         op.kind = OP_PREP_EMBED;
@@ -562,6 +601,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
         gemm_rows(*this, "feat_embed." + ls, pk, S, row_ld(Cl[l]), J, X, row_ld(D, (long)(1 + l) * C), ACT_NONE, -1,
                   RowMap{J, 0, C, (long)(1 + l) * J * C}, pos);
     }
+    }
 
     // ---- deformable context blocks (pose_dformer.py:115-141), tokens 1..L with token 0 as query bias
     if (cfg.context_blocks) {
@@ -577,9 +617,32 @@ void Engine::build_lifter(const Tensor feats[4]) {
         for (int i = 0; i < L; ++i) {
             const std::string p = V + ".context_blocks." + std::to_string(i);
             const std::string n = "ctx" + std::to_string(i);
-            layernorm(*this, n + ".norm1", p + ".norm1", 1e-5f, X, tok, X, tok0, Q, (long)J * L, C);
             const int pk_ao = make_linear_pack(*this, {p + ".attention_weights", p + ".sampling_offsets"});
             ctx_ao_pack.push_back(pk_ao);
+            if (fused_lifter) {
+                Op op;
+                op.kind = OP_CTX_ATTN;
+                op.name = n + ".attn";
+                op.pack = pk_ao;
+                op.out = X;
+                use(X);
+                op.p0 = pidx(*this, p + ".norm1.weight");
+                op.p1 = pidx(*this, p + ".norm1.bias");
+                op.eps = 1e-5f;
+                for (int l = 0; l < L; ++l) {
+                    op.in[l] = feats[l].buf;
+                    op.lvlH[l] = feats[l].H; op.lvlW[l] = feats[l].W; op.lvlC[l] = Cl[l];
+                    use(feats[l].buf);
+                    op.pw[l] = pidx(*this, p + ".embed_proj." + std::to_string(l) + ".weight");
+                    op.pb[l] = pidx(*this, p + ".embed_proj." + std::to_string(l) + ".bias");
+                    op.flops_per_frame += 2.0 * J * NH * (double)HD * Cl[l];
+                }
+                op.flops_per_frame += 2.0 * J * L * (double)C * 3 * NH * NS;
+                op.i0 = J; op.i1 = L; op.i2 = NH; op.i3 = NS; op.C = C;
+                op.bf16 = bf16() ? 1 : 0;
+                push(op);
+            } else {
+            layernorm(*this, n + ".norm1", p + ".norm1", 1e-5f, X, tok, X, tok0, Q, (long)J * L, C);
             gemm_rows(*this, n + ".attn_off", pk_ao, Q, row_ld(C), (long)J * L, AO, row_ld(3 * NH * NS), ACT_NONE, -1,
                       row_ld(0));
             {
@@ -605,9 +668,15 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 gemm_rows(*this, n + ".embed_proj." + std::to_string(l), pk, U[l], row_ld(Cl[l]), (long)J * NH, X, dst,
                           ACT_NONE, X, dst);
             }
-            layernorm(*this, n + ".norm2", p + ".norm2", 1e-5f, X, tok, -1, row_ld(0), Q, (long)J * L, C);
-            gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(C), (long)J * L, Hb,
-                      row_ld(2 * C), ACT_GELU, -1, row_ld(0));
+            }
+            if (ln_fold) {
+                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), X, tok, (long)J * L, Hb,
+                          row_ld(2 * C), ACT_GELU, -1, row_ld(0), -1, p + ".norm2", 1e-5f);
+            } else {
+                layernorm(*this, n + ".norm2", p + ".norm2", 1e-5f, X, tok, -1, row_ld(0), Q, (long)J * L, C);
+                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(C), (long)J * L, Hb,
+                          row_ld(2 * C), ACT_GELU, -1, row_ld(0));
+            }
             gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}), Hb, row_ld(2 * C), (long)J * L, X, tok,
                       ACT_NONE, X, tok);
         }
@@ -617,12 +686,18 @@ void Engine::build_lifter(const Tensor feats[4]) {
     // ---- Block x L over the L1 level-tokens of each joint, then over the J joint tokens (:231-238)
     auto attn_blocks = [&](const std::string& group, const std::string& tag, int dim, long rows_pf, int tokens,
                            int groups_pf) {
+        const bool ln_fold = ln_fold_ok(dim);
         for (int i = 0; i < L; ++i) {
             const std::string p = V + "." + group + "." + std::to_string(i);
             const std::string n = tag + std::to_string(i);
-            layernorm(*this, n + ".norm1", p + ".norm1", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
-            gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}), Q, row_ld(dim), rows_pf, QKV,
-                      row_ld(3 * dim), ACT_NONE, -1, row_ld(0));
+            if (ln_fold) {
+                gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}), X, row_ld(dim), rows_pf, QKV,
+                          row_ld(3 * dim), ACT_NONE, -1, row_ld(0), -1, p + ".norm1", 1e-6f);
+            } else {
+                layernorm(*this, n + ".norm1", p + ".norm1", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
+                gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}), Q, row_ld(dim), rows_pf, QKV,
+                          row_ld(3 * dim), ACT_NONE, -1, row_ld(0));
+            }
             {
                 Op op;
                 op.kind = OP_ATTENTION;
@@ -636,9 +711,14 @@ void Engine::build_lifter(const Tensor feats[4]) {
             }
             gemm_rows(*this, n + ".proj", make_linear_pack(*this, {p + ".attn.proj"}), O, row_ld(dim), rows_pf, X,
                       row_ld(dim), ACT_NONE, X, row_ld(dim));
-            layernorm(*this, n + ".norm2", p + ".norm2", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
-            gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(dim), rows_pf, Hb,
-                      row_ld(2 * dim), ACT_GELU, -1, row_ld(0));
+            if (ln_fold) {
+                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), X, row_ld(dim), rows_pf, Hb,
+                          row_ld(2 * dim), ACT_GELU, -1, row_ld(0), -1, p + ".norm2", 1e-6f);
+            } else {
+                layernorm(*this, n + ".norm2", p + ".norm2", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
+                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(dim), rows_pf, Hb,
+                          row_ld(2 * dim), ACT_GELU, -1, row_ld(0));
+            }
             gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}), Hb, row_ld(2 * dim), rows_pf, X,
                       row_ld(dim), ACT_NONE, X, row_ld(dim));
         }
@@ -754,6 +834,7 @@ bool Engine::build() {
         err = "unsupported lifter configuration (levels must be 4, 4x4 deformable sampling, embed_dim_ratio % 32 == 0)";
         return false;
     }
+    if (const char* fz = getenv("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;      // A/B runs only
     Tensor img{EXT_IMAGES, cfg.height, cfg.width, 3};
     Tensor feats[4];
     if (cfg.backbone == CAPF_HRNET) {
