@@ -15,7 +15,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
-    "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes",
+    "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16",
 ]
 
 
@@ -96,6 +96,7 @@ def load_library():
     lib.capf_fliptest_fuse.argtypes = [P, P, c_int, P]
     lib.capf_op_pack_conv_bf16.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 8
+    lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
     lib.capf_pose_errors.argtypes = [P, P, P, c_int, c_int, P, P]
     lib.capf_segment_sums.argtypes = [P, P, P, P, c_int, c_int, P, P]
     lib.capf_keypoints_loss.argtypes = [P, c_int, P, P, P, c_int, c_int, c_float, P, P]
@@ -433,6 +434,19 @@ def linear(x, w, bias=None, act=0, residual=None):
     rc = lib.capf_op_linear(_stream(x), _p(x), _p(w), _p(bias), _p(residual), _p(y), M, N, K, act)
     if rc:
         raise CapfError(f"capf_op_linear failed ({rc})")
+    return y
+
+
+def linear_bf16(x, w, bias=None, residual=None, gelu=False):
+    """x bf16 [M,K], w bf16 [N,K] -> fp32 [M,N] (+ fp32 residual), or with gelu=True -> bf16 GELU(x w^T + b)."""
+    import torch
+    lib = load_library()
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.bfloat16 if gelu else torch.float32)
+    rc = lib.capf_op_linear_bf16(_stream(x), _p(x.contiguous()), _p(w.contiguous()), _p(bias), _p(residual), _p(y), M, N, K, 1 if gelu else 0)
+    if rc:
+        raise CapfError(f"capf_op_linear_bf16 failed ({rc})")
     return y
 
 

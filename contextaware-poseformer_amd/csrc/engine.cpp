@@ -39,6 +39,16 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
                                      params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks,
                                      pk.Kpad, s));
+        } else if (pk.bf16) {            // linear weights as bf16 [N][Kpad] (a 1x1 "conv" without BatchNorm), bias fp32
+            int n0 = 0;
+            for (int i = 0; i < pk.n_lin; ++i) {
+                const int n = (int)params[pk.w[i]].shape[0];
+                unsigned short* Wb = reinterpret_cast<unsigned short*>(W) + (size_t)n0 * pk.Kpad;
+                HIP_TRY(launch_pack_conv_bf16(params[pk.w[i]].ptr, nullptr, nullptr, nullptr, nullptr, 0.f, Wb, nullptr, n, pk.K, 1,
+                                              pk.Kpad, s));
+                HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+                n0 += n;
+            }
         } else {
             int n0 = 0;
             for (int i = 0; i < pk.n_lin; ++i) {
@@ -91,7 +101,10 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
     };
     switch (op.kind) {
         case OP_GEMM: {
-            if (op.bf16) HIP_TRY(launch_gemm_bf16(gemm_args(op, batch), s));
+            if (op.bf16 == 2) {
+                const GemmArgs a = gemm_args(op, batch);
+                HIP_TRY(launch_gemm_bf16_rows(a.A, a.Wp, a.bias, a.M, a.N, a.K, a.Kpad, a.out, a.omap, a.res, a.rmap, op.out_bf16, s));
+            } else if (op.bf16) HIP_TRY(launch_gemm_bf16(gemm_args(op, batch), s));
             else HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
             break;
         }
@@ -126,7 +139,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
         case OP_LAYERNORM:
             HIP_TRY(launch_layernorm(ptr(op.in[0]), op.amap, ptr(op.aux), op.rmap, params[op.p0].ptr,
                                      params[op.p1].ptr, op.eps, ptr(op.out), (int)(op.rows_per_frame * batch),
-                                     op.C, s));
+                                     op.C, s, op.out_bf16));
             break;
         case OP_DEFORM: {
             DeformArgs a{};
@@ -177,7 +190,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             break;
         }
         case OP_ATTENTION:
-            HIP_TRY(launch_attention(ptr(op.in[0]), ptr(op.out), op.i0 * batch, op.i1, op.i2, op.i3, s));
+            HIP_TRY(launch_attention(ptr(op.in[0]), ptr(op.out), op.i0 * batch, op.i1, op.i2, op.i3, s, op.out_bf16));
             break;
         case OP_HEAD:
             HIP_TRY(launch_head(ptr(op.in[0]), params[op.p0].ptr, params[op.p1].ptr, op.eps, params[op.p2].ptr,
@@ -623,6 +636,14 @@ int capf_op_conv_bf16(void* stream, const void* x, const void* wp, const float* 
     return capf::launch_gemm_bf16(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
 }
 
+int capf_op_linear_bf16(void* stream, const void* x_bf16, const void* w_bf16, const float* bias, const float* residual, void* y,
+                        int M, int N, int K, int gelu_bf16_out) {
+    if (!x_bf16 || !w_bf16 || !y || K % 64 != 0) return CAPF_ERR_INVALID;
+    return capf::launch_gemm_bf16_rows(x_bf16, w_bf16, bias, M, N, K, K, static_cast<float*>(y), capf::row_ld(N), residual,
+                                       capf::row_ld(N), gelu_bf16_out, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
+}
+
 int capf_preprocess(void* stream, const uint8_t* images_bgr, int batch, int height, int width, const float mean[3],
                     const float* std3, int mode, float* images_out, const float* gt_in, float* gt_out, const float* k2d_in,
                     float* k2d_out, const float* kcrop_in, float* kcrop_out) {
@@ -679,7 +700,8 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
                                "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn"};
     if (name) *name = op.name.c_str();
-    if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
+    if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 == 2 ? capf::gemm_bf16_rows_kernel_name((int)(op.rows_per_frame * batch), op.N)
+                                                                      : op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
                                                                               : capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)));
     if (flops) *flops = op.flops_per_frame * batch;
     return CAPF_OK;
@@ -697,6 +719,11 @@ int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes) {
             const capf::Pack& pk = e.packs[op.pack];
             const double M = (double)op.rows_per_frame * B;
             const double in_elems = op.conv ? B * op.H * op.W * op.Cin : M * op.K;
+            if (op.bf16 == 2) {          // lifter projection: bf16 operands, fp32 (or, after GELU, bf16) result
+                b = in_elems * 2.0 + (double)pk.N * pk.K * 2.0 + (double)pk.N * 4.0 + M * op.N * (op.out_bf16 ? 2.0 : 4.0) +
+                    (op.aux >= 0 ? M * op.N * 4.0 : 0.0);
+                break;
+            }
             b = in_elems * (op.conv && !op.bf16 ? 4.0 : act)                    // fp32 stem reads the fp32 image
                 + (double)pk.N * pk.K * (pk.bf16 ? 2.0 : 4.0) + (double)pk.N * 4.0
                 + M * op.N * (op.out_bf16 ? 2.0 : act)

@@ -44,11 +44,20 @@ __device__ __forceinline__ void wait_vmcnt_b() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// 4 waves per block, block tile BM x BN, wave tile WM x WN, S LDS stages.  Conv mode only (the lifter's
-// GEMMs stay fp32: its LayerNorm / softmax / residual stream is kept in fp32).
+// 4 waves per block, block tile BM x BN, wave tile WM x WN, S LDS stages.
+// OUTF32 / GELU select the epilogue of the lifter's projections (pose_dformer.py:15-59, run as 1x1 "convolutions" over an
+// [M, 1] image of K channels): bf16 operands and fp32 accumulation like the convs, but the residual stream stays fp32 —
+//   OUTF32: out / res are fp32, addressed through the (G, S1, S2) row maps (qkv, proj + residual, fc2 + residual);
+//   GELU:   exact-erf GELU before the bf16 store (fc1, whose output is only ever the bf16 operand of fc2).
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist on the device side only
 // one output tile (logical id `bid`) with the calling block; body of the single and the grouped kernel
-template <int BM, int BN, int WM, int WN, int S>
+__device__ __forceinline__ long rowmap_b(const RowMap& r, int m) {
+    if (r.G == 1) return (long)m * r.S1 + r.off;
+    const int q = m / r.G;
+    return (long)q * r.S1 + (long)(m - q * r.G) * r.S2 + r.off;
+}
+
+template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false>
 __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid, unsigned short* __restrict__ lds) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -244,7 +253,6 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
     long o_row[TM];
     bool m_ok[TM];
     f32x4 bv[TN][4];
-    u16x4 rv[TM][TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -253,6 +261,38 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
             bv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias && (full || n < p.N)) bv[j][g] = *reinterpret_cast<const f32x4*>(p.bias + n);
         }
+    if (OUTF32) {
+        f32x4 rf[TM][TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 32 + (lane & 31);
+            m_ok[i] = full || m < p.M;
+            o_row[i] = m_ok[i] ? rowmap_b(p.omap, m) : 0;
+            const long r_row = (p.res && m_ok[i]) ? rowmap_b(p.rmap, m) : 0;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                    rf[i][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.res && m_ok[i] && (full || n < p.N)) rf[i][j][g] = *reinterpret_cast<const f32x4*>(p.res + r_row + n);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + bv[j][g][e]) + rf[i][j][g][e];
+                    if (m_ok[i] && (full || n < p.N)) *reinterpret_cast<f32x4*>(p.out + o_row[i] + n) = v;
+                }
+        return;
+    }
+    u16x4 rv[TM][TN][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + (lane & 31);
@@ -279,6 +319,7 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][4 * g + e] + bv[j][g][e] + bf2f(rv[i][j][g][e]);
+                    if (GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
                     if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
                     v[e] = f2bf(t);
                 }
@@ -292,11 +333,11 @@ __device__ __forceinline__ int xcd_remap_b(int b, int nblk) {   // see igemm_f32
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int S>
+template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) unsigned short lds[S * (BM + BN) * BKH];
-    igemm_bf16_tile<BM, BN, WM, WN, S>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
+    igemm_bf16_tile<BM, BN, WM, WN, S, OUTF32, GELU>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
 #endif
 }
 
@@ -416,6 +457,35 @@ hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     if (a.N <= 64) return ((long)a.M >= 128L * 512) ? launch_cfg_b<128, 64, 64, 32, 3>(a, s) : launch_cfg_b<64, 64, 32, 32, 3>(a, s);
     if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return launch_cfg_b<128, 128, 64, 64, 2>(a, s);
     return launch_cfg_b<64, 64, 32, 32, 3>(a, s);
+}
+
+// The lifter's projections on the bf16 MFMA path: out[omap(m) + n] = f(A[m, :K] . W[n, :K] + bias[n]) with A bf16 [M][K]
+// contiguous and W bf16 [N][Kpad].  mode 0: fp32 out (+ fp32 residual through rmap); mode 1: GELU, bf16 out [M][N].
+template <int BM, int BN, int WM, int WN, int S>
+static hipError_t launch_rows_b(const GemmArgs& a, int mode, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    if (mode == 0) hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, S, true, false>), dim3(nbm * nbn), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, S, false, true>), dim3(nbm * nbn), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+static bool rows_b_big(int M, int N) { return (long)((M + 127) / 128) * ((N + 127) / 128) >= 384; }
+
+const char* gemm_bf16_rows_kernel_name(int M, int N) { return rows_b_big(M, N) ? "igemm_bf16<w4,128x128,rows>" : "igemm_bf16<w4,64x64,rows>"; }
+
+hipError_t launch_gemm_bf16_rows(const void* A_bf16, const void* W_bf16, const float* bias, int M, int N, int K, int Kpad,
+                                 float* out, RowMap omap, const float* res, RowMap rmap, int gelu_bf16_out, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (Kpad % BKH != 0 || K % 8 != 0 || N % 4 != 0 || (double)M * K * 2.0 >= 2.0e9) return hipErrorInvalidValue;
+    if (gelu_bf16_out && (res || omap.G != 1)) return hipErrorInvalidValue;
+    GemmArgs a{};
+    a.A = static_cast<const float*>(A_bf16); a.Wp = static_cast<const float*>(W_bf16); a.bias = bias; a.res = res; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.Kpad = Kpad;
+    a.conv = 1; a.Cin = K; a.H = M; a.W = 1; a.Ho = M; a.Wo = 1; a.ks = 1; a.stride = 1; a.pad = 0;
+    a.omap = omap; a.rmap = rmap; a.act = ACT_NONE;
+    prep_conv_b(a);
+    if (rows_b_big(M, N)) return launch_rows_b<128, 128, 64, 64, 2>(a, gelu_bf16_out, s);
+    return launch_rows_b<64, 64, 32, 32, 3>(a, gelu_bf16_out, s);
 }
 
 }  // namespace capf

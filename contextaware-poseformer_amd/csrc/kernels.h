@@ -69,6 +69,11 @@ bool gemm_bf16_groupable(const GemmArgs& a);
 hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s);   // bf16 twin of launch_gemm_f32_group
 const char* gemm_bf16_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);
+// lifter projections on the bf16 MFMA path (igemm_bf16.hip): A bf16 [M][K], W bf16 [N][Kpad]; gelu_bf16_out = 0: fp32 out
+// (+ fp32 residual) through the row maps; 1: GELU then bf16 out [M][N]
+hipError_t launch_gemm_bf16_rows(const void* A_bf16, const void* W_bf16, const float* bias, int M, int N, int K, int Kpad,
+                                 float* out, RowMap omap, const float* res, RowMap rmap, int gelu_bf16_out, hipStream_t s);
+const char* gemm_bf16_rows_kernel_name(int M, int N);
 
 // out = relu( sum_i up_{s_i}(in_i) ), NHWC, s_i = nearest-upsample factor (1 = same resolution)
 struct FuseSumArgs {
@@ -97,7 +102,7 @@ hipError_t launch_sample_ref(const float* feat, const float* ref, float* S, int*
                              int W, int C, hipStream_t s, int feat_bf16 = 0);
 // LayerNorm over rows: out[r,:] = LN(in[imap(r)] (+ add[amap(r)]))   width C
 hipError_t launch_layernorm(const float* in, RowMap imap, const float* add, RowMap amap, const float* g,
-                            const float* b, float eps, float* out, int rows, int C, hipStream_t s);
+                            const float* b, float eps, float* out, int rows, int C, hipStream_t s, int out_bf16 = 0);
 // deformable sampling (pose_dformer.py:122-135 minus the embed_proj GEMM):
 //   AO [rows=(b,p,l), NH*NS + 2*NH*NS] = [attention logits | offset pre-activations]
 //   U_l[(b,p,h), :] = sum_s softmax_s(logit[h,s]) * bilinear_border(feat_l, tanh(off[h,s]) + ref[b,p])
@@ -144,7 +149,7 @@ struct CtxAttnArgs {
 };
 hipError_t launch_ctx_attn(const CtxAttnArgs& a, hipStream_t s);
 // tiny multi-head attention: QKV [G*N, 3*heads*d] -> O [G*N, heads*d]; N tokens per group
-hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int heads, int d, hipStream_t s);
+hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int heads, int d, hipStream_t s, int out_bf16 = 0);
 // head (pose_dformer.py:240): out[r, 0..2] = Linear(LN(X[r,:]))
 hipError_t launch_head(const float* X, const float* g, const float* b, float eps, const float* w,
                        const float* wb, float* out, int rows, int C, int NO, hipStream_t s);

@@ -124,7 +124,13 @@ hipError_t launch_sample_ref(const float* feat, const float* ref, float* S, int*
 }
 
 // ---- LayerNorm, one wave per row (two-pass, like ATen's CPU kernel) -------------------------------
-template <int MAXV>
+__device__ __forceinline__ unsigned short f2bf_l(float f) {     // round-to-nearest-even, like every bf16 store of the path
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+// OB: the normalised rows are written as bf16 (the A operand of a bf16 MFMA projection, compute_dtype = bf16)
+template <int MAXV, bool OB = false>
 __global__ void layernorm_kernel(const float* __restrict__ in, RowMap imap, const float* __restrict__ add,
                                  RowMap amap, const float* __restrict__ g, const float* __restrict__ b,
                                  float eps, float* __restrict__ out, int rows, int C) {
@@ -158,13 +164,28 @@ __global__ void layernorm_kernel(const float* __restrict__ in, RowMap imap, cons
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) out[(long)r * C + c] = (v[i] - mean) * rstd * g[c] + b[c];
+        if (c < C) {
+            const float y = (v[i] - mean) * rstd * g[c] + b[c];
+            if (OB) reinterpret_cast<unsigned short*>(out)[(long)r * C + c] = f2bf_l(y);
+            else out[(long)r * C + c] = y;
+        }
     }
 }
 
 hipError_t launch_layernorm(const float* in, RowMap imap, const float* add, RowMap amap, const float* g,
-                            const float* b, float eps, float* out, int rows, int C, hipStream_t s) {
+                            const float* b, float eps, float* out, int rows, int C, hipStream_t s, int out_bf16) {
     dim3 grid((rows + 3) / 4), block(256);
+    if (out_bf16) {
+        if (C <= 128)
+            hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, in, imap, add, amap, g, b, eps, out, rows, C);
+        else if (C <= 640)
+            hipLaunchKernelGGL((layernorm_kernel<10, true>), grid, block, 0, s, in, imap, add, amap, g, b, eps, out, rows, C);
+        else if (C <= 1536)
+            hipLaunchKernelGGL((layernorm_kernel<24, true>), grid, block, 0, s, in, imap, add, amap, g, b, eps, out, rows, C);
+        else
+            return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (C <= 128)
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, in, imap, add, amap, g, b, eps, out, rows, C);
     else if (C <= 640)
@@ -238,9 +259,20 @@ hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// store 4 consecutive attention outputs as fp32 or (OB) bf16
+template <bool OB>
+__device__ __forceinline__ void st4(float* out, long idx, f32x4 v) {
+    if (!OB) { *reinterpret_cast<f32x4*>(out + idx) = v; return; }
+    unsigned short* o = reinterpret_cast<unsigned short*>(out) + idx;
+    uint2 pk;
+    pk.x = (unsigned)f2bf_l(v[0]) | ((unsigned)f2bf_l(v[1]) << 16);
+    pk.y = (unsigned)f2bf_l(v[2]) | ((unsigned)f2bf_l(v[3]) << 16);
+    *reinterpret_cast<uint2*>(o) = pk;
+}
+
 // ---- tiny attention (Attention.forward pose_dformer.py:46-59): 5 or 17 tokens per group -----------
 // qkv row layout [3][heads][d] (the reshape at :49).  One thread per (group, head, query).
-template <int NMAX>
+template <int NMAX, bool OB = false>
 __global__ void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int groups, int N,
                                  int heads, int d, float scale) {
     const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -277,7 +309,7 @@ __global__ void attention_kernel(const float* __restrict__ qkv, float* __restric
         den += sc[j];
     }
     const float inv = 1.0f / den;
-    float* o = out + (g * N + i) * (long)(heads * d) + h * d;
+    const long o = (g * N + i) * (long)(heads * d) + h * d;
     for (int c = 0; c < d; c += 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -287,7 +319,7 @@ __global__ void attention_kernel(const float* __restrict__ qkv, float* __restric
                 acc += va * (sc[j] * inv);
             }
         }
-        *reinterpret_cast<f32x4*>(o + c) = acc;
+        st4<OB>(out, o + c, acc);
     }
 }
 
@@ -295,7 +327,7 @@ __global__ void attention_kernel(const float* __restrict__ qkv, float* __restric
 // q.k dot products are combined with two shuffles, every lane then accumulates its own slice of P.V).
 // 4x the threads of the kernel above for the 17-token joint attention, where B*8*17 threads cannot fill
 // 256 CUs.
-template <int NMAX, int PARTS>
+template <int NMAX, int PARTS, bool OB = false>
 __global__ void attention_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int groups, int N,
                                        int heads, int d, float scale) {
     const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -338,7 +370,7 @@ __global__ void attention_split_kernel(const float* __restrict__ qkv, float* __r
     }
     const float inv = 1.0f / den;
     if (!live) return;
-    float* o = out + (g * N + i) * (long)(heads * d) + h * d + c0;
+    const long o = (g * N + i) * (long)(heads * d) + h * d + c0;
     for (int c = 0; c < dp; c += 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -348,14 +380,14 @@ __global__ void attention_split_kernel(const float* __restrict__ qkv, float* __r
                 acc += va * (sc[j] * inv);
             }
         }
-        *reinterpret_cast<f32x4*>(o + c) = acc;
+        st4<OB>(out, o + c, acc);
     }
 }
 
 // The 17-token joint attention (B * 8 (group, head) pairs of 17 x 80 floats): one wave per pair, q / k / v
 // staged in LDS with coalesced reads, 17 x 17 scores, one softmax row per lane, P.V with d-contiguous stores.
 // (The per-query kernels above read k / v rows straight from global memory: 36 us per block at B = 64.)
-template <int NMAX>
+template <int NMAX, bool OB = false>
 __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
                                                            int heads, int d, float scale) {
     extern __shared__ float sm[];
@@ -395,41 +427,49 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
         for (int j = 0; j < N; ++j) p[j] *= inv;
     }
     __syncthreads();
-    float* ob = out + (g * N) * (long)(heads * d) + h * d;
+    const long ob = (g * N) * (long)(heads * d) + h * d;
     for (int idx = lane; idx < nd; idx += blockDim.x) {
         const int t = idx / d, c = idx - t * d;
         float acc = 0.f;
         for (int j = 0; j < N; ++j) acc += P[t * (NMAX + 1) + j] * v[j * ld + c];
-        ob[(long)t * (heads * d) + c] = acc;
+        if (OB) reinterpret_cast<unsigned short*>(out)[ob + (long)t * (heads * d) + c] = f2bf_l(acc);
+        else out[ob + (long)t * (heads * d) + c] = acc;
     }
 }
 
-hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int heads, int d, hipStream_t s) {
+hipError_t launch_attention(const float* qkv, float* out, int groups, int N, int heads, int d, hipStream_t s, int out_bf16) {
     if (d % 4 != 0) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)d);
     if (N > 5 && N <= 17 && (size_t)(3 * 17 * (d + 1) + 17 * 18) * sizeof(float) <= 64 * 1024 && (long)groups * heads <= 0x7fffffffL) {
         const size_t lds = (size_t)(3 * 17 * (d + 1) + 17 * 18) * sizeof(float);
-        hipLaunchKernelGGL(attention_lds_kernel<17>, dim3((unsigned)((long)groups * heads)), dim3(256), lds, s, qkv, out, N, heads, d,
-                           scale);
+        const dim3 grid((unsigned)((long)groups * heads)), block(256);
+        if (out_bf16) hipLaunchKernelGGL((attention_lds_kernel<17, true>), grid, block, lds, s, qkv, out, N, heads, d, scale);
+        else hipLaunchKernelGGL((attention_lds_kernel<17, false>), grid, block, lds, s, qkv, out, N, heads, d, scale);
         return hipGetLastError();
     }
     if (d % 16 == 0 && N <= 17) {
         const long total = (long)groups * heads * N * 4;
         dim3 grid((unsigned)((total + 255) / 256)), block(256);
-        if (N <= 5)
-            hipLaunchKernelGGL((attention_split_kernel<5, 4>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
-        else
-            hipLaunchKernelGGL((attention_split_kernel<17, 4>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+        if (N <= 5) {
+            if (out_bf16) hipLaunchKernelGGL((attention_split_kernel<5, 4, true>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+            else hipLaunchKernelGGL((attention_split_kernel<5, 4, false>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+        } else {
+            if (out_bf16) hipLaunchKernelGGL((attention_split_kernel<17, 4, true>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+            else hipLaunchKernelGGL((attention_split_kernel<17, 4, false>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+        }
         return hipGetLastError();
     }
     const long total = (long)groups * heads * N;
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
-    if (N <= 5)
-        hipLaunchKernelGGL(attention_kernel<5>, grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
-    else if (N <= 17)
-        hipLaunchKernelGGL(attention_kernel<17>, grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
-    else
+    if (N <= 5) {
+        if (out_bf16) hipLaunchKernelGGL((attention_kernel<5, true>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+        else hipLaunchKernelGGL((attention_kernel<5, false>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+    } else if (N <= 17) {
+        if (out_bf16) hipLaunchKernelGGL((attention_kernel<17, true>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+        else hipLaunchKernelGGL((attention_kernel<17, false>), grid, block, 0, s, qkv, out, groups, N, heads, d, scale);
+    } else {
         return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

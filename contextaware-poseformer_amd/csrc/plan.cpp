@@ -406,7 +406,7 @@ static void reg_ln(Engine& e, const std::string& p, int C) {
     e.add_param(p + ".bias", CAPF_P_LN_B, {C});
 }
 
-static int make_linear_pack(Engine& e, const std::vector<std::string>& names) {
+static int make_linear_pack(Engine& e, const std::vector<std::string>& names, bool as_bf16 = false) {
     Pack pk;
     pk.kind = 1;
     pk.n_lin = (int)names.size();
@@ -419,8 +419,9 @@ static int make_linear_pack(Engine& e, const std::vector<std::string>& names) {
     }
     pk.N = N;
     pk.K = K;
-    pk.Kpad = round32(K);
-    pk.direct = (pk.n_lin == 1 && pk.Kpad == K);
+    pk.Kpad = as_bf16 ? round64(K) : round32(K);
+    pk.direct = !as_bf16 && (pk.n_lin == 1 && pk.Kpad == K);
+    pk.bf16 = as_bf16;                         // bf16 copy [N][Kpad] for the bf16 MFMA projections (compute_dtype = bf16)
     e.packs.push_back(pk);
     return (int)e.packs.size() - 1;
 }
@@ -450,6 +451,10 @@ static void gemm_rows(Engine& e, const std::string& name, int pack, int a_buf, R
         op.eps = ln_eps;
     }
     op.flops_per_frame = 2.0 * rows_pf * (double)pk.N * pk.K;
+    if (pk.kind == 1 && pk.bf16) {           // bf16 operands (A buffer holds bf16 rows), fp32 accumulate
+        op.bf16 = 2;
+        op.out_bf16 = act == ACT_GELU ? 1 : 0;   // fc1: GELU, bf16 hidden rows; everything else lands in the fp32 stream
+    }
     e.use(a_buf);
     e.use(res_buf);
     e.use(out_buf);
@@ -457,7 +462,7 @@ static void gemm_rows(Engine& e, const std::string& name, int pack, int a_buf, R
 }
 
 static void layernorm(Engine& e, const std::string& name, const std::string& ln, float eps, int in_buf, RowMap imap,
-                      int add_buf, RowMap amap, int out_buf, long rows_pf, int C) {
+                      int add_buf, RowMap amap, int out_buf, long rows_pf, int C, bool out_bf16 = false) {
     Op op;
     op.kind = OP_LAYERNORM;
     op.name = name;
@@ -471,6 +476,7 @@ static void layernorm(Engine& e, const std::string& name, const std::string& ln,
     op.eps = eps;
     op.rows_per_frame = rows_pf;
     op.C = C;
+    op.out_bf16 = out_bf16 ? 1 : 0;
     e.use(in_buf);
     e.use(add_buf);
     e.use(out_buf);
@@ -540,7 +546,9 @@ void Engine::build_lifter(const Tensor feats[4]) {
     // recomputes the statistics of its own rows, which is free at K = 128 (norm + GEMM 22.7 -> 18.3 us at batch 64) and
     // a loss at K = 640, where 30 column tiles would each re-read 160 KB of rows (29 + 9.5 -> 44 us): the joint
     // blocks keep their LayerNorm launch
-    auto ln_fold_ok = [&](int dim) { return fused_lifter && dim <= 256; };
+    // (compute_dtype = bf16: the projections take bf16 A rows, which the LayerNorm kernel writes directly)
+    const bool lb = bf16();                   // lifter projections (qkv / proj / fc1 / fc2) on the bf16 MFMA path
+    auto ln_fold_ok = [&](int dim) { return fused_lifter && dim <= 256 && !lb; };
     const bool ln_fold = ln_fold_ok(C);
     if (fused_lifter) {
         Op op;
@@ -673,11 +681,11 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), X, tok, (long)J * L, Hb,
                           row_ld(2 * C), ACT_GELU, -1, row_ld(0), -1, p + ".norm2", 1e-5f);
             } else {
-                layernorm(*this, n + ".norm2", p + ".norm2", 1e-5f, X, tok, -1, row_ld(0), Q, (long)J * L, C);
-                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(C), (long)J * L, Hb,
+                layernorm(*this, n + ".norm2", p + ".norm2", 1e-5f, X, tok, -1, row_ld(0), Q, (long)J * L, C, lb);
+                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}, lb), Q, row_ld(C), (long)J * L, Hb,
                           row_ld(2 * C), ACT_GELU, -1, row_ld(0));
             }
-            gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}), Hb, row_ld(2 * C), (long)J * L, X, tok,
+            gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}, lb), Hb, row_ld(2 * C), (long)J * L, X, tok,
                       ACT_NONE, X, tok);
         }
     }
@@ -694,8 +702,8 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}), X, row_ld(dim), rows_pf, QKV,
                           row_ld(3 * dim), ACT_NONE, -1, row_ld(0), -1, p + ".norm1", 1e-6f);
             } else {
-                layernorm(*this, n + ".norm1", p + ".norm1", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
-                gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}), Q, row_ld(dim), rows_pf, QKV,
+                layernorm(*this, n + ".norm1", p + ".norm1", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim, lb);
+                gemm_rows(*this, n + ".qkv", make_linear_pack(*this, {p + ".attn.qkv"}, lb), Q, row_ld(dim), rows_pf, QKV,
                           row_ld(3 * dim), ACT_NONE, -1, row_ld(0));
             }
             {
@@ -706,20 +714,21 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 op.out = O;
                 op.i0 = groups_pf; op.i1 = tokens; op.i2 = cfg.num_heads; op.i3 = dim / cfg.num_heads;
                 op.flops_per_frame = 4.0 * groups_pf * tokens * tokens * dim;
+                op.out_bf16 = lb ? 1 : 0;      // the attention output is only ever the A operand of proj
                 use(QKV); use(O);
                 push(op);
             }
-            gemm_rows(*this, n + ".proj", make_linear_pack(*this, {p + ".attn.proj"}), O, row_ld(dim), rows_pf, X,
+            gemm_rows(*this, n + ".proj", make_linear_pack(*this, {p + ".attn.proj"}, lb), O, row_ld(dim), rows_pf, X,
                       row_ld(dim), ACT_NONE, X, row_ld(dim));
             if (ln_fold) {
                 gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), X, row_ld(dim), rows_pf, Hb,
                           row_ld(2 * dim), ACT_GELU, -1, row_ld(0), -1, p + ".norm2", 1e-6f);
             } else {
-                layernorm(*this, n + ".norm2", p + ".norm2", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim);
-                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), Q, row_ld(dim), rows_pf, Hb,
+                layernorm(*this, n + ".norm2", p + ".norm2", 1e-6f, X, row_ld(dim), -1, row_ld(0), Q, rows_pf, dim, lb);
+                gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}, lb), Q, row_ld(dim), rows_pf, Hb,
                           row_ld(2 * dim), ACT_GELU, -1, row_ld(0));
             }
-            gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}), Hb, row_ld(2 * dim), rows_pf, X,
+            gemm_rows(*this, n + ".fc2", make_linear_pack(*this, {p + ".mlp.fc2"}, lb), Hb, row_ld(2 * dim), rows_pf, X,
                       row_ld(dim), ACT_NONE, X, row_ld(dim));
         }
     };

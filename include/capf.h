@@ -219,6 +219,12 @@ int capf_op_conv_bf16(void* stream, const void* x_nhwc_bf16, const void* w_packe
                       const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout,
                       int ks, int stride, int act);
 
+/* nn.Linear on the bf16 MFMA path (the lifter's qkv / proj / fc1 / fc2 under compute_dtype = CAPF_BF16, pose_dformer.py:15-59):
+ * x bf16 [M,K], w bf16 [N,K] (K % 64 == 0), bias fp32; gelu_bf16_out = 0: y fp32 [M,N] = x w^T + bias (+ fp32 residual);
+ * gelu_bf16_out = 1: y bf16 [M,N] = GELU(x w^T + bias) (exact erf).  fp32 accumulation in both.                        */
+int capf_op_linear_bf16(void* stream, const void* x_bf16, const void* w_bf16, const float* bias, const float* residual, void* y,
+                        int M, int N, int K, int gelu_bf16_out);
+
 /* ---- the steps on either side of the path ---------------------------------
  * capf_preprocess: data_prefetcher.preload (ContextPose/mvn/datasets/utils.py:33-82) as one launch pair:
  *   images_bgr uint8 [B,H,W,3] -> images_out fp32 RGB NHWC ((u/255 - mean) / std; std == NULL: CPN, mean only);

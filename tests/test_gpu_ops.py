@@ -74,6 +74,32 @@ def test_linear_matches_torch(M, N, K, act, res):
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,gelu,res", [(1088, 1920, 640, False, False), (1088, 640, 1280, False, True), (5440, 384, 128, False, False),
+                                            (4352, 256, 128, True, False), (17, 640, 640, False, True), (85, 128, 256, False, True),
+                                            (4352, 1280, 640, True, False), (300, 132, 64, False, False)])
+def test_linear_bf16_matches_torch_on_bf16_rounded_operands(M, N, K, gelu, res):
+    """The lifter's projections on the bf16 MFMA path (compute_dtype = bf16): bf16 operands, fp32 accumulation, fp32 result
+    (+ fp32 residual) or GELU + one bf16 rounding — against fp32 F.linear of the SAME bf16-rounded operands."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    want = F.linear(x.float(), w.float(), b)
+    r = torch.randn(M, N, generator=g) if res else None
+    if res:
+        want = want + r
+    got = capf.linear_bf16(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, gelu=gelu)
+    if gelu:
+        want = F.gelu(want)
+        assert got.dtype == torch.bfloat16
+        tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
+    else:
+        assert got.dtype == torch.float32
+        tol = 3e-5 * max(1.0, want.abs().max().item())
+    assert (got.float().cpu() - want).abs().max().item() <= tol
+
+
 BF16_CASES = [(32, 32, 3, 1, 64, 64, 2, 1, True), (64, 64, 3, 1, 32, 32, 2, 1, False), (48, 48, 3, 1, 24, 20, 1, 1, True),
               (256, 256, 3, 1, 8, 8, 3, 0, True), (64, 256, 1, 1, 16, 12, 2, 1, True), (96, 48, 1, 1, 10, 6, 2, 0, False),
               (32, 64, 3, 2, 16, 12, 3, 1, False), (2048, 256, 1, 1, 4, 3, 1, 1, False), (128, 128, 3, 1, 5, 3, 7, 1, True)]

@@ -95,9 +95,10 @@ def test_batch_independence_and_determinism():
 
 @pytest.mark.parametrize("backbone,B,H,W", [("hrnet_32", 2, 256, 256), ("hrnet_48", 2, 256, 256), ("cpn", 1, 384, 288)])
 def test_bf16_backbone_path_tracks_the_fp32_oracle(backbone, B, H, W):
-    """compute_dtype='bf16' (BASELINE configs[2]/[4]): bf16 MFMA convolutions with bf16 activations, fp32
-    lifter.  bf16 carries 8 bits of mantissa, so after ~100 layers the context maps agree with the fp32 oracle
-    to about 1e-2 relative and the 17x3 joints to a few 1e-2 absolute — reported, and bounded here."""
+    """compute_dtype='bf16' (BASELINE configs[2]/[4]): bf16 MFMA convolutions with bf16 activations, and the lifter's
+    qkv / proj / fc1 / fc2 projections on bf16 operands (fp32 accumulation; LayerNorm, softmax, samplers and the
+    residual stream stay fp32).  bf16 carries 8 bits of mantissa: the context maps agree with the fp32 oracle to
+    < 1e-2 relative and the 17x3 joints to < 1e-2 absolute (metres) — reported, and bounded at 2x the measurement."""
     import copy, contextlib, io
     from capf import synth
     from mvn.models.conpose import CA_PF
@@ -128,9 +129,11 @@ def test_bf16_backbone_path_tracks_the_fp32_oracle(backbone, B, H, W):
 
 # bounds = 2x what this build measures on the MI355X for these seeds (printed by the test); bf16 operands with fp32
 # accumulation through ~300 conv layers against the fp32 oracle
-BF16_MAP_REL = {"hrnet_32": 1.6e-2, "hrnet_48": 1.6e-2, "cpn": 0.8e-2}
-BF16_JOINT_MAX = {"hrnet_32": 1.4e-2, "hrnet_48": 1.4e-2, "cpn": 0.4e-2}
-BF16_JOINT_MEAN = {"hrnet_32": 5e-3, "hrnet_48": 5e-3, "cpn": 1.5e-3}
+# measured (maps rel L2 / joints max / joints mean): hrnet_32 7.8e-3 / 7.4e-3 / 4.2e-3, hrnet_48 7.7e-3 / 8.3e-3 / 4.1e-3,
+# cpn 2.9e-3 / 9.3e-3 / 7.4e-3 (with the lifter's projections on bf16 operands as well)
+BF16_MAP_REL = {"hrnet_32": 1.6e-2, "hrnet_48": 1.6e-2, "cpn": 0.6e-2}
+BF16_JOINT_MAX = {"hrnet_32": 1.5e-2, "hrnet_48": 1.7e-2, "cpn": 1.9e-2}
+BF16_JOINT_MEAN = {"hrnet_32": 8.5e-3, "hrnet_48": 8.5e-3, "cpn": 1.5e-2}
 
 
 def test_mpi_variant_matches_reference_golden():
