@@ -349,7 +349,12 @@ struct GroupArgsB {
     int cfg[MAXG];         // 0: 128x64 (S=2), 1: 64x64 (S=3), 2: 128x32 (S=2)
     int n;
 };
-#define GROUP_LDS_HALVES (2 * (128 + 64) * BKH)   // 48 KiB
+#ifndef CAPF_BF16_GROUP_STAGES
+#define CAPF_BF16_GROUP_STAGES 2
+#endif
+// 48 KiB at 2 stages = 3 blocks per CU.  Measured alternatives (profiles/README.md, round 2): 3 stages / 72 KiB / 2 blocks per CU
+// -6.5 % (HRNet-48 B=256), -2 % (CPN), -8 % (HRNet-32 B=64); 64x64 + 128x32 tiles only in 40 KiB / 4 blocks per CU -9 %, -1 %, 0 %.
+#define GROUP_LDS_HALVES (CAPF_BF16_GROUP_STAGES * (128 + 64) * BKH)
 
 __global__ __launch_bounds__(256) void igemm_bf16_group_kernel(GroupArgsB ga) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -363,9 +368,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_group_kernel(GroupArgsB ga) {
     if (bid >= ga.tiles[pi]) return;
     const GemmArgs& p = ga.g[pi];
     switch (ga.cfg[pi]) {
-        case 0: igemm_bf16_tile<128, 64, 64, 32, 2>(p, bid, lds); break;
-        case 1: igemm_bf16_tile<64, 64, 32, 32, 3>(p, bid, lds); break;
-        default: igemm_bf16_tile<128, 32, 32, 32, 2>(p, bid, lds); break;
+        case 0: igemm_bf16_tile<128, 64, 64, 32, CAPF_BF16_GROUP_STAGES>(p, bid, lds); break;
+        case 1: igemm_bf16_tile<64, 64, 32, 32, CAPF_BF16_GROUP_STAGES + 1>(p, bid, lds); break;
+        default: igemm_bf16_tile<128, 32, 32, 32, CAPF_BF16_GROUP_STAGES>(p, bid, lds); break;
     }
 #endif
 }
