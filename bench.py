@@ -281,7 +281,7 @@ def main():
                 for l, ops_ in members.items():
                     kern = table[l][1]
                     if len(ops_) > 1 and kern.startswith("igemm"):
-                        kern = "igemm_bf16_group" if kern.startswith("igemm_bf16") else "igemm_f32_group"
+                        kern = "igemm_bf16_group" if kern.startswith("igemm_bf16") else ("igemm_wino_group" if kern.startswith("igemm_wino") else "igemm_f32_group")
                     if not kern or table[l][0].startswith("copy."):
                         continue
                     e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0])

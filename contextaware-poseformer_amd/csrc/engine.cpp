@@ -35,6 +35,11 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
         if (pk.kind == 0 && pk.bf16) {
             HIP_TRY(launch_pack_conv_bf16(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks, pk.Kpad, s));
+        } else if (pk.kind == 0 && pk.wino) {
+            HIP_TRY(launch_pack_conv_wino(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
+                                          params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s));
+            HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
+                                     params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w2_off, B, pk.N, pk.Cin, pk.ks, pk.Kpad2, s));
         } else if (pk.kind == 0) {
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
                                      params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks,
@@ -79,6 +84,10 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.out = ptr(op.out);
     a.M = (int)(op.rows_per_frame * batch);
     a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
+    if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
+        a.Wp = pack_arena + pk.w2_off;
+        a.Kpad = pk.Kpad2;
+    }
     a.conv = op.conv;
     a.Cin = op.Cin; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo;
     a.ks = op.ks; a.stride = op.stride; a.pad = op.pad;
@@ -105,6 +114,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
                 const GemmArgs a = gemm_args(op, batch);
                 HIP_TRY(launch_gemm_bf16_rows(a.A, a.Wp, a.bias, a.M, a.N, a.K, a.Kpad, a.out, a.omap, a.res, a.rmap, op.out_bf16, s));
             } else if (op.bf16) HIP_TRY(launch_gemm_bf16(gemm_args(op, batch), s));
+            else if (wino_now(op, batch)) HIP_TRY(launch_gemm_wino(gemm_args(op, batch), s));
             else HIP_TRY(launch_gemm_f32(gemm_args(op, batch), s));
             break;
         }
@@ -208,10 +218,13 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
 // events (profiling): log gets (event index, leader op) pairs and member ops point at their leader.
 int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log) {
     auto groupable = [&](const Op& op, const GemmArgs& a) {
-        return op.kind == OP_GEMM && (op.bf16 ? gemm_bf16_groupable(a) : gemm_f32_groupable(a));
+        if (op.kind != OP_GEMM) return false;
+        if (op.bf16) return gemm_bf16_groupable(a);
+        if (wino_now(op, batch)) return gemm_wino_ok(a);
+        return gemm_f32_groupable(a);
     };
     for (const std::vector<int>& level : region_levels[region]) {
-        for (int pass = 0; pass < 2; ++pass) {           // pass 0: fp32 convs, pass 1: bf16 convs
+        for (int pass = 0; pass < 3; ++pass) {           // pass 0: direct fp32 convs, 1: bf16 convs, 2: Winograd fp32 convs
             GemmArgs group[MAXG];
             int members[MAXG];
             int n = 0;
@@ -219,13 +232,16 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
                 if (n == 0) return CAPF_OK;
                 if (log) HIP_TRY(log->mark(s, members, n));
                 if (pass == 0) HIP_TRY(launch_gemm_f32_group(group, n, s));
-                else HIP_TRY(launch_gemm_bf16_group(group, n, s));
+                else if (pass == 1) HIP_TRY(launch_gemm_bf16_group(group, n, s));
+                else HIP_TRY(launch_gemm_wino_group(group, n, s));
                 n = 0;
                 return CAPF_OK;
             };
             for (int oi : level) {
                 const Op& op = ops[oi];
-                if (op.kind != OP_GEMM || (op.bf16 != 0) != (pass == 1)) continue;
+                if (op.kind != OP_GEMM) continue;
+                const int kind = op.bf16 ? 1 : (wino_now(op, batch) ? 2 : 0);
+                if (kind != pass) continue;
                 const GemmArgs a = gemm_args(op, batch);
                 if (!groupable(op, a)) continue;
                 group[n] = a;
@@ -584,6 +600,40 @@ int capf_op_conv(void* stream, const float* x, const float* wp, const float* bia
     return capf::launch_gemm_f32(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_op_pack_conv_wino(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, float* wp, float* bias, int Cout, int Cin) {
+    return capf::launch_pack_conv_wino(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
+}
+
+static bool wino_desc(capf::GemmArgs& a, const float* x, const float* wp, const float* bias, const float* residual, float* y, int B,
+                      int H, int W, int Cin, int Cout, int act) {
+    a = capf::GemmArgs{};
+    a.A = x; a.Wp = wp; a.bias = bias; a.res = residual; a.out = y;
+    a.Ho = H; a.Wo = W; a.M = B * H * W; a.N = Cout; a.K = 9 * Cin; a.Kpad = 12 * Cin;
+    a.conv = 1; a.Cin = Cin; a.H = H; a.W = W; a.ks = 3; a.stride = 1; a.pad = 1;
+    a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
+    a.act = act;
+    return capf::gemm_wino_ok(a);
+}
+
+int capf_op_conv_wino(void* stream, const float* x, const float* wp, const float* bias, const float* residual, float* y, int B,
+                      int H, int W, int Cin, int Cout, int act) {
+    capf::GemmArgs a;
+    if (!wino_desc(a, x, wp, bias, residual, y, B, H, W, Cin, Cout, act)) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_gemm_wino(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_wino_group(void* stream, int n, const capf_conv_desc* d) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i)
+        if (d[i].ks != 3 || d[i].stride != 1 ||
+            !wino_desc(g[i], d[i].x, d[i].w_packed, d[i].bias, d[i].residual, d[i].y, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].Cout, d[i].act))
+            return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_gemm_wino_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_op_conv_group(void* stream, int n, const capf_conv_desc* d) {
     if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
     capf::GemmArgs g[capf::MAXG];
@@ -702,6 +752,7 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     if (name) *name = op.name.c_str();
     if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 == 2 ? capf::gemm_bf16_rows_kernel_name((int)(op.rows_per_frame * batch), op.N)
                                                                       : op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
+                                                                      : h->e.wino_now(op, batch) ? capf::gemm_wino_kernel_name()
                                                                               : capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)));
     if (flops) *flops = op.flops_per_frame * batch;
     return CAPF_OK;

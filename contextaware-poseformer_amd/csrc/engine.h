@@ -49,8 +49,11 @@ struct Pack {
     int bn_g = -1, bn_b = -1, bn_m = -1, bn_v = -1;
     int N = 0, K = 0, Kpad = 0, Cin = 0, ks = 1;
     size_t w_off = 0, b_off = 0;   // element offsets inside the pack arena
+    size_t w2_off = 0;             // wino packs: the direct-kernel layout [N][Kpad2] as well (small batches run the direct kernel)
+    int Kpad2 = 0;
     bool direct = false;           // linear with Kpad == K and no concat: use the parameter in place
     bool bf16 = false;             // conv weights packed as bf16 (Kpad % 64 == 0)
+    bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
 };
 
 enum OpKind {
@@ -86,6 +89,7 @@ struct Op {
     int ln_w = -1, ln_b = -1;                // OP_GEMM rows mode: LayerNorm the A rows on the fly (parameter indices), eps in `eps`
     double flops_per_frame = 0.0;
     int bf16 = 0;                 // tensors of this op are bf16 (conv: bf16 MFMA kernel)
+    int wino = 0;                 // 3x3 stride-1 fp32 conv on the Winograd kernel (igemm_wino.hip)
     int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
     int region = -1;              // index of the enclosing fork/join region, -1 outside
@@ -156,6 +160,9 @@ struct Engine {
     size_t ws_bytes = 0;
     bool packed = false;
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
+    int wino_min_batch = 8;        // below this batch the Winograd-eligible convs run the direct kernel (B = 1: 305 vs 286 frames/s)
+    bool wino_now(const Op& op, int batch) const { return op.wino && batch >= wino_min_batch; }
+    bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)
     bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)
     int lanes = 2;                 // fork/join regions: 0 in program order, 1 on side streams, 2 as grouped launches (capf_set_lanes)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};

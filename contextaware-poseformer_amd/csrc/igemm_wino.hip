@@ -1,0 +1,774 @@
+// fp32 3x3 / stride-1 convolution with the Winograd F(2,3) transform applied ALONG W, fused into one MFMA kernel
+// (v_mfma_f32_32x32x2_f32).  Covers the BasicBlock / Bottleneck 3x3 convs of HRNet and CPN (pose_hrnet.py:66-136,
+// networks/resnet.py:58-93): 77 % of the path's FLOPs.
+//
+//   direct:   y[h, w, n]  = sum_{kh, kw, c} x[h + kh - 1, w + kw - 1, c] * g[n, c, kh, kw]               9 MACs per (c, n, pixel)
+//   F(2,3):   a "tile" t is the output pair (w = 2 wt, 2 wt + 1) of a row; with d_j = x[h + kh - 1, 2 wt - 1 + j, c], j = 0..3,
+//             v_0 = d_0 - d_2,  v_1 = d_1 + d_2,  v_2 = d_2 - d_1,  v_3 = d_1 - d_3                    (input transform  B^T d)
+//             u_0 = g_0,  u_1 = (g_0 + g_1 + g_2) / 2,  u_2 = (g_0 - g_1 + g_2) / 2,  u_3 = g_2        (weights, packed   G g)
+//             m_p = sum_{kh, c} v_p * u_p          (FOUR independent GEMMs over K = 3 C, M = tiles)      12 MACs per (c, n, pair) = 6 per pixel
+//             y_0 = m_0 + m_1 + m_2,   y_1 = m_1 - m_2 - m_3                                           (output transform A^T m)
+//   i.e. 1.5x fewer MFMAs than the implicit GEMM of igemm_f32.hip for the same result (to fp32 roundoff: the transform
+//   coefficients are 0, +-1, 1/2).  The 2-D F(2x2,3x3) variant would need 16 accumulator sets per output tile (a whole
+//   AGPR file for one 32x32 MFMA tile) and 2.7x the LDS per staged chunk; the 1-D form needs 4 and reuses the direct
+//   kernel's operand path unchanged:
+//     * the raw pixels d_0..d_3 are the im2col of a "3 x 4 kernel, stride (1, 2)" convolution, so they are staged by the
+//       same `buffer_load_dwordx4 ... lds` loader (block-uniform descriptor, per-row tap mask, hardware zero fill for
+//       padding) as four consecutive 32-channel sub-chunks j = 0..3 of one (kh, channel chunk) SUPERCHUNK; the packed
+//       weights u_0..u_3 are laid out in the same (kh, chunk, p, c) order, so the W loader is the direct kernel's too;
+//     * the input transform happens between the LDS read and the MFMA: 4 ds_read_b128 of raw pixels + 16 v_add/v_sub give
+//       the four A fragments of an 8-deep k-step (4 x 4 MFMAs); the output transform is 6 adds per element in the epilogue;
+//     * one barrier per superchunk (64 MFMAs per wave) instead of one per 32-deep chunk (32): the superchunk's 16 DMA
+//       instructions per thread are spread over the 4096 MFMA cycles of the previous one.
+// Block = 4 waves, 64 tiles (128 output pixels) x 64 channels, wave tile 32 tiles x 32 channels x 4 positions (64
+// accumulator registers); LDS = 2 superstages x 4 sub-stages x (64 + 64) rows x 128 B = 128 KiB (one block per CU).
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace capf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+static constexpr int WBK = 32;                 // channels per sub-chunk (128 B rows)
+static constexpr int WBT = 64, WBN = 64;       // block tile: 64 tiles x 64 output channels
+static constexpr int WSUB = (WBT + WBN) * WBK; // floats per sub-stage
+static constexpr int WLDS = 2 * 4 * WSUB;      // 2 superstages x 4 sub-stages
+
+#ifdef CAPF_DIAG   // (diagnosis build) per-block stamps: {t_entry, t_prologue_done, t_loop_done, t_exit, realtime_entry, hw_id, xcc_id, realtime_exit}
+__device__ unsigned long long capf_wino_timeline[8192 * 8];
+#define WINO_STAMP(var) var = __builtin_amdgcn_s_memtime()
+#else
+#define WINO_STAMP(var)
+#endif
+
+__device__ __forceinline__ int fast_div_w(int n, FastDiv d) {
+    return (int)((__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// One output tile (logical id `bid`) of problem p.  p.M = number of tiles (B * H * W / 2), p.Ho = H, p.Wo = W / 2 (tile grid),
+// p.Kpad = 12 * Cin, p.fd_hw / p.fd_wo divide by H * (W/2) and W/2.
+// PP = false: two superstages (128 KiB), the next superchunk's DMA instructions ride in the MFMA slots of the current one.
+// PP = true ("ping-pong"): ONE superstage (64 KiB, two blocks per CU).  A block alternates a compute phase (64 MFMAs per wave,
+//   fragments + transforms of the next k-step in the slots) with a load phase (16 DMA instructions per thread, wait, barrier)
+//   and relies on the co-resident block — naturally out of phase, on the same SIMDs — to use the matrix pipe meanwhile; the
+//   partner also covers the ~10 us a tile spends outside its K loop (first-load wait, residual loads, output stores), which
+//   with one block per CU were fully exposed: 2048 tiles of the 64x64 layer-1 conv took 166 us for 82 us of MFMA time.
+template <bool PP>
+__device__ __forceinline__ void wino_tile(const GemmArgs& p, const int bid, float* __restrict__ lds) {
+#ifdef CAPF_DIAG
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+    const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    WINO_STAMP(dbg_t0);
+    constexpr int NT = 256;
+    constexpr int RPR = NT / 8;                          // 32 tile rows per DMA round
+    constexpr int RA = WBT / RPR, RB = WBN / RPR;        // 2 + 2 DMA instructions per thread per sub-chunk
+    constexpr int NSUBLOAD = RA + RB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nbn = (p.N + WBN - 1) / WBN;
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * WBT, n0 = tile_n * WBN;      // m0: first tile row
+
+    const int srow = tid >> 3;
+    const int kq = (((tid & 7) ^ ((srow >> 1) & 7))) * 4; // source-side XOR swizzle (see igemm_f32.hip)
+
+    const int CC = p.Cin / WBK;                          // channel chunks
+    const int nsc = 3 * CC;                              // superchunks
+
+    constexpr unsigned OOB_A = 0x80000000u;
+    long a_base;
+    {
+        const int b = fast_div_w(m0, p.fd_hw), rem = m0 - b * p.Ho * p.Wo;
+        const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+        a_base = ((long)b * p.H * p.W + (long)(h - 1) * p.W + (2 * wt - 1)) * p.Cin;
+    }
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a_base), 0, 0x7FFFFF00u, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wp + (long)n0 * p.Kpad), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)p.Kpad * 4u, 0x00020000);
+    unsigned a_rel[RA], a_mask[RA];                      // mask bit kh * 4 + j: raw pixel j of input row kh is inside the image
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int t = m0 + srow + RPR * i;
+        a_rel[i] = 0;
+        a_mask[i] = 0u;
+        if (t < p.M) {
+            const int b = fast_div_w(t, p.fd_hw), rem = t - b * p.Ho * p.Wo;
+            const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+            const int h0 = h - 1, w0 = 2 * wt - 1;
+            const long off = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            a_rel[i] = (unsigned)(off - a_base + kq) * 4u;
+            const int j_lo = max(0, -w0), j_hi = min(4, p.W - w0);
+            const int kh_lo = max(0, -h0), kh_hi = min(3, p.H - h0);
+            if (j_hi > j_lo && kh_hi > kh_lo) {
+                const unsigned wbits = ((1u << j_hi) - 1) & ~((1u << j_lo) - 1);
+                const unsigned below_hi = (1u << (kh_hi * 4)) - 1, below_lo = (1u << (kh_lo * 4)) - 1;
+                a_mask[i] = (wbits * 0x111u) & below_hi & ~below_lo;
+            }
+        }
+    }
+    unsigned w_off[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) w_off[i] = (unsigned)((srow + RPR * i) * p.Kpad + kq) * 4u;
+
+    // walk of the sub-chunk being prepared: (kh, channel chunk, j), j fastest
+    int u_kh = 0, u_cc = 0, u_j = 0;
+    unsigned voff[NSUBLOAD];
+    unsigned soff_a = 0;
+    auto prepare = [&]() {
+        const unsigned bit = u_kh < 3 ? (1u << (u_kh * 4 + u_j)) : 0u;
+        soff_a = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * p.W + u_j) * p.Cin + u_cc * WBK) * 4u);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] : OOB_A;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            voff[RA + i] = w_off[i];
+            w_off[i] += WBK * 4u;
+        }
+        if (++u_j == 4) {
+            u_j = 0;
+            if (++u_cc == CC) { u_cc = 0; ++u_kh; }
+        }
+    };
+    // fire load #idx of the prepared sub-chunk into sub-stage `sub` (0..7)
+    auto fire = [&](int idx, int sub) {
+        float* As = lds + sub * WSUB;
+        if (idx < RA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(As + (idx * RPR + wave * 8) * WBK), 16, voff[idx], soff_a, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(As + WBT * WBK + ((idx - RA) * RPR + wave * 8) * WBK), 16,
+                                                     voff[idx], 0, 0, 0);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * 32;          // tile rows of this wave inside the block tile
+    const int wn0 = (wave & 1) * 32;           // channels of this wave
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    const int fhalf = lane >> 5;
+
+    // prologue: superchunk 0 -> superstage 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        prepare();
+#pragma unroll
+        for (int i = 0; i < NSUBLOAD; ++i) fire(i, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // K loop.  Per 8-deep k-step a wave issues 16 MFMAs (slot i = 4 e + p: position p, k sub-step e) and, between them, the
+    // step's other work, ONE piece per 64-cycle MFMA slot so that nothing but an LDS-DMA instruction (60-100 cycles of
+    // issue, tools/dma_rate.hip) ever overflows its slot:
+    //   slots 0-3    the next k-step's fragments, two ds_read_b128 each: (d2, d1) (d0, d3) (u0, u1) (u2, u3)
+    //   slots 4-14   even: one DMA instruction of the NEXT superchunk (16 per superchunk: 6 + 6 + 4 over steps 0-2, each
+    //                sub-chunk's offsets prepared just before its first load); odd 7, 9, 11, 13: the input transform of the
+    //                next fragments, 4 VALU each, in the order their operands were read (v1, v2, v0, v3)
+    //   step 3       no loads before slot 8; there: vmcnt(0) + lgkmcnt(0) + s_barrier (the next superchunk has landed, every
+    //                wave has issued its last read of this one); slots 8-11 read the next superchunk's first fragments,
+    //                slots 12-15 transform them.  The second half of step 3 runs from registers only.
+    f32x4 dn[4];                               // raw pixels of the next k-step
+    f32x4 v[2][4], uf[2][4];                   // transformed activations / weights of the current and next k-step
+    const float* const a_ptr = lds + (wm0 + frow) * WBK;
+    const float* const b_ptr = lds + WBT * WBK + (wn0 + frow) * WBK;
+    auto rd_a = [&](int ss, int q, int j) { dn[j] = *reinterpret_cast<const f32x4*>(a_ptr + (ss * 4 + j) * WSUB + q * 4); };
+    auto rd_b = [&](int ss, int q, int j, int buf) { uf[buf][j] = *reinterpret_cast<const f32x4*>(b_ptr + (ss * 4 + j) * WSUB + q * 4); };
+    auto xform = [&](int pq, int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (pq == 0) v[buf][0][e] = dn[0][e] - dn[2][e];
+            else if (pq == 1) v[buf][1][e] = dn[1][e] + dn[2][e];
+            else if (pq == 2) v[buf][2][e] = dn[2][e] - dn[1][e];
+            else v[buf][3][e] = dn[1][e] - dn[3][e];
+        }
+    };
+    {
+        const int q0 = fhalf ^ fsw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rd_a(0, q0, j); rd_b(0, q0, j, 0); }
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) xform(pq, 0);
+    }
+    WINO_STAMP(dbg_t1);
+    // epilogue operands (bias, residual rows of the two output pixels): transposed accumulator -> this lane owns tile row
+    // t = m0 + wm0 + (lane & 31) and, per register group g, four consecutive channels n = 8 g + 4 (lane >> 5) + e
+    const int t = m0 + wm0 + (lane & 31);
+    const bool t_ok = t < p.M;
+    const long o_row = (long)(2 * t) * p.omap.S1 + p.omap.off;          // output pixel 2 t (and 2 t + 1: the next NHWC row)
+    const long r_row = (long)(2 * t) * p.rmap.S1 + p.rmap.off;
+    f32x4 bv[4], r0[4], r1[4];
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
+            bv[g] = r0[g] = r1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {
+                if (p.bias) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.res && t_ok) {
+                    r0[g] = *reinterpret_cast<const f32x4*>(p.res + r_row + n);
+                    r1[g] = *reinterpret_cast<const f32x4*>(p.res + r_row + p.rmap.S1 + n);
+                }
+            }
+        }
+    };
+    if (PP) {
+        for (int sc = 0; sc < nsc; ++sc) {
+            // the last compute phase has no load phase behind it: its 64 MFMAs hide the latency of the residual rows
+            if (sc == nsc - 1) load_epilogue_operands();
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                const int fb = step & 1, nb = fb ^ 1;
+                const int q_next = ((step + 1) * 2 + fhalf) ^ fsw;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int pq = i & 3, e = i >> 2;
+                    acc[pq] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[fb][pq][e], v[fb][pq][e], acc[pq], 0, 0, 0);
+                    if (step < 3) {
+                        if (i == 0) { rd_a(0, q_next, 2); rd_a(0, q_next, 1); }
+                        else if (i == 1) { rd_a(0, q_next, 0); rd_a(0, q_next, 3); }
+                        else if (i == 2) { rd_b(0, q_next, 0, nb); rd_b(0, q_next, 1, nb); }
+                        else if (i == 3) { rd_b(0, q_next, 2, nb); rd_b(0, q_next, 3, nb); }
+                        else if (i == 6) xform(1, nb);
+                        else if (i == 8) xform(2, nb);
+                        else if (i == 10) xform(0, nb);
+                        else if (i == 12) xform(3, nb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (sc + 1 < nsc) {
+                // load phase: every wave has issued its last read of the superstage -> overwrite it with the next superchunk
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    prepare();
+#pragma unroll
+                    for (int i = 0; i < NSUBLOAD; ++i) fire(i, j);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int q0 = fhalf ^ fsw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rd_a(0, q0, j); rd_b(0, q0, j, 0); }
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) xform(pq, 0);
+            }
+        }
+    } else
+    for (int sc = 0; sc < nsc; ++sc) {
+        const int ss = sc & 1, sn = ss ^ 1;
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int fb = step & 1, nb = fb ^ 1;
+            const int rs = step < 3 ? ss : sn;                                 // superstage the next fragments come from
+            const int q_next = (((step + 1) & 3) * 2 + fhalf) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pq = i & 3, e = i >> 2;
+                acc[pq] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[fb][pq][e], v[fb][pq][e], acc[pq], 0, 0, 0);
+                if (step == 3 && i == 7) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                const int ri = step < 3 ? i : i - 8;                           // read / transform slots shift behind the barrier in step 3
+                if (ri == 0) { rd_a(rs, q_next, 2); rd_a(rs, q_next, 1); }
+                else if (ri == 1) { rd_a(rs, q_next, 0); rd_a(rs, q_next, 3); }
+                else if (ri == 2) { rd_b(rs, q_next, 0, nb); rd_b(rs, q_next, 1, nb); }
+                else if (ri == 3) { rd_b(rs, q_next, 2, nb); rd_b(rs, q_next, 3, nb); }
+                if (step < 3) {
+                    if (i >= 4 && (i & 1) == 0) {                              // DMA slots 4, 6, ..., 14
+                        const int k = step * 6 + (i - 4) / 2;                  // DMA instruction 0..15 of the next superchunk
+                        if (k < 16) {
+                            if ((k & 3) == 0) prepare();
+                            fire(k & 3, sn * 4 + (k >> 2));
+                        }
+                    }
+                    if (i == 7) xform(1, nb);
+                    else if (i == 9) xform(2, nb);
+                    else if (i == 11) xform(0, nb);
+                    else if (i == 13) xform(3, nb);
+                } else {
+                    if (i == 12) xform(1, nb);
+                    else if (i == 13) xform(2, nb);
+                    else if (i == 14) xform(0, nb);
+                    else if (i == 15) xform(3, nb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WINO_STAMP(dbg_t2);
+
+    // ---- epilogue: output transform + bias (+ residual) (+ ReLU)
+    if (!PP) load_epilogue_operands();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = acc[0][4 * g + e], a1 = acc[1][4 * g + e], a2 = acc[2][4 * g + e], a3 = acc[3][4 * g + e];
+            float s0 = ((a0 + a1) + a2) + bv[g][e] + r0[g][e];
+            float s1 = ((a1 - a2) - a3) + bv[g][e] + r1[g][e];
+            if (p.act == ACT_RELU) { s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f); }
+            y0[e] = s0; y1[e] = s1;
+        }
+        if (t_ok && n < p.N) {
+            *reinterpret_cast<f32x4*>(p.out + o_row + n) = y0;
+            *reinterpret_cast<f32x4*>(p.out + o_row + p.omap.S1 + n) = y1;
+        }
+    }
+#ifdef CAPF_DIAG
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = capf_wino_timeline + (size_t)blockIdx.x * 8;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = dbg_r0; d[5] = hw; d[6] = xcc; d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Half-size block tiles for the shapes the 64 x 64 tile does not fit: HBT x HBN = 64 tiles x 32 channels (the 32-channel
+// high-resolution branch: a 64-wide tile would multiply zeros in half of its MFMAs) or 32 tiles x 64 channels (the 8 x 8
+// branch: twice the blocks, so that every CU gets its ping-pong pair at batch 64).  The four waves are 2 sub-tiles (32 tiles x
+// 32 channels each, split along M or N) x 2 POSITION PAIRS: wave (pp, sub) accumulates positions p = 2 pp, 2 pp + 1 — per
+// 8-deep k-step 3 raw-pixel reads (d_pp .. d_pp+2) + 2 weight reads + 8 VALU feed 8 MFMAs — and the two pairs of a sub-tile
+// meet in the epilogue through LDS (each wave finishes two of the four 8-channel register groups).  One superstage
+// (4 x (HBT + HBN) x 128 B = 48 KiB), ping-pong schedule as wino_tile<true>.
+template <int HBT, int HBN>
+__device__ __forceinline__ void wino_tile_h(const GemmArgs& p, const int bid, float* __restrict__ lds) {
+    constexpr int RPR = 32;
+    constexpr int RA = HBT / RPR, RB = HBN / RPR, NSUBLOAD = RA + RB;
+    constexpr int HSUB = (HBT + HBN) * WBK;
+    static_assert((HBT == 64 && HBN == 32) || (HBT == 32 && HBN == 64), "half tiles");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nbn = (p.N + HBN - 1) / HBN;
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * HBT, n0 = tile_n * HBN;
+
+    const int srow = tid >> 3;
+    const int kq = (((tid & 7) ^ ((srow >> 1) & 7))) * 4;
+    const int CC = p.Cin / WBK;
+    const int nsc = 3 * CC;
+
+    constexpr unsigned OOB_A = 0x80000000u;
+    long a_base;
+    {
+        const int b = fast_div_w(m0, p.fd_hw), rem = m0 - b * p.Ho * p.Wo;
+        const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+        a_base = ((long)b * p.H * p.W + (long)(h - 1) * p.W + (2 * wt - 1)) * p.Cin;
+    }
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a_base), 0, 0x7FFFFF00u, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wp + (long)n0 * p.Kpad), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)p.Kpad * 4u, 0x00020000);
+    unsigned a_rel[RA], a_mask[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int t = m0 + srow + RPR * i;
+        a_rel[i] = 0;
+        a_mask[i] = 0u;
+        if (t < p.M) {
+            const int b = fast_div_w(t, p.fd_hw), rem = t - b * p.Ho * p.Wo;
+            const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+            const int h0 = h - 1, w0 = 2 * wt - 1;
+            const long off = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            a_rel[i] = (unsigned)(off - a_base + kq) * 4u;
+            const int j_lo = max(0, -w0), j_hi = min(4, p.W - w0);
+            const int kh_lo = max(0, -h0), kh_hi = min(3, p.H - h0);
+            if (j_hi > j_lo && kh_hi > kh_lo) {
+                const unsigned wbits = ((1u << j_hi) - 1) & ~((1u << j_lo) - 1);
+                const unsigned below_hi = (1u << (kh_hi * 4)) - 1, below_lo = (1u << (kh_lo * 4)) - 1;
+                a_mask[i] = (wbits * 0x111u) & below_hi & ~below_lo;
+            }
+        }
+    }
+    unsigned w_off[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) w_off[i] = (unsigned)((srow + RPR * i) * p.Kpad + kq) * 4u;
+
+    int u_kh = 0, u_cc = 0, u_j = 0;
+    unsigned voff[NSUBLOAD];
+    unsigned soff_a = 0;
+    auto prepare = [&]() {
+        const unsigned bit = u_kh < 3 ? (1u << (u_kh * 4 + u_j)) : 0u;
+        soff_a = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * p.W + u_j) * p.Cin + u_cc * WBK) * 4u);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] : OOB_A;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            voff[RA + i] = w_off[i];
+            w_off[i] += WBK * 4u;
+        }
+        if (++u_j == 4) {
+            u_j = 0;
+            if (++u_cc == CC) { u_cc = 0; ++u_kh; }
+        }
+    };
+    auto fire = [&](int idx, int sub) {
+        float* As = lds + sub * HSUB;
+        if (idx < RA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(As + (idx * RPR + wave * 8) * WBK), 16, voff[idx], soff_a, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(As + HBT * WBK + ((idx - RA) * RPR + wave * 8) * WBK), 16,
+                                                     voff[idx], 0, 0, 0);
+    };
+    auto load_superchunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prepare();
+#pragma unroll
+            for (int i = 0; i < NSUBLOAD; ++i) fire(i, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int pp = wave >> 1;                  // position pair
+    const int sub = wave & 1;                  // sub-tile
+    const int wm0 = HBT == 64 ? sub * 32 : 0;
+    const int wn0 = HBT == 64 ? 0 : sub * 32;
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    const int fhalf = lane >> 5;
+
+    load_superchunk();
+
+    f32x4 dn[3];                               // raw pixels d_pp, d_pp+1, d_pp+2 of the next k-step
+    f32x4 v[2][2], uf[2][2];
+    const float* const a_ptr = lds + (wm0 + frow) * WBK + pp * HSUB;
+    const float* const b_ptr = lds + HBT * WBK + (wn0 + frow) * WBK + 2 * pp * HSUB;
+    auto rd_a = [&](int q, int j) { dn[j] = *reinterpret_cast<const f32x4*>(a_ptr + j * HSUB + q * 4); };
+    auto rd_b = [&](int q, int j, int buf) { uf[buf][j] = *reinterpret_cast<const f32x4*>(b_ptr + j * HSUB + q * 4); };
+    // B^T d for this wave's two positions: pp = 0: (d0 - d2, d1 + d2); pp = 1 (dn = d1, d2, d3): (d2 - d1, d1 - d3)
+    auto xform = [&](int which, int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = dn[0][e], x1 = dn[1][e], x2 = dn[2][e];
+            if (which == 0) v[buf][0][e] = pp == 0 ? x0 - x2 : x1 - x0;
+            else v[buf][1][e] = pp == 0 ? x1 + x2 : x0 - x2;
+        }
+    };
+    auto first_frags = [&]() {
+        const int q0 = fhalf ^ fsw;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rd_a(q0, j);
+        rd_b(q0, 0, 0); rd_b(q0, 1, 0);
+        xform(0, 0); xform(1, 0);
+    };
+    first_frags();
+
+    // epilogue operands of the two register groups this wave finishes (g = 2 pp, 2 pp + 1)
+    const int t = m0 + wm0 + (lane & 31);
+    const bool t_ok = t < p.M;
+    const long o_row = (long)(2 * t) * p.omap.S1 + p.omap.off;
+    const long r_row = (long)(2 * t) * p.rmap.S1 + p.rmap.off;
+    f32x4 bv[2], r0[2], r1[2];
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * (2 * pp + k);
+            bv[k] = r0[k] = r1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {
+                if (p.bias) bv[k] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.res && t_ok) {
+                    r0[k] = *reinterpret_cast<const f32x4*>(p.res + r_row + n);
+                    r1[k] = *reinterpret_cast<const f32x4*>(p.res + r_row + p.rmap.S1 + n);
+                }
+            }
+        }
+    };
+
+    for (int sc = 0; sc < nsc; ++sc) {
+        if (sc == nsc - 1) load_epilogue_operands();
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int fb = step & 1, nb = fb ^ 1;
+            const int q_next = ((step + 1) * 2 + fhalf) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pq = i & 1, e = i >> 1;
+                acc[pq] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[fb][pq][e], v[fb][pq][e], acc[pq], 0, 0, 0);
+                if (step < 3) {
+                    if (i == 0) { rd_a(q_next, 0); rd_a(q_next, 1); }
+                    else if (i == 1) { rd_a(q_next, 2); rd_b(q_next, 0, nb); }
+                    else if (i == 2) rd_b(q_next, 1, nb);
+                    else if (i == 5) xform(0, nb);
+                    else if (i == 6) xform(1, nb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (sc + 1 < nsc) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_superchunk();
+            first_frags();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
+
+    // partial output transform:  pp = 0: (s0, s1) = (m0 + m1, m1);  pp = 1: (m2, -(m2 + m3));  y0 = s0 + s0', y1 = s1 + s1'
+    float* const xch = lds;                    // [sub][writer pp][4 slots][64 lanes] f32x4 = 16 KiB
+    {
+        float* dst = xch + (((sub * 2 + pp) * 4) * 64 + lane) * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int g = 2 * (pp ^ 1) + k;    // a group the partner finishes
+            f32x4 s0, s1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[0][4 * g + e], y = acc[1][4 * g + e];
+                s0[e] = pp == 0 ? x + y : x;
+                s1[e] = pp == 0 ? y : -(x + y);
+            }
+            *reinterpret_cast<f32x4*>(dst + (2 * k + 0) * 64 * 4) = s0;
+            *reinterpret_cast<f32x4*>(dst + (2 * k + 1) * 64 * 4) = s1;
+        }
+    }
+    __syncthreads();
+    const float* src = xch + (((sub * 2 + (pp ^ 1)) * 4) * 64 + lane) * 4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int g = 2 * pp + k;
+        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(src + (2 * k + 0) * 64 * 4);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(src + (2 * k + 1) * 64 * 4);
+        f32x4 y0, y1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = acc[0][4 * g + e], y = acc[1][4 * g + e];
+            const float m_s0 = pp == 0 ? x + y : x, m_s1 = pp == 0 ? y : -(x + y);
+            // fixed order whichever wave finishes the group: (pair 0 partial) + (pair 1 partial)
+            float s0 = (pp == 0 ? m_s0 + o0[e] : o0[e] + m_s0) + bv[k][e] + r0[k][e];
+            float s1 = (pp == 0 ? m_s1 + o1[e] : o1[e] + m_s1) + bv[k][e] + r1[k][e];
+            if (p.act == ACT_RELU) { s0 = fmaxf(s0, 0.f); s1 = fmaxf(s1, 0.f); }
+            y0[e] = s0; y1[e] = s1;
+        }
+        if (t_ok && n < p.N) {
+            *reinterpret_cast<f32x4*>(p.out + o_row + n) = y0;
+            *reinterpret_cast<f32x4*>(p.out + o_row + p.omap.S1 + n) = y1;
+        }
+    }
+}
+#endif
+
+__device__ __forceinline__ int xcd_remap_w(int b, int nblk) {   // see igemm_f32.hip :: xcd_remap
+    const int q = nblk >> 3, r = nblk & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// tile configuration of a problem: 0 = 64 tiles x 64 channels, 1 = 64 x 32, 2 = 32 x 64
+#if defined(__HIP_DEVICE_COMPILE__)
+template <bool PP>
+__device__ __forceinline__ void wino_dispatch(const GemmArgs& p, int cfg, int bid, float* lds) {
+    if (cfg == 1) wino_tile_h<64, 32>(p, bid, lds);
+    else if (cfg == 2) wino_tile_h<32, 64>(p, bid, lds);
+    else wino_tile<PP>(p, bid, lds);
+}
+#endif
+
+template <bool PP>
+__global__ __launch_bounds__(256) void igemm_wino_kernel(GemmArgs p, int cfg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    wino_dispatch<PP>(p, cfg, xcd_remap_w(blockIdx.x, gridDim.x), wlds);
+#endif
+}
+
+// grouped launch: up to MAXG Winograd problems in one grid (the 3x3 convs of an HRNet level), longest K first
+struct WinoGroupArgs {
+    GemmArgs g[MAXG];
+    int start[MAXG + 1];
+    int tiles[MAXG];
+    int cfg[MAXG];
+    int n;
+};
+
+template <bool PP>
+__global__ __launch_bounds__(256) void igemm_wino_group_kernel(WinoGroupArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
+    const int l = b - ga.start[pi];
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int bid = (l & 7) * per_xcd + (l >> 3);
+    if (bid >= ga.tiles[pi]) return;
+    wino_dispatch<PP>(ga.g[pi], ga.cfg[pi], bid, wlds);
+#endif
+}
+
+// ---- weights: BN fold + G transform, packed [Cout][(kh, chunk, p, c)] (K'' = 12 Cin) ----------------------------------
+__global__ void pack_conv_wino_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                      float* __restrict__ Wp, float* __restrict__ bias, int Cout, int Cin) {
+    const int Kw = 12 * Cin, CC = Cin / WBK;
+    const long total = (long)Cout * Kw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kw), k = (int)(i - (long)n * Kw);
+        const int cl = k % WBK, pq = (k / WBK) % 4, cc = (k / (4 * WBK)) % CC, kh = k / (4 * WBK * CC);
+        const int c = cc * WBK + cl;
+        const float sc = gamma ? gamma[n] / sqrtf(var[n] + eps) : 1.f;
+        const float* g = w + (((long)n * Cin + c) * 3 + kh) * 3;
+        const float g0 = g[0] * sc, g1 = g[1] * sc, g2 = g[2] * sc;
+        float u;
+        if (pq == 0) u = g0;
+        else if (pq == 1) u = 0.5f * ((g0 + g1) + g2);
+        else if (pq == 2) u = 0.5f * ((g0 - g1) + g2);
+        else u = g2;
+        Wp[i] = u;
+        if (k == 0 && bias) bias[n] = gamma ? beta[n] - mean[n] * sc : 0.f;
+    }
+}
+
+hipError_t launch_pack_conv_wino(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                                 float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s) {
+    if (Cin % WBK != 0) return hipErrorInvalidValue;
+    const long total = (long)Cout * 12 * Cin;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_conv_wino_kernel, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, Wp, bias, Cout, Cin);
+    return hipGetLastError();
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+bool gemm_wino_ok(const GemmArgs& a) {
+    return a.conv && a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin % WBK == 0 && (a.W & 1) == 0 && (a.N & 3) == 0 &&
+           a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale && a.act != ACT_GELU && !a.out_bf16 && a.H == a.Ho && a.W == a.Wo;
+}
+
+// rewrite a direct-conv problem description into the tile-grid form wino_tile expects; false if out of range
+static bool wino_prepare(GemmArgs& a) {
+    if (!gemm_wino_ok(a)) return false;
+    const long tiles = (long)(a.M / (a.Ho * a.Wo)) * a.H * (a.W / 2);
+    if ((double)a.M * (double)a.omap.S1 >= 4.0e9 || tiles > 0x7fffffffL) return false;
+    a.Wo = a.W / 2;                         // tile grid: H x W/2
+    a.M = (int)tiles;
+    a.Kpad = 12 * a.Cin;
+    a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.fd_wo = make_fastdiv((unsigned)a.Wo);
+    return true;
+}
+
+static hipError_t wino_attr() {
+    static hipError_t once = [] {
+        const void* big[] = {reinterpret_cast<const void*>(igemm_wino_kernel<false>), reinterpret_cast<const void*>(igemm_wino_group_kernel<false>)};
+        for (const void* f : big) {
+            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS * (int)sizeof(float));
+            if (r != hipSuccess) return r;
+        }
+        const void* half[] = {reinterpret_cast<const void*>(igemm_wino_kernel<true>), reinterpret_cast<const void*>(igemm_wino_group_kernel<true>)};
+        for (const void* f : half) {
+            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS / 2 * (int)sizeof(float));
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    }();
+    return once;
+}
+
+// CAPF_WINO_MODE (A/B runs only): 0 (default) ping-pong, 64 KiB, two blocks per CU; 1: double-buffered 64 x 64 tile, 128 KiB
+static int wino_mode() {
+    static const int m = [] { const char* e = getenv("CAPF_WINO_MODE"); return e ? atoi(e) : 0; }();
+    return m;
+}
+
+static const int kWT[3] = {64, 64, 32}, kWN[3] = {64, 32, 64};
+
+// tile configuration for a prepared problem (a.M = tiles): narrow outputs -> 64 x 32; few tiles -> 32 x 64 (twice the blocks)
+static int wino_cfg(const GemmArgs& a) {
+    if (a.N % 64 != 0) return 1;
+    const long blocks = (long)((a.M + 63) / 64) * (a.N / 64);
+    return blocks < 512 ? 2 : 0;
+}
+
+static int wino_tiles(const GemmArgs& a, int cfg) { return ((a.M + kWT[cfg] - 1) / kWT[cfg]) * ((a.N + kWN[cfg] - 1) / kWN[cfg]); }
+
+hipError_t launch_gemm_wino(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    if (!wino_prepare(a)) return hipErrorInvalidValue;
+    hipError_t r = wino_attr();
+    if (r != hipSuccess) return r;
+    const int cfg = wino_cfg(a);
+    const int nb = wino_tiles(a, cfg);
+    if (wino_mode() == 1) hipLaunchKernelGGL(igemm_wino_kernel<false>, dim3(nb), dim3(256), WLDS * sizeof(float), s, a, cfg);
+    else hipLaunchKernelGGL(igemm_wino_kernel<true>, dim3(nb), dim3(256), (cfg == 0 ? WLDS / 2 : 4 * (64 + 32) * WBK) * sizeof(float), s, a, cfg);
+    return hipGetLastError();
+}
+
+const char* gemm_wino_kernel_name() { return "igemm_wino<w4,F(2,3)>"; }
+
+hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n == 1) return launch_gemm_wino(list[0], s);
+    if (n > MAXG) return hipErrorInvalidValue;
+    hipError_t r = wino_attr();
+    if (r != hipSuccess) return r;
+    struct Item { int idx, cfg, tiles; double cost; };
+    Item it[MAXG];
+    GemmArgs prep[MAXG];
+    bool any_full = false;
+    for (int i = 0; i < n; ++i) {
+        prep[i] = list[i];
+        if (!wino_prepare(prep[i])) return hipErrorInvalidValue;
+        const int cfg = wino_cfg(prep[i]);
+        any_full |= cfg == 0;
+        it[i] = Item{i, cfg, wino_tiles(prep[i], cfg), (double)prep[i].Cin * kWT[cfg] * kWN[cfg]};
+    }
+    for (int i = 1; i < n; ++i)                  // longest tile first
+        for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    WinoGroupArgs ga;
+    ga.n = n;
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+        ga.g[i] = prep[it[i].idx];
+        ga.cfg[i] = it[i].cfg;
+        ga.tiles[i] = it[i].tiles;
+        ga.start[i] = start;
+        start += (it[i].tiles + 7) & ~7;
+    }
+    ga.start[n] = start;
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
+    if (wino_mode() == 1) hipLaunchKernelGGL(igemm_wino_group_kernel<false>, dim3(start), dim3(256), WLDS * sizeof(float), s, ga);
+    else hipLaunchKernelGGL(igemm_wino_group_kernel<true>, dim3(start), dim3(256), (any_full ? WLDS / 2 : 4 * (64 + 32) * WBK) * sizeof(float), s, ga);
+    return hipGetLastError();
+}
+
+}  // namespace capf
+
+#ifdef CAPF_DIAG
+extern "C" int capf_debug_wino_timeline(unsigned long long* dst, int blocks) {
+    if (blocks > 8192) blocks = 8192;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_wino_timeline), (size_t)blocks * 64);
+}
+#endif

@@ -54,6 +54,15 @@ bool gemm_f32_groupable(const GemmArgs& a);
 hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_f32_kernel_name(const GemmArgs& a);   // which template instantiation launch_gemm_f32 picks
 
+// Winograd F(2,3)-along-W variant of the 3x3 / stride-1 / pad-1 fp32 conv (igemm_wino.hip): same GemmArgs as the direct conv,
+// Wp = weights packed by launch_pack_conv_wino ([N][12 * Cin]); needs Cin % 32 == 0, even W, N % 4 == 0
+bool gemm_wino_ok(const GemmArgs& a);
+hipError_t launch_gemm_wino(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s);
+const char* gemm_wino_kernel_name();
+hipError_t launch_pack_conv_wino(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                                 float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s);
+
 // conv weight fold + pack:  Wp[n][(kh*ks+kw)*Cin+ci] = w[n][ci][kh][kw] * gamma[n]/sqrt(var[n]+eps)
 //                            bias[n] = beta[n] - mean[n]*gamma[n]/sqrt(var[n]+eps)
 hipError_t launch_pack_conv(const float* w, const float* gamma, const float* beta, const float* mean,

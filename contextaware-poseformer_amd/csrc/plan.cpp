@@ -119,6 +119,11 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     const bool use_bf16 = bf16() && x.C % 8 == 0;       // the Cin = 3 stem stays on the fp32 kernel
     pk.bf16 = use_bf16;
     pk.Kpad = use_bf16 ? round64(pk.K) : round32(pk.K);
+    // Winograd F(2,3) along W (igemm_wino.hip) for the 3x3 stride-1 fp32 convs: 1.5x fewer MFMAs; block tiles of 64 x 64,
+    // 64 x 32 (32-channel outputs) or 32 x 64 (few tiles) are chosen per problem at launch
+    const bool use_wino = this->use_wino && !use_bf16 && ks == 3 && stride == 1 && x.C % 32 == 0 && x.W % 2 == 0 && Cout % 32 == 0;
+    pk.wino = use_wino;
+    if (use_wino) { pk.Kpad2 = pk.Kpad; pk.Kpad = 12 * x.C; }
     packs.push_back(pk);
 
     Op op;
@@ -140,6 +145,7 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
         use(residual->buf);
     }
     op.bf16 = use_bf16 ? 1 : 0;
+    op.wino = use_wino ? 1 : 0;
     op.out_bf16 = (bf16() && !use_bf16) ? 1 : 0;
     y.buf = new_buffer(act_elems((size_t)y.H * y.W * Cout), conv);
     op.out = y.buf;
@@ -844,6 +850,8 @@ bool Engine::build() {
         return false;
     }
     if (const char* fz = getenv("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;      // A/B runs only
+    if (const char* wz = getenv("CAPF_WINO")) use_wino = atoi(wz) != 0;                  // A/B runs only
+    if (const char* wb = getenv("CAPF_WINO_MIN_BATCH")) wino_min_batch = atoi(wb);
     Tensor img{EXT_IMAGES, cfg.height, cfg.width, 3};
     Tensor feats[4];
     if (cfg.backbone == CAPF_HRNET) {
@@ -900,6 +908,10 @@ bool Engine::build() {
         if (pk.direct) continue;
         pk.w_off = off;
         off += round64(pk.bf16 ? ((size_t)pk.N * pk.Kpad + 1) / 2 : (size_t)pk.N * pk.Kpad);
+        if (pk.wino) {
+            pk.w2_off = off;
+            off += round64((size_t)pk.N * pk.Kpad2);
+        }
         pk.b_off = off;
         off += round64((size_t)pk.N);
     }

@@ -74,6 +74,50 @@ def test_linear_matches_torch(M, N, K, act, res):
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
+WINO_CASES = [(64, 64, 32, 32, 3, 1, True), (32, 32, 64, 64, 2, 1, False), (128, 128, 16, 16, 5, 1, True), (256, 256, 8, 8, 3, 0, True),
+              (64, 64, 64, 64, 1, 1, True), (96, 96, 6, 10, 2, 0, False), (64, 128, 12, 8, 3, 1, True), (128, 32, 16, 12, 2, 1, False),
+              (32, 64, 2, 2, 1, 1, True), (256, 128, 24, 18, 2, 1, True)]
+
+
+@pytest.mark.parametrize("ci,co,H,W,B,act,res", WINO_CASES)
+def test_winograd_conv_matches_torch(ci, co, H, W, B, act, res):
+    """The F(2,3)-along-W kernel (csrc/igemm_wino.hip) against an fp32 PyTorch conv + eval BatchNorm: all three block-tile
+    configurations (64x64, 64x32 for 32-channel outputs, 32x64 for few tiles), ragged tile counts, W as small as 2
+    (every tile touches both borders), residual / ReLU epilogues."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(ci * 7 + co + H * 3 + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5
+    bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+           torch.rand(co, generator=g) * 0.4 + 0.8)
+    want = F.batch_norm(F.conv2d(x, w, None, 1, 1), bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    r = torch.randn_like(want) if res else None
+    if res:
+        want = want + r
+    if act == 1:
+        want = F.relu(want)
+    wp, bias = capf.pack_conv_wino(w.cuda(), tuple(t.cuda() for t in bnp))
+    got = capf.conv_nhwc_wino(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
+                              r.permute(0, 2, 3, 1).contiguous().cuda() if res else None).cpu().permute(0, 3, 1, 2)
+    err = (got - want).abs().max().item()
+    assert err < 3e-5 * max(1.0, want.abs().max().item()), err
+
+
+def test_grouped_winograd_launch_is_bit_identical_to_single_launches():
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(3)
+    probs = []
+    for c, r_ in ((32, 32), (64, 16), (128, 8), (256, 4)):
+        x = torch.randn(6, r_, r_, c, generator=g).cuda()
+        w = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).cuda()
+        res = torch.randn(6, r_, r_, c, generator=g).cuda()
+        wp, b = capf.pack_conv_wino(w)
+        probs.append((x, wp, b, 1, res))
+    grouped = capf.conv_nhwc_wino_group(probs)
+    for (x, wp, b, act, res), yg in zip(probs, grouped):
+        assert torch.equal(yg, capf.conv_nhwc_wino(x, wp, b, act, res))
+
+
 @pytest.mark.parametrize("M,N,K,gelu,res", [(1088, 1920, 640, False, False), (1088, 640, 1280, False, True), (5440, 384, 128, False, False),
                                             (4352, 256, 128, True, False), (17, 640, 640, False, True), (85, 128, 256, False, True),
                                             (4352, 1280, 640, True, False), (300, 132, 64, False, False)])
