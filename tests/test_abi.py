@@ -178,3 +178,26 @@ def test_conv_group_rejects_bad_arguments_without_a_gpu():
     assert lib.capf_op_conv_group(None, 2, d) != 0
     d[1].Cin, d[1].ks = 32, 7                                       # 49 taps do not fit the 32-bit tap mask
     assert lib.capf_op_conv_group(None, 2, d) != 0
+
+
+def test_integration_stub_struct_matches_the_header_and_the_binding():
+    """INTEGRATION.md's ctypes stub, include/capf.h's capf_config and capf.lib.CapfConfig must list the same fields in the
+    same order (round 1 shipped a stub one field short: the library would have read past the caller's struct)."""
+    import ctypes, os, re
+    from capf.lib import CapfConfig
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bound = [n for n, _ in CapfConfig._fields_]
+    header = open(os.path.join(root, "include", "capf.h")).read()
+    body = header[header.index("typedef struct capf_config {"):header.index("} capf_config;")]
+    decl = []
+    for line in body.splitlines()[1:]:
+        m = re.match(r"\s*int32_t\s+([^;]+);", line)
+        if m:
+            decl += [re.sub(r"\[\d+\]", "", v).strip() for v in m.group(1).split(",")]
+    assert decl == bound
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class capf_config(ctypes.Structure)"):doc.index("class CA_PF(nn.Module):")]
+    assert re.findall(r'\("(\w+)", ctypes\.c_int32', stub) == bound
+    assert ctypes.sizeof(CapfConfig) == 4 * 22
+    ctor = re.search(r"c = capf_config\(([^\n]*)\)\s+#", doc).group(1)
+    assert len(re.sub(r"\([^)]*\)", "T", ctor).split(",")) == len(bound)

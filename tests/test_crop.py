@@ -48,6 +48,46 @@ def test_oracle_warp_half_pixel_shift_averages_neighbours_and_constant_stays_con
     assert np.all(out2[:, :, 1] == 200)                             # weights sum to exactly 2^15
 
 
+def test_oracle_warp_exact_2x_downscale_is_the_rounded_mean_of_four_pixels():
+    """dst = (src - 0.5) / 2, so dst pixel (x, y) samples src at (2x + 0.5, 2y + 0.5): both fractions are 16/32, the four
+    15-bit weights are 8192 each and OpenCV's rounding (acc + 2^14) >> 15 gives floor((a + b + c + d + 2) / 4)."""
+    co = _oracle()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(12, 16, 3), dtype=np.uint8)
+    m = np.array([[0.5, 0.0, -0.25], [0.0, 0.5, -0.25]])
+    out = co.warp_affine_linear_u8(img, m, 7, 5)
+    i = img.astype(np.int64)
+    want = (i[0:10:2, 0:14:2] + i[0:10:2, 1:15:2] + i[1:11:2, 0:14:2] + i[1:11:2, 1:15:2] + 2) // 4
+    assert np.array_equal(out, want.astype(np.uint8))
+
+
+def test_oracle_warp_non_axis_aligned_cases_worked_by_hand():
+    """(a) a quarter turn, x' = (Hs - 1) - y, y' = x: every sample point is a pixel centre -> out[y', x'] = img[Hs-1-x', y'].
+    (b) a shear x' = x + y / 4: dst row y' samples src at x = x' - y'/4, i.e. fraction f = (-y'/4) mod 1 in {0, 3/4, 1/2, 1/4}
+    (all multiples of 1/32), weights ((1-f) 2^15, f 2^15), value ((1-f) a + f b) with OpenCV's (acc + 2^14) >> 15."""
+    co = _oracle()
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(9, 11, 3), dtype=np.uint8)
+    hs = img.shape[0]
+    out = co.warp_affine_linear_u8(img, np.array([[0.0, -1.0, hs - 1.0], [1.0, 0.0, 0.0]]), hs, 11)      # out is [11 rows, 9 cols]
+    want = np.zeros((11, hs, 3), np.uint8)
+    for yp in range(11):
+        for xp in range(hs):
+            want[yp, xp] = img[hs - 1 - xp, yp]
+    assert np.array_equal(out, want)
+    out = co.warp_affine_linear_u8(img, np.array([[1.0, 0.25, 0.0], [0.0, 1.0, 0.0]]), 8, 8)
+    i = img.astype(np.int64)
+    for yp in range(8):
+        for xp in range(3, 8):                      # columns whose two source pixels are inside the image
+            xs = xp - yp / 4.0
+            x0 = int(np.floor(xs))
+            f32 = int(round((xs - x0) * 32))         # exact: multiples of 8
+            w1 = f32 * 1024
+            w0 = 32768 - w1
+            val = (i[yp, x0] * w0 + (i[yp, x0 + 1] * w1 if w1 else 0) + 16384) >> 15
+            assert np.array_equal(out[yp, xp], val.astype(np.uint8)), (yp, xp)
+
+
 @pytest.mark.parametrize("center,scale", [((500.0, 480.0), (1.5, 2.0)), ((512.3, 431.7), (1.037, 1.3826)),
                                           ((100.0, 900.0), (2.25, 3.0))])
 def test_library_affine_matches_the_oracle(center, scale):
