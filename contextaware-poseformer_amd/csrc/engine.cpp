@@ -94,6 +94,11 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
     a.act = op.act;
     a.out_bf16 = op.out_bf16;
+    static const bool splitk_on = [] { const char* e = getenv("CAPF_SPLITK"); return !e || atoi(e) != 0; }();   // A/B runs only
+    if (op.conv && !op.bf16 && split_ws && lanes != 1 && splitk_on) {      // one stream: launches use the scratch one after the other
+        a.split_ws = split_ws; a.split_cnt = split_cnt;
+        a.split_ws_elems = SPLIT_WS_ELEMS; a.split_cnt_elems = SPLIT_CNT_ELEMS;
+    }
     if (op.ln_w >= 0) {
         a.ln_g = params[op.ln_w].ptr;
         a.ln_b = params[op.ln_b].ptr;
@@ -348,6 +353,9 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
     if (device >= 0) {
         hipError_t r = hipSetDevice(device);
         if (r == hipSuccess && e.pack_elems) r = hipMalloc(reinterpret_cast<void**>(&e.pack_arena), e.pack_elems * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&e.split_ws), Engine::SPLIT_WS_ELEMS * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&e.split_cnt), Engine::SPLIT_CNT_ELEMS * sizeof(int));
+        if (r == hipSuccess) r = hipMemset(e.split_cnt, 0, Engine::SPLIT_CNT_ELEMS * sizeof(int));
         for (int i = 0; i < 3 && r == hipSuccess; ++i) r = hipStreamCreateWithFlags(&e.side[i], hipStreamNonBlocking);
         e.events.resize(e.n_events);
         for (auto& x : e.events)
@@ -365,6 +373,8 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
 void capf_destroy(capf_handle* h) {
     if (!h) return;
     if (h->e.pack_arena) (void)hipFree(h->e.pack_arena);
+    if (h->e.split_ws) (void)hipFree(h->e.split_ws);
+    if (h->e.split_cnt) (void)hipFree(h->e.split_cnt);
     for (auto& x : h->e.events)
         if (x) (void)hipEventDestroy(x);
     for (auto& st : h->e.side)

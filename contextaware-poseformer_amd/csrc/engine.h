@@ -156,6 +156,10 @@ struct Engine {
     size_t pack_elems = 0;
 
     float* pack_arena = nullptr;   // device, owned
+    float* split_ws = nullptr;     // device, owned: split-K slabs + per-tile counters of the small-batch conv launches
+    int* split_cnt = nullptr;
+    static constexpr long SPLIT_WS_ELEMS = 4L << 20;
+    static constexpr int SPLIT_CNT_ELEMS = 16384;
     float* ws = nullptr;           // device, borrowed
     size_t ws_bytes = 0;
     bool packed = false;

@@ -85,7 +85,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (two passes over rows that are about to be streamed anyway), gamma / beta sit in LDS behind the ring, and the
 // normalisation is applied to the A fragments between the LDS read and the MFMA: 12 VALU instructions per
 // fragment, no normalised copy of the activations in HBM and no LayerNorm launch.
-template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL, bool LNA = false>
+template <int NW, int BM, int BN, int WM, int WN, int S, int AMODE, bool GELU, bool PLAIN, int ABL, bool LNA = false, bool SPLITK = false>
 __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, const int ky, float* __restrict__ lds,
                                            const int dbg_block) {
     constexpr int NT = 64 * NW;
@@ -184,9 +184,15 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     const bool uni = AMODE == AMODE_CONV && (p.Cin & (BK - 1)) == 0;
     int u_tap = 0, u_ci = 0, u_kh = 0, u_kw = 0;  // uniform walk (u_ci = first channel of the chunk)
     int tap = 0, ci = kq, kh = 0, kw = 0;         // per-thread walk (ci = this thread's channel)
+    if (SPLITK && AMODE == AMODE_CONV && uni && c_begin > 0) {          // split-K slice: start the walk at chunk c_begin
+        u_tap = (c_begin * BK) / p.Cin;
+        u_ci = c_begin * BK - u_tap * p.Cin;
+        u_kh = u_tap / p.ks;
+        u_kw = u_tap - u_kh * p.ks;
+    }
     if (AMODE == AMODE_CONV && !uni) {
-        tap = kq / p.Cin;
-        ci = kq - tap * p.Cin;
+        tap = (c_begin * BK + kq) / p.Cin;
+        ci = c_begin * BK + kq - tap * p.Cin;
         kh = tap / p.ks;
         kw = tap - kh * p.ks;
     }
@@ -439,6 +445,55 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     if (ABL == 5 && p.M > 0) return;     // (ablation) no epilogue; the condition is opaque to the compiler, the MFMAs stay
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     const bool vec_ok = (p.N & 3) == 0;
+    if (SPLITK && AMODE == AMODE_CONV && PLAIN && p.split_cnt) {
+        // ---- conv split-K: park the raw partial tile, count, and let the last slice of the tile reduce + finish
+        float* slab = p.split_ws + (long)ky * p.split_stride;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 32 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                    if (m < p.M && n < p.N)
+                        *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) =
+                            f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                }
+        }
+        __threadfence();                              // release: the slab is visible device-wide before the count moves
+        __shared__ int s_last;
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(p.split_cnt + bid, 1) == p.splits - 1;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();                              // acquire: see every other slice's slab
+        if (tid == 0) p.split_cnt[bid] = 0;           // self-resetting: the next launch finds zeros
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int sl = 0; sl < p.splits; ++sl) {       // fixed order: the sum does not depend on which slice came last
+            const float* src = p.split_ws + (long)sl * p.split_stride;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm0 + i * 32 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                        if (m < p.M && n < p.N) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)m * p.N + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += v[e];
+                        }
+                    }
+            }
+        }
+    }
     // Pass 1: EVERY bias / residual load of the tile is issued before the first store.  vmcnt retires in
     // order, so a load issued after a store would make its consumer wait for that store's completion too
     // (~1.5 us per 32x32 sub-tile when loads and stores alternate); it is also what an in-place residual
@@ -470,7 +525,7 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
         o_row[i] = 0; r_row[i] = 0; rs[i] = 1.0f;
         if (m_ok[i]) {
             if (p.rscale) rs[i] = p.rscale[m / p.rs_div];
-            o_row[i] = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (long)ky * p.split_stride;
+            o_row[i] = (PLAIN ? (long)m * p.omap.S1 + p.omap.off : rowmap(p.omap, m)) + (p.split_cnt ? 0 : (long)ky * p.split_stride);
             if (p.res) r_row[i] = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : rowmap(p.rmap, m);
         }
 #pragma unroll
@@ -556,12 +611,15 @@ struct GroupArgs {
     int start[MAXG + 1];   // first physical block of problem i (multiples of 8)
     int tiles[MAXG];       // real tiles of problem i
     int cfg[MAXG];         // 0: 128x64 (S=2), 1: 64x64 (S=3), 2: 128x32 (S=2)
+    int splits[MAXG];      // split-K slices per tile (1 = none); tiles[] counts blocks = tiles x splits
     int n;
 };
 static constexpr int GROUP_LDS_FLOATS = 2 * (128 + 64) * BK;   // 48 KiB: 3 blocks per CU for every configuration
 static_assert(3 * (64 + 64) * BK <= GROUP_LDS_FLOATS && 2 * (128 + 32) * BK <= GROUP_LDS_FLOATS, "group LDS");
 
-template <int ABL>
+// SPLITK: the variant with the conv split-K path compiled in (small batches only: the extra code costs the plain kernel
+// 2-40 % through the instruction cache, so it is a separate instantiation)
+template <int ABL, bool SPLITK = false>
 __global__ __launch_bounds__(256) void igemm_f32_group_kernel(GroupArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float lds[GROUP_LDS_FLOATS];
@@ -573,10 +631,12 @@ __global__ __launch_bounds__(256) void igemm_f32_group_kernel(GroupArgs ga) {
     const int bid = (l & 7) * per_xcd + (l >> 3);                 // XCD-contiguous tile order inside the problem
     if (bid >= ga.tiles[pi]) return;                              // padding block
     const GemmArgs& p = ga.g[pi];
+    const int sp = SPLITK ? ga.splits[pi] : 1;
+    const int tile = sp > 1 ? bid / sp : bid, ky = sp > 1 ? bid - tile * sp : 0;
     switch (ga.cfg[pi]) {
-        case 0: igemm_tile<4, 128, 64, 64, 32, 2, AMODE_CONV, false, true, ABL>(p, bid, 0, lds, b); break;
-        case 1: igemm_tile<4, 64, 64, 32, 32, 3, AMODE_CONV, false, true, ABL>(p, bid, 0, lds, b); break;
-        default: igemm_tile<4, 128, 32, 32, 32, 2, AMODE_CONV, false, true, ABL>(p, bid, 0, lds, b); break;
+        case 0: igemm_tile<4, 128, 64, 64, 32, 2, AMODE_CONV, false, true, ABL, false, SPLITK>(p, tile, ky, lds, b); break;
+        case 1: igemm_tile<4, 64, 64, 32, 32, 3, AMODE_CONV, false, true, ABL, false, SPLITK>(p, tile, ky, lds, b); break;
+        default: igemm_tile<4, 128, 32, 32, 32, 2, AMODE_CONV, false, true, ABL, false, SPLITK>(p, tile, ky, lds, b); break;
     }
 #endif
 }
@@ -829,9 +889,19 @@ bool gemm_f32_groupable(const GemmArgs& a) {
            a.omap.G == 1 && (!a.res || a.rmap.G == 1) && a.M > 0 && a.N > 0 && a.Kpad % BK == 0 && !a.out_bf16;
 }
 
+// tiles of a conv problem under the grouped kernel's tile choice at small sizes (64x64, or 128x32 for N <= 32)
+static long group_tiles_small(const GemmArgs& a) {
+    return a.N <= 32 ? (long)((a.M + 127) / 128) : (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+}
+// does a lone conv gain from the split-K path of the grouped kernel? (few tiles, long K, scratch available)
+static bool worth_splitting(const GemmArgs& a) {
+    return a.conv && a.split_ws && a.split_cnt && gemm_f32_groupable(a) && a.Kpad / BK >= 32 && group_tiles_small(a) <= 16 &&
+           (long)a.M * a.N * 2 <= a.split_ws_elems;
+}
+
 hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    if (n == 1) return launch_gemm_f32(list[0], s);
+    if (n == 1 && !worth_splitting(list[0])) return launch_gemm_f32(list[0], s);
     if (n > MAXG) return hipErrorInvalidValue;
     static const int BMs[3] = {128, 64, 128}, BNs[3] = {64, 64, 32};
     // work in units of one 64x64x32 tile-chunk (1024 MFMA cycles of a CU), per CU
@@ -858,37 +928,71 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     for (int i = 1; i < n; ++i)                  // longest tile first (insertion sort, n <= 8)
         for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    // Small batches: a level is a few dozen tiles and its duration is the K loop of the longest problem (72 chunks for the
+    // 256-channel 8x8 branch against 9 for the 32-channel one).  A problem with a long K and a handful of tiles is split
+    // along K; the slices of a tile meet through the scratch the caller lent (GemmArgs::split_ws / split_cnt), reduced in
+    // fixed order by the last slice to finish (see igemm_tile).  The decision is a function of the problem ALONE
+    // (worth_splitting), so a conv sums in the same order whether it is launched on its own or inside a group.
+    // Measured (HRNet-32 256x256, frames/s with / without): batch 1 362 / 302, batch 2 678 / 600, batch 4 1171 / 1172.  A
+    // group-wide rule (split everything to the shortest problem's length whenever the level had < 192 tiles) lost 13 % /
+    // 10 % at batch 2 / 4: the device-scope release / acquire around the counter (an L2 write-back on this multi-XCD
+    // part) and the second pass over the slabs cost ~15 us, which only a long loop on a handful of tiles repays.
+    long ws_used = 0, cnt_used = 0;
     GroupArgs ga;
     ga.n = n;
     int start = 0;
     for (int i = 0; i < n; ++i) {
         GemmArgs a = list[it[i].idx];
-        a.splits = 1; a.cps = a.Kpad / BK; a.split_stride = 0;
+        const int chunks = a.Kpad / BK;
+        a.splits = 1; a.cps = chunks; a.split_stride = 0;
+        float* ws = a.split_ws; int* cnt = a.split_cnt;
+        a.split_ws = nullptr; a.split_cnt = nullptr;
+        if (ws && cnt && worth_splitting(list[it[i].idx])) {
+            int sp = std::min(8, chunks / 12);
+            const long slab = (long)a.M * a.N;
+            if ((ws_used + slab * sp) > list[it[i].idx].split_ws_elems || cnt_used + it[i].tiles > list[it[i].idx].split_cnt_elems) sp = 1;
+            if (sp > 1) {
+                a.cps = (chunks + sp - 1) / sp;
+                sp = (chunks + a.cps - 1) / a.cps;
+                a.splits = sp;
+                a.split_stride = slab;
+                a.split_ws = ws + ws_used;
+                a.split_cnt = cnt + cnt_used;
+                ws_used += slab * sp;
+                cnt_used += it[i].tiles;
+            }
+        }
         if (a.rs_div <= 0) a.rs_div = 1;
         if ((double)a.M * (double)a.omap.S1 >= 4.0e9 || (a.res && (double)a.M * (double)a.rmap.S1 >= 4.0e9))
             return hipErrorInvalidValue;
         if (!prep_conv(a)) return hipErrorInvalidValue;
         ga.g[i] = a;
         ga.cfg[i] = it[i].cfg;
-        ga.tiles[i] = it[i].tiles;
+        ga.splits[i] = a.splits;
+        ga.tiles[i] = it[i].tiles * a.splits;
         ga.start[i] = start;
-        start += (it[i].tiles + 7) & ~7;
+        start += (ga.tiles[i] + 7) & ~7;
     }
     ga.start[n] = start;
-    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; ga.splits[i] = 1; }
 #ifdef CAPF_DIAG
     static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
     if (abl == 7) hipLaunchKernelGGL((igemm_f32_group_kernel<7>), dim3(start), dim3(256), 0, s, ga);
     else
 #endif
-    hipLaunchKernelGGL((igemm_f32_group_kernel<0>), dim3(start), dim3(256), 0, s, ga);
+    bool any_split = false;
+    for (int i = 0; i < n; ++i) any_split |= ga.splits[i] > 1;
+    if (any_split) hipLaunchKernelGGL((igemm_f32_group_kernel<0, true>), dim3(start), dim3(256), 0, s, ga);
+    else hipLaunchKernelGGL((igemm_f32_group_kernel<0>), dim3(start), dim3(256), 0, s, ga);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
+    if (a_in.splits <= 1 && worth_splitting(a_in)) return launch_gemm_f32_group(&a_in, 1, s);
     GemmArgs a = a_in;
+    a.split_ws = nullptr; a.split_cnt = nullptr;                           // (the in-kernel reduction belongs to the grouped kernel)
     if (a.splits <= 1) { a.splits = 1; a.cps = a.Kpad / BK; a.split_stride = 0; }
     else if (a.conv || a.bias || a.res) return hipErrorInvalidValue;     // split-K slabs are raw partial sums
     if (a.rs_div <= 0) a.rs_div = 1;

@@ -707,6 +707,8 @@ static const int kWT[3] = {64, 64, 32}, kWN[3] = {64, 32, 64};
 
 // tile configuration for a prepared problem (a.M = tiles): narrow outputs -> 64 x 32; few tiles -> 32 x 64 (twice the blocks)
 static int wino_cfg(const GemmArgs& a) {
+    static const int forced = [] { const char* e = getenv("CAPF_WINO_CFG"); return e ? atoi(e) : -1; }();   // tuning only
+    if (forced == 1 || (forced == 2 && a.N % 64 == 0)) return forced;
     if (a.N % 64 != 0) return 1;
     const long blocks = (long)((a.M + 63) / 64) * (a.N / 64);
     return blocks < 512 ? 2 : 0;

@@ -41,6 +41,13 @@ struct GemmArgs {
     int splits, cps;        // split-K (rows mode): grid.y slices of `cps` chunks, slab s at out + s*split_stride
     long split_stride;
     int out_bf16;           // small-Cin stem kernel only: fp32 image in, bf16 activations out
+    // conv-mode split-K with an in-kernel, deterministic reduction (small batches: a long-K conv with a handful of tiles):
+    // slice ky writes its raw partial tile to split_ws + ky * split_stride ([M][N]); the LAST slice to finish a tile (a
+    // device-scope counter per tile, self-resetting) sums the slices in order 0..splits-1 and runs the epilogue
+    float* split_ws;
+    int* split_cnt;
+    long split_ws_elems;    // capacity of the scratch the caller lends (floats / counters); the launchers carve it up
+    int split_cnt_elems;
     const float* ln_g;      // rows mode: LayerNorm the A rows over their K columns on the fly (gamma, beta [K]); nullptr = off
     const float* ln_b;
     float ln_eps;

@@ -266,7 +266,9 @@ def test_grouped_conv_launch_is_bit_identical_to_single_launches(gi):
 
 @pytest.mark.parametrize("dtype,backbone", [("fp32", "hrnet_32"), ("bf16", "hrnet_32"), ("fp32", "cpn"), ("bf16", "hrnet_48")])
 def test_engine_modes_are_bit_identical(dtype, backbone):
-    """capf_set_lanes 0 / 1 / 2 (program order, side streams, grouped launches) give the same bits."""
+    """capf_set_lanes 0 / 2 (program order, grouped launches) give the same bits; mode 1 (side streams, kept for A/B runs)
+    has no split-K scratch — concurrent launches would share it — so its long-K small-batch convs sum K in one pass instead
+    of slices: equal to roundoff, not to the bit."""
     import copy, contextlib, io
     from capf import synth
     from mvn.models.conpose import CA_PF
@@ -284,7 +286,8 @@ def test_engine_modes_are_bit_identical(dtype, backbone):
         for mode in (0, 1, 2):
             model.engine_for(img).set_lanes(mode)
             outs.append(model(img, k2d, kc.clone()).clone())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[2])
+    assert (outs[0] - outs[1]).abs().max().item() <= (2e-6 if dtype == "fp32" else 1e-2)
 
 
 def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
