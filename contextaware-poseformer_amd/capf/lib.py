@@ -96,8 +96,8 @@ def load_library():
     lib.capf_fliptest_fuse.argtypes = [P, P, c_int, P]
     lib.capf_op_pack_conv_bf16.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 8
-    lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
-    lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 6
+    lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
+    lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
     lib.capf_pose_errors.argtypes = [P, P, P, c_int, c_int, P, P]
     lib.capf_segment_sums.argtypes = [P, P, P, P, c_int, c_int, P, P]
@@ -366,29 +366,33 @@ def conv_nhwc(x, wp, bias, ks, stride=1, act=0, residual=None):
     return y
 
 
-def pack_conv_wino(w, bn=None, eps=1e-5):
-    """w [Cout,Cin,3,3] cuda fp32 -> (Winograd F(2,3) weights [Cout, 12*Cin], bias [Cout]) for conv_nhwc_wino."""
+def pack_conv_wino(w, bn=None, eps=1e-5, variant=23):
+    """w [Cout,Cin,3,3] cuda fp32 -> (Winograd weights [Cout, 12*Cin] for F(2,3) / [Cout, 18*Cin] for F(4,3), bias [Cout])."""
     import torch
     lib = load_library()
     co, ci, ks, _ = w.shape
     assert ks == 3
-    wp = torch.empty(co, 12 * ci, device=w.device)
+    wp = torch.empty(co, (18 if variant == 43 else 12) * ci, device=w.device)
     bias = torch.empty(co, device=w.device)
     g, b, m, v = bn if bn is not None else (None, None, None, None)
-    rc = lib.capf_op_pack_conv_wino(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci)
+    rc = lib.capf_op_pack_conv_wino(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci, variant)
     if rc:
         raise CapfError(f"capf_op_pack_conv_wino failed ({rc})")
     return wp, bias
 
 
+def _wino_variant(wp, ci):
+    return 43 if wp.shape[1] == 18 * ci else 23
+
+
 def conv_nhwc_wino(x, wp, bias, act=0, residual=None):
-    """3x3 stride-1 conv through the Winograd kernel: x [B,H,W,Cin] cuda fp32 NHWC -> [B,H,W,Cout]."""
+    """3x3 stride-1 conv through the Winograd kernel (variant from the packed pitch): x [B,H,W,Cin] cuda fp32 NHWC -> [B,H,W,Cout]."""
     import torch
     lib = load_library()
     B, H, W, ci = x.shape
     co = wp.shape[0]
     y = torch.empty(B, H, W, co, device=x.device)
-    rc = lib.capf_op_conv_wino(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, act)
+    rc = lib.capf_op_conv_wino(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, act, _wino_variant(wp, ci))
     if rc:
         raise CapfError(f"capf_op_conv_wino failed ({rc})")
     return y
@@ -398,7 +402,7 @@ def conv_nhwc_wino_group(problems):
     """problems: list of (x, wp_wino, bias, act, residual) -> outputs; ONE grouped Winograd launch."""
     import torch
     lib = load_library()
-    lib.capf_op_conv_wino_group.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ConvDesc)]
+    lib.capf_op_conv_wino_group.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ConvDesc), ctypes.c_int]
     descs = (ConvDesc * len(problems))()
     outs = []
     for d, (x, wp, bias, act, residual) in zip(descs, problems):
@@ -409,7 +413,7 @@ def conv_nhwc_wino_group(problems):
         d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
         d.residual = residual.data_ptr() if residual is not None else None
         d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, co, 3, 1, act
-    rc = lib.capf_op_conv_wino_group(_stream(problems[0][0]), len(problems), descs)
+    rc = lib.capf_op_conv_wino_group(_stream(problems[0][0]), len(problems), descs, _wino_variant(problems[0][1], problems[0][0].shape[3]))
     if rc:
         raise CapfError(f"capf_op_conv_wino_group failed ({rc})")
     return outs

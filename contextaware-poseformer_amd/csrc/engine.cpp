@@ -37,7 +37,7 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks, pk.Kpad, s));
         } else if (pk.kind == 0 && pk.wino) {
             HIP_TRY(launch_pack_conv_wino(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
-                                          params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s));
+                                          params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s, pk.Kpad == 18 * pk.Cin ? 43 : 23));
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                      params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w2_off, B, pk.N, pk.Cin, pk.ks, pk.Kpad2, s));
         } else if (pk.kind == 0) {
@@ -611,16 +611,16 @@ int capf_op_conv(void* stream, const float* x, const float* wp, const float* bia
 }
 
 int capf_op_pack_conv_wino(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
-                           const float* var, float eps, float* wp, float* bias, int Cout, int Cin) {
-    return capf::launch_pack_conv_wino(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, static_cast<hipStream_t>(stream)) == hipSuccess
+                           const float* var, float eps, float* wp, float* bias, int Cout, int Cin, int variant) {
+    return capf::launch_pack_conv_wino(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, static_cast<hipStream_t>(stream), variant) == hipSuccess
                ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
 }
 
 static bool wino_desc(capf::GemmArgs& a, const float* x, const float* wp, const float* bias, const float* residual, float* y, int B,
-                      int H, int W, int Cin, int Cout, int act) {
+                      int H, int W, int Cin, int Cout, int act, int variant) {
     a = capf::GemmArgs{};
     a.A = x; a.Wp = wp; a.bias = bias; a.res = residual; a.out = y;
-    a.Ho = H; a.Wo = W; a.M = B * H * W; a.N = Cout; a.K = 9 * Cin; a.Kpad = 12 * Cin;
+    a.Ho = H; a.Wo = W; a.M = B * H * W; a.N = Cout; a.K = 9 * Cin; a.Kpad = (variant == 43 ? 18 : 12) * Cin;
     a.conv = 1; a.Cin = Cin; a.H = H; a.W = W; a.ks = 3; a.stride = 1; a.pad = 1;
     a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
     a.act = act;
@@ -628,18 +628,18 @@ static bool wino_desc(capf::GemmArgs& a, const float* x, const float* wp, const 
 }
 
 int capf_op_conv_wino(void* stream, const float* x, const float* wp, const float* bias, const float* residual, float* y, int B,
-                      int H, int W, int Cin, int Cout, int act) {
+                      int H, int W, int Cin, int Cout, int act, int variant) {
     capf::GemmArgs a;
-    if (!wino_desc(a, x, wp, bias, residual, y, B, H, W, Cin, Cout, act)) return CAPF_ERR_UNSUPPORTED;
+    if ((variant != 23 && variant != 43) || !wino_desc(a, x, wp, bias, residual, y, B, H, W, Cin, Cout, act, variant)) return CAPF_ERR_UNSUPPORTED;
     return capf::launch_gemm_wino(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
-int capf_op_conv_wino_group(void* stream, int n, const capf_conv_desc* d) {
-    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+int capf_op_conv_wino_group(void* stream, int n, const capf_conv_desc* d, int variant) {
+    if (n <= 0 || n > capf::MAXG || !d || (variant != 23 && variant != 43)) return CAPF_ERR_INVALID;
     capf::GemmArgs g[capf::MAXG];
     for (int i = 0; i < n; ++i)
         if (d[i].ks != 3 || d[i].stride != 1 ||
-            !wino_desc(g[i], d[i].x, d[i].w_packed, d[i].bias, d[i].residual, d[i].y, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].Cout, d[i].act))
+            !wino_desc(g[i], d[i].x, d[i].w_packed, d[i].bias, d[i].residual, d[i].y, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].Cout, d[i].act, variant))
             return CAPF_ERR_UNSUPPORTED;
     return capf::launch_gemm_wino_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }

@@ -24,6 +24,8 @@
 // accumulator registers); LDS = 2 superstages x 4 sub-stages x (64 + 64) rows x 128 B = 128 KiB (one block per CU).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace capf {
@@ -337,7 +339,7 @@ __device__ __forceinline__ void wino_tile(const GemmArgs& p, const int bid, floa
     if (tid == 0 && blockIdx.x < 8192) {
         unsigned long long* d = capf_wino_timeline + (size_t)blockIdx.x * 8;
         unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = __builtin_amdgcn_s_memtime();
         d[4] = dbg_r0; d[5] = hw; d[6] = xcc; d[7] = __builtin_amdgcn_s_memrealtime();
@@ -582,17 +584,308 @@ __device__ __forceinline__ void wino_tile_h(const GemmArgs& p, const int bid, fl
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// F(4,3) along W: a tile is FOUR output pixels (w = 4 wt .. 4 wt + 3) computed from six raw pixels d_0..d_5
+// (w_in = 4 wt - 1 + j) through SIX positions:
+//   v = B^T d:  v0 = 4 d0 - 5 d2 + d4          v1 = -4 (d1 + d2) + (d3 + d4)      v2 = 4 (d1 - d2) + (d4 - d3)
+//               v3 = 2 (d3 - d1) + (d4 - d2)   v4 = 2 (d1 - d3) + (d4 - d2)        v5 = 4 d1 - 5 d3 + d5
+//   u = G g:    u0 = g0 / 4   u1 = -(g0 + g1 + g2) / 6   u2 = -(g0 - g1 + g2) / 6   u3 = g0 / 24 + g1 / 12 + g2 / 6
+//               u4 = g0 / 24 - g1 / 12 + g2 / 6   u5 = g2
+//   y = A^T m:  y0 = m0 + m1 + m2 + m3 + m4      y1 = (m1 - m2) + 2 (m3 - m4)
+//               y2 = (m1 + m2) + 4 (m3 + m4)     y3 = (m1 - m2) + 8 (m3 - m4) + m5
+// 18 MACs per four outputs = 4.5 per pixel: HALF the MFMAs of the direct conv (F(2,3): two thirds).  fp32 error against
+// an fp64 conv: 4e-6 .. 9e-6 absolute on O(4) outputs (direct: 1e-6 .. 2e-6) — three orders below the 1e-3 bar.
+// Launched on its own it is no faster than F(2,3) (batch 64: 64x64 64->64 162 vs 144 us, the 32x32 / 16x16 / 8x8 branches 39 /
+// 48 / 90 vs 38 / 38 / 48 us, the 32-channel branch 45 vs 48 us): with 48 instead of 64 MFMAs per superchunk the load phase
+// (18 DMA instructions per thread + 8 fragment reads + 60 VALU of first-fragment transforms) outlasts the compute phase — the
+// timeline shows 5.35 us per superchunk per block against 3.25 us of MFMA time, and offsetting the second resident block of a
+// CU by one compute phase at start (LDS_ALLOC base != 0; tried) does not move it.  Inside the grouped launch of an HRNet
+// level, where blocks of four different shapes share the CUs, the saved MFMAs do show: a 4-branch level 157 -> 146 us and
+// 5143 -> 5307 frames/s end to end (selecting it only for the large maps: 5183-5272), so the plan uses it wherever W % 4 == 0.
+// Block = 4 waves = 2 sub-tiles (32 tiles x 32 channels) x 2 position TRIPLES: triple 0 (p0..p2) reads d0..d4, triple 1
+// (p3..p5) reads d1..d5; per 8-deep k-step 5 raw reads + 3 weight reads + 48 VALU feed 12 MFMAs; the triples meet in the
+// epilogue through LDS.  One superstage of six sub-chunks (6 x 96 rows x 128 B = 72 KiB, two blocks per CU), ping-pong
+// schedule as wino_tile<true>.  Block tiles 64 tiles x 32 channels or 32 tiles x 64 channels (= 128 output pixels x 64 / 256 x 32).
+template <int HBT, int HBN>
+__device__ __forceinline__ void wino43_tile(const GemmArgs& p, const int bid, float* __restrict__ lds) {
+#ifdef CAPF_DIAG
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+    const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    WINO_STAMP(dbg_t0);
+    constexpr int RPR = 32;
+    constexpr int RA = HBT / RPR, RB = HBN / RPR, NSUBLOAD = RA + RB;
+    constexpr int HSUB = (HBT + HBN) * WBK;
+    static_assert((HBT == 64 && HBN == 32) || (HBT == 32 && HBN == 64), "F(4,3) tiles");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nbn = (p.N + HBN - 1) / HBN;
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * HBT, n0 = tile_n * HBN;
+
+    const int srow = tid >> 3;
+    const int kq = (((tid & 7) ^ ((srow >> 1) & 7))) * 4;
+    const int CC = p.Cin / WBK;
+    const int nsc = 3 * CC;
+
+    constexpr unsigned OOB_A = 0x80000000u;
+    long a_base;
+    {
+        const int b = fast_div_w(m0, p.fd_hw), rem = m0 - b * p.Ho * p.Wo;
+        const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+        a_base = ((long)b * p.H * p.W + (long)(h - 1) * p.W + (4 * wt - 1)) * p.Cin;
+    }
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a_base), 0, 0x7FFFFF00u, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wp + (long)n0 * p.Kpad), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)p.Kpad * 4u, 0x00020000);
+    unsigned a_rel[RA], a_mask[RA];                      // mask bit kh * 8 + j
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int t = m0 + srow + RPR * i;
+        a_rel[i] = 0;
+        a_mask[i] = 0u;
+        if (t < p.M) {
+            const int b = fast_div_w(t, p.fd_hw), rem = t - b * p.Ho * p.Wo;
+            const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+            const int h0 = h - 1, w0 = 4 * wt - 1;
+            const long off = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            a_rel[i] = (unsigned)(off - a_base + kq) * 4u;
+            const int j_lo = max(0, -w0), j_hi = min(6, p.W - w0);
+            const int kh_lo = max(0, -h0), kh_hi = min(3, p.H - h0);
+            if (j_hi > j_lo && kh_hi > kh_lo) {
+                const unsigned wbits = ((1u << j_hi) - 1) & ~((1u << j_lo) - 1);
+                const unsigned below_hi = (1u << (kh_hi * 8)) - 1, below_lo = (1u << (kh_lo * 8)) - 1;
+                a_mask[i] = (wbits * 0x10101u) & below_hi & ~below_lo;
+            }
+        }
+    }
+    unsigned w_off[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) w_off[i] = (unsigned)((srow + RPR * i) * p.Kpad + kq) * 4u;
+
+    int u_kh = 0, u_cc = 0, u_j = 0;
+    unsigned voff[NSUBLOAD];
+    unsigned soff_a = 0;
+    auto prepare = [&]() {
+        const unsigned bit = u_kh < 3 ? (1u << (u_kh * 8 + u_j)) : 0u;
+        soff_a = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * p.W + u_j) * p.Cin + u_cc * WBK) * 4u);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) voff[i] = (a_mask[i] & bit) ? a_rel[i] : OOB_A;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            voff[RA + i] = w_off[i];
+            w_off[i] += WBK * 4u;
+        }
+        if (++u_j == 6) {
+            u_j = 0;
+            if (++u_cc == CC) { u_cc = 0; ++u_kh; }
+        }
+    };
+    auto fire = [&](int idx, int sub) {
+        float* As = lds + sub * HSUB;
+        if (idx < RA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(As + (idx * RPR + wave * 8) * WBK), 16, voff[idx], soff_a, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(As + HBT * WBK + ((idx - RA) * RPR + wave * 8) * WBK), 16,
+                                                     voff[idx], 0, 0, 0);
+    };
+    auto load_superchunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            prepare();
+#pragma unroll
+            for (int i = 0; i < NSUBLOAD; ++i) fire(i, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int pp = wave >> 1;                  // position triple
+    const int sub = wave & 1;                  // sub-tile
+    const int wm0 = HBT == 64 ? sub * 32 : 0;
+    const int wn0 = HBT == 64 ? 0 : sub * 32;
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    const int fhalf = lane >> 5;
+
+    load_superchunk();
+
+    f32x4 dn[5];                               // raw pixels d_pp .. d_pp+4 of the next k-step
+    f32x4 v[2][3], uf[2][3];
+    const float* const a_ptr = lds + (wm0 + frow) * WBK + pp * HSUB;
+    const float* const b_ptr = lds + HBT * WBK + (wn0 + frow) * WBK + 3 * pp * HSUB;
+    auto rd_a = [&](int q, int j) { dn[j] = *reinterpret_cast<const f32x4*>(a_ptr + j * HSUB + q * 4); };
+    auto rd_b = [&](int q, int j, int buf) { uf[buf][j] = *reinterpret_cast<const f32x4*>(b_ptr + j * HSUB + q * 4); };
+    // one (position, k sub-step) unit of the input transform: which = 0, 1, 2 = this wave's first / second / third position
+    // (triple 0: p0 p1 p2 on d0..d4; triple 1: p3 p4 p5 on d1..d5), 5 VALU each — small enough to ride in an MFMA shadow
+    auto xform1 = [&](int which, int e, int buf) {
+        const float x0 = dn[0][e], x1 = dn[1][e], x2 = dn[2][e], x3 = dn[3][e], x4 = dn[4][e];
+        if (pp == 0) {
+            if (which == 0) v[buf][0][e] = (4.0f * x0 - 5.0f * x2) + x4;
+            else if (which == 1) v[buf][1][e] = (x3 + x4) - 4.0f * (x1 + x2);
+            else v[buf][2][e] = 4.0f * (x1 - x2) + (x4 - x3);
+        } else {
+            if (which == 0) v[buf][0][e] = 2.0f * (x2 - x0) + (x3 - x1);
+            else if (which == 1) v[buf][1][e] = 2.0f * (x0 - x2) + (x3 - x1);
+            else v[buf][2][e] = (4.0f * x0 - 5.0f * x2) + x4;
+        }
+    };
+    auto xform = [&](int which, int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xform1(which, e, buf);
+    };
+    auto first_frags = [&]() {
+        const int q0 = fhalf ^ fsw;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) rd_a(q0, j);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rd_b(q0, j, 0);
+        xform(0, 0); xform(1, 0); xform(2, 0);
+    };
+    first_frags();
+    WINO_STAMP(dbg_t1);
+
+    // epilogue operands of the two register groups this wave finishes (g = 2 pp, 2 pp + 1), four output pixels each
+    const int t = m0 + wm0 + (lane & 31);
+    const bool t_ok = t < p.M;
+    const long o_row = (long)(4 * t) * p.omap.S1 + p.omap.off;
+    const long r_row = (long)(4 * t) * p.rmap.S1 + p.rmap.off;
+    f32x4 bv[2], rr[2][4];
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * (2 * pp + k);
+            bv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rr[k][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {
+                if (p.bias) bv[k] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.res && t_ok) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) rr[k][o] = *reinterpret_cast<const f32x4*>(p.res + r_row + (long)o * p.rmap.S1 + n);
+                }
+            }
+        }
+    };
+
+    for (int sc = 0; sc < nsc; ++sc) {
+        if (sc == nsc - 1) load_epilogue_operands();
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int fb = step & 1, nb = fb ^ 1;
+            const int q_next = ((step + 1) * 2 + fhalf) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int pq = i % 3, e = i / 3;
+                acc[pq] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[fb][pq][e], v[fb][pq][e], acc[pq], 0, 0, 0);
+                if (step < 3) {
+                    if (i == 0) { rd_a(q_next, 0); rd_a(q_next, 1); }
+                    else if (i == 1) { rd_a(q_next, 2); rd_a(q_next, 3); }
+                    else if (i == 2) { rd_a(q_next, 4); rd_b(q_next, 0, nb); }
+                    else if (i == 3) { rd_b(q_next, 1, nb); rd_b(q_next, 2, nb); }
+                    else if (i >= 6) {                 // 12 transform units over slots 6..11, two per slot
+                        const int u0 = (i - 6) * 2, u1 = u0 + 1;
+                        xform1(u0 / 4, u0 % 4, nb);
+                        xform1(u1 / 4, u1 % 4, nb);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (sc + 1 < nsc) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_superchunk();
+            first_frags();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WINO_STAMP(dbg_t2);
+    __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
+
+    // partial output transform of this wave's triple (s[o] = contribution to output pixel o):
+    //   triple 0 (m0 m1 m2): m0 + (m1 + m2),  m1 - m2,        m1 + m2,        m1 - m2
+    //   triple 1 (m3 m4 m5): m3 + m4,         2 (m3 - m4),    4 (m3 + m4),    8 (m3 - m4) + m5
+    auto partial = [&](int g, int o, int e) -> float {
+        const float a0 = acc[0][4 * g + e], a1 = acc[1][4 * g + e], a2 = acc[2][4 * g + e];
+        if (pp == 0) {
+            if (o == 0) return a0 + (a1 + a2);
+            if (o == 2) return a1 + a2;
+            return a1 - a2;
+        }
+        if (o == 0) return a0 + a1;
+        if (o == 1) return 2.0f * (a0 - a1);
+        if (o == 2) return 4.0f * (a0 + a1);
+        return 8.0f * (a0 - a1) + a2;
+    };
+    float* const xch = lds;                    // [sub][writer pp][8 slots][64 lanes] f32x4 = 32 KiB
+    {
+        float* dst = xch + (((sub * 2 + pp) * 8) * 64 + lane) * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int g = 2 * (pp ^ 1) + k;    // a group the partner finishes
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                f32x4 sv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[e] = partial(g, o, e);
+                *reinterpret_cast<f32x4*>(dst + (4 * k + o) * 64 * 4) = sv;
+            }
+        }
+    }
+    __syncthreads();
+    const float* src = xch + (((sub * 2 + (pp ^ 1)) * 8) * 64 + lane) * 4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int g = 2 * pp + k;
+        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4 other = *reinterpret_cast<const f32x4*>(src + (4 * k + o) * 64 * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mine = partial(g, o, e);
+                // fixed order whichever wave finishes the group: (triple 0 partial) + (triple 1 partial)
+                float sv = (pp == 0 ? mine + other[e] : other[e] + mine) + bv[k][e] + rr[k][o][e];
+                if (p.act == ACT_RELU) sv = fmaxf(sv, 0.f);
+                y[e] = sv;
+            }
+            if (t_ok && n < p.N) *reinterpret_cast<f32x4*>(p.out + o_row + (long)o * p.omap.S1 + n) = y;
+        }
+    }
+#ifdef CAPF_DIAG
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = capf_wino_timeline + (size_t)blockIdx.x * 8;
+        d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = dbg_r0; d[5] = 0; d[6] = 0; d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+#endif
+
 __device__ __forceinline__ int xcd_remap_w(int b, int nblk) {   // see igemm_f32.hip :: xcd_remap
     const int q = nblk >> 3, r = nblk & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-// tile configuration of a problem: 0 = 64 tiles x 64 channels, 1 = 64 x 32, 2 = 32 x 64
+// tile configuration of a problem: F(2,3): 0 = 64 tiles x 64 channels, 1 = 64 x 32, 2 = 32 x 64; F(4,3): 3 = 64 x 32, 4 = 32 x 64
 #if defined(__HIP_DEVICE_COMPILE__)
 template <bool PP>
 __device__ __forceinline__ void wino_dispatch(const GemmArgs& p, int cfg, int bid, float* lds) {
     if (cfg == 1) wino_tile_h<64, 32>(p, bid, lds);
     else if (cfg == 2) wino_tile_h<32, 64>(p, bid, lds);
+    else if (cfg == 3) wino43_tile<64, 32>(p, bid, lds);
+    else if (cfg == 4) wino43_tile<32, 64>(p, bid, lds);
     else wino_tile<PP>(p, bid, lds);
 }
 #endif
@@ -632,49 +925,64 @@ __global__ __launch_bounds__(256) void igemm_wino_group_kernel(WinoGroupArgs ga)
 // ---- weights: BN fold + G transform, packed [Cout][(kh, chunk, p, c)] (K'' = 12 Cin) ----------------------------------
 __global__ void pack_conv_wino_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                      float* __restrict__ Wp, float* __restrict__ bias, int Cout, int Cin) {
-    const int Kw = 12 * Cin, CC = Cin / WBK;
+                                      float* __restrict__ Wp, float* __restrict__ bias, int Cout, int Cin, int NP) {
+    const int Kw = 3 * NP * Cin, CC = Cin / WBK;          // NP = 4: F(2,3), 6: F(4,3)
     const long total = (long)Cout * Kw;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kw), k = (int)(i - (long)n * Kw);
-        const int cl = k % WBK, pq = (k / WBK) % 4, cc = (k / (4 * WBK)) % CC, kh = k / (4 * WBK * CC);
+        const int cl = k % WBK, pq = (k / WBK) % NP, cc = (k / (NP * WBK)) % CC, kh = k / (NP * WBK * CC);
         const int c = cc * WBK + cl;
         const float sc = gamma ? gamma[n] / sqrtf(var[n] + eps) : 1.f;
         const float* g = w + (((long)n * Cin + c) * 3 + kh) * 3;
         const float g0 = g[0] * sc, g1 = g[1] * sc, g2 = g[2] * sc;
         float u;
-        if (pq == 0) u = g0;
-        else if (pq == 1) u = 0.5f * ((g0 + g1) + g2);
-        else if (pq == 2) u = 0.5f * ((g0 - g1) + g2);
-        else u = g2;
+        if (NP == 4) {
+            if (pq == 0) u = g0;
+            else if (pq == 1) u = 0.5f * ((g0 + g1) + g2);
+            else if (pq == 2) u = 0.5f * ((g0 - g1) + g2);
+            else u = g2;
+        } else {
+            if (pq == 0) u = 0.25f * g0;
+            else if (pq == 1) u = -((g0 + g1) + g2) / 6.0f;
+            else if (pq == 2) u = -((g0 - g1) + g2) / 6.0f;
+            else if (pq == 3) u = (g0 / 24.0f + g1 / 12.0f) + g2 / 6.0f;
+            else if (pq == 4) u = (g0 / 24.0f - g1 / 12.0f) + g2 / 6.0f;
+            else u = g2;
+        }
         Wp[i] = u;
         if (k == 0 && bias) bias[n] = gamma ? beta[n] - mean[n] * sc : 0.f;
     }
 }
 
+// variant 23: F(2,3), Wp [Cout][12 Cin]; 43: F(4,3), Wp [Cout][18 Cin]
 hipError_t launch_pack_conv_wino(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
-                                 float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s) {
-    if (Cin % WBK != 0) return hipErrorInvalidValue;
-    const long total = (long)Cout * 12 * Cin;
+                                 float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s, int variant) {
+    if (Cin % WBK != 0 || (variant != 23 && variant != 43)) return hipErrorInvalidValue;
+    const int NP = variant == 43 ? 6 : 4;
+    const long total = (long)Cout * 3 * NP * Cin;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(pack_conv_wino_kernel, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, Wp, bias, Cout, Cin);
+    hipLaunchKernelGGL(pack_conv_wino_kernel, dim3(blocks), dim3(256), 0, s, w, gamma, beta, mean, var, eps, Wp, bias, Cout, Cin, NP);
     return hipGetLastError();
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
+// the variant rides in the packed-weight pitch: Kpad == 18 Cin -> F(4,3) (needs W % 4 == 0), otherwise F(2,3) (even W)
+static bool is43(const GemmArgs& a) { return a.Kpad == 18 * a.Cin; }
+
 bool gemm_wino_ok(const GemmArgs& a) {
-    return a.conv && a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin % WBK == 0 && (a.W & 1) == 0 && (a.N & 3) == 0 &&
-           a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale && a.act != ACT_GELU && !a.out_bf16 && a.H == a.Ho && a.W == a.Wo;
+    return a.conv && a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin % WBK == 0 && (a.W % (is43(a) ? 4 : 2)) == 0 && (a.N & 3) == 0 &&
+           a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale && a.act != ACT_GELU && !a.out_bf16 && a.H == a.Ho && a.W == a.Wo &&
+           (a.Kpad == 12 * a.Cin || a.Kpad == 18 * a.Cin);
 }
 
-// rewrite a direct-conv problem description into the tile-grid form wino_tile expects; false if out of range
+// rewrite a direct-conv problem description into the tile-grid form the tile functions expect; false if out of range
 static bool wino_prepare(GemmArgs& a) {
     if (!gemm_wino_ok(a)) return false;
-    const long tiles = (long)(a.M / (a.Ho * a.Wo)) * a.H * (a.W / 2);
+    const int px = is43(a) ? 4 : 2;
+    const long tiles = (long)(a.M / (a.Ho * a.Wo)) * a.H * (a.W / px);
     if ((double)a.M * (double)a.omap.S1 >= 4.0e9 || tiles > 0x7fffffffL) return false;
-    a.Wo = a.W / 2;                         // tile grid: H x W/2
+    a.Wo = a.W / px;                        // tile grid: H x W/px
     a.M = (int)tiles;
-    a.Kpad = 12 * a.Cin;
     a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
     a.fd_wo = make_fastdiv((unsigned)a.Wo);
     return true;
@@ -689,7 +997,7 @@ static hipError_t wino_attr() {
         }
         const void* half[] = {reinterpret_cast<const void*>(igemm_wino_kernel<true>), reinterpret_cast<const void*>(igemm_wino_group_kernel<true>)};
         for (const void* f : half) {
-            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS / 2 * (int)sizeof(float));
+            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * (64 + 32) * WBK * (int)sizeof(float));
             if (r != hipSuccess) return r;
         }
         return hipSuccess;
@@ -703,11 +1011,14 @@ static int wino_mode() {
     return m;
 }
 
-static const int kWT[3] = {64, 64, 32}, kWN[3] = {64, 32, 64};
+static const int kWT[5] = {64, 64, 32, 64, 32}, kWN[5] = {64, 32, 64, 32, 64};
+static const int kWLDS[5] = {WLDS / 2, 4 * (64 + 32) * WBK, 4 * (64 + 32) * WBK, 6 * (64 + 32) * WBK, 6 * (64 + 32) * WBK};   // floats
 
-// tile configuration for a prepared problem (a.M = tiles): narrow outputs -> 64 x 32; few tiles -> 32 x 64 (twice the blocks)
+// tile configuration for a prepared problem (a.M = tiles).  F(2,3): narrow outputs -> 64 x 32; few tiles -> 32 x 64 (twice the
+// blocks).  F(4,3): 32 tiles x 64 channels, or 64 x 32 for outputs that are not a multiple of 64 wide.
 static int wino_cfg(const GemmArgs& a) {
     static const int forced = [] { const char* e = getenv("CAPF_WINO_CFG"); return e ? atoi(e) : -1; }();   // tuning only
+    if (is43(a)) return a.N % 64 != 0 ? 3 : 4;
     if (forced == 1 || (forced == 2 && a.N % 64 == 0)) return forced;
     if (a.N % 64 != 0) return 1;
     const long blocks = (long)((a.M + 63) / 64) * (a.N / 64);
@@ -724,11 +1035,11 @@ hipError_t launch_gemm_wino(const GemmArgs& a_in, hipStream_t s) {
     const int cfg = wino_cfg(a);
     const int nb = wino_tiles(a, cfg);
     if (wino_mode() == 1) hipLaunchKernelGGL(igemm_wino_kernel<false>, dim3(nb), dim3(256), WLDS * sizeof(float), s, a, cfg);
-    else hipLaunchKernelGGL(igemm_wino_kernel<true>, dim3(nb), dim3(256), (cfg == 0 ? WLDS / 2 : 4 * (64 + 32) * WBK) * sizeof(float), s, a, cfg);
+    else hipLaunchKernelGGL(igemm_wino_kernel<true>, dim3(nb), dim3(256), kWLDS[cfg] * sizeof(float), s, a, cfg);
     return hipGetLastError();
 }
 
-const char* gemm_wino_kernel_name() { return "igemm_wino<w4,F(2,3)>"; }
+const char* gemm_wino_kernel_name() { return "igemm_wino<w4,F(2,3)/F(4,3)>"; }
 
 hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
@@ -739,13 +1050,13 @@ hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
     struct Item { int idx, cfg, tiles; double cost; };
     Item it[MAXG];
     GemmArgs prep[MAXG];
-    bool any_full = false;
+    int lds_floats = 0;
     for (int i = 0; i < n; ++i) {
         prep[i] = list[i];
         if (!wino_prepare(prep[i])) return hipErrorInvalidValue;
         const int cfg = wino_cfg(prep[i]);
-        any_full |= cfg == 0;
-        it[i] = Item{i, cfg, wino_tiles(prep[i], cfg), (double)prep[i].Cin * kWT[cfg] * kWN[cfg]};
+        lds_floats = std::max(lds_floats, kWLDS[cfg]);
+        it[i] = Item{i, cfg, wino_tiles(prep[i], cfg), (double)prep[i].Cin * kWT[cfg] * kWN[cfg] * (cfg >= 3 ? 1.5 : 1.0)};
     }
     for (int i = 1; i < n; ++i)                  // longest tile first
         for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
@@ -762,7 +1073,7 @@ hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
     if (wino_mode() == 1) hipLaunchKernelGGL(igemm_wino_group_kernel<false>, dim3(start), dim3(256), WLDS * sizeof(float), s, ga);
-    else hipLaunchKernelGGL(igemm_wino_group_kernel<true>, dim3(start), dim3(256), (any_full ? WLDS / 2 : 4 * (64 + 32) * WBK) * sizeof(float), s, ga);
+    else hipLaunchKernelGGL(igemm_wino_group_kernel<true>, dim3(start), dim3(256), lds_floats * sizeof(float), s, ga);
     return hipGetLastError();
 }
 

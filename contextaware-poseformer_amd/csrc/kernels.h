@@ -68,7 +68,7 @@ hipError_t launch_gemm_wino(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_wino_kernel_name();
 hipError_t launch_pack_conv_wino(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
-                                 float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s);
+                                 float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s, int variant = 23);
 
 // conv weight fold + pack:  Wp[n][(kh*ks+kw)*Cin+ci] = w[n][ci][kh][kw] * gamma[n]/sqrt(var[n]+eps)
 //                            bias[n] = beta[n] - mean[n]*gamma[n]/sqrt(var[n]+eps)

@@ -123,7 +123,9 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     // 64 x 32 (32-channel outputs) or 32 x 64 (few tiles) are chosen per problem at launch
     const bool use_wino = this->use_wino && !use_bf16 && ks == 3 && stride == 1 && x.C % 32 == 0 && x.W % 2 == 0 && Cout % 32 == 0;
     pk.wino = use_wino;
-    if (use_wino) { pk.Kpad2 = pk.Kpad; pk.Kpad = 12 * x.C; }
+    // F(4,3) (half the MFMAs of the direct conv) where the row length allows four-pixel tiles, F(2,3) (two thirds) otherwise.
+    // HRNet only: F(4,3) pays inside the grouped multi-branch launches (+3.2 % end to end), not for CPN's lone convs (-0.8 %).
+    if (use_wino) { pk.Kpad2 = pk.Kpad; pk.Kpad = ((x.W % 4 == 0 && wino_f43 && cfg.backbone == CAPF_HRNET && x.H * x.W >= wino_f43_min_hw && x.H * x.W <= wino_f43_max_hw) ? 18 : 12) * x.C; }
     packs.push_back(pk);
 
     Op op;
@@ -852,6 +854,9 @@ bool Engine::build() {
     if (const char* fz = getenv("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;      // A/B runs only
     if (const char* wz = getenv("CAPF_WINO")) use_wino = atoi(wz) != 0;                  // A/B runs only
     if (const char* wb = getenv("CAPF_WINO_MIN_BATCH")) wino_min_batch = atoi(wb);
+    if (const char* wf = getenv("CAPF_WINO_F43")) wino_f43 = atoi(wf) != 0;               // A/B runs only
+    if (const char* wf = getenv("CAPF_WINO_F43_MINHW")) wino_f43_min_hw = atoi(wf);
+    if (const char* wf = getenv("CAPF_WINO_F43_MAXHW")) wino_f43_max_hw = atoi(wf);
     Tensor img{EXT_IMAGES, cfg.height, cfg.width, 3};
     Tensor feats[4];
     if (cfg.backbone == CAPF_HRNET) {

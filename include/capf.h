@@ -208,15 +208,16 @@ typedef struct capf_conv_desc {
     int32_t B, H, W, Cin, Cout, ks, stride, act;
 } capf_conv_desc;
 int capf_op_conv_group(void* stream, int n, const capf_conv_desc* convs);
-/* The same 3x3 / stride-1 / pad-1 convolution through the Winograd F(2,3)-along-W kernel (csrc/igemm_wino.hip: 1.5x fewer
- * MFMAs, results equal to the direct kernel's to fp32 roundoff).  capf_op_pack_conv_wino folds BatchNorm like
- * capf_op_pack_conv and applies the weight transform: wp [Cout][12 * Cin].  Needs Cin % 32 == 0, even W, Cout % 4 == 0
- * (CAPF_ERR_UNSUPPORTED otherwise).  capf_op_conv_wino_group: up to 8 such convs in one grid (capf_conv_desc with ks 3, stride 1). */
+/* The same 3x3 / stride-1 / pad-1 convolution through the Winograd-along-W kernels (csrc/igemm_wino.hip), results equal to
+ * the direct kernel's to fp32 roundoff.  variant 23: F(2,3), 1.5x fewer MFMAs, wp [Cout][12 * Cin], even W;  variant 43:
+ * F(4,3), 2x fewer MFMAs, wp [Cout][18 * Cin], W % 4 == 0.  capf_op_pack_conv_wino folds BatchNorm like capf_op_pack_conv
+ * and applies the weight transform.  Needs Cin % 32 == 0, Cout % 4 == 0 (CAPF_ERR_UNSUPPORTED otherwise).
+ * capf_op_conv_wino_group: up to 8 such convs of one variant in one grid (capf_conv_desc with ks 3, stride 1). */
 int capf_op_pack_conv_wino(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
-                           const float* var, float eps, float* wp, float* bias, int Cout, int Cin);
+                           const float* var, float eps, float* wp, float* bias, int Cout, int Cin, int variant);
 int capf_op_conv_wino(void* stream, const float* x, const float* wp, const float* bias, const float* residual, float* y, int B,
-                      int H, int W, int Cin, int Cout, int act);
-int capf_op_conv_wino_group(void* stream, int n, const capf_conv_desc* d);
+                      int H, int W, int Cin, int Cout, int act, int variant);
+int capf_op_conv_wino_group(void* stream, int n, const capf_conv_desc* d, int variant);
 int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual,
                    float* y, int M, int N, int K, int act);
 /* bf16 twins (igemm_bf16.hip, v_mfma_f32_32x32x16_bf16): x / residual / y are bf16 NHWC, w_packed is bf16

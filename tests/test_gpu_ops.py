@@ -103,6 +103,30 @@ def test_winograd_conv_matches_torch(ci, co, H, W, B, act, res):
     assert err < 3e-5 * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("ci,co,H,W,B,act,res", [(64, 64, 32, 32, 2, 1, True), (32, 32, 16, 64, 3, 1, False), (128, 128, 8, 8, 5, 0, True),
+                                                 (96, 96, 6, 12, 2, 1, True), (256, 64, 4, 4, 3, 1, False), (64, 160, 12, 8, 2, 1, True)])
+def test_winograd_f43_conv_matches_torch(ci, co, H, W, B, act, res):
+    """The selectable F(4,3)-along-W variant (four-pixel tiles, six positions; not in the default plan): same comparison,
+    tolerance 1e-4 relative (its transform constants reach 8 and 1/24; measured 1.3e-5 .. 2.9e-5)."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(ci + co * 5 + H + W)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5
+    bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+           torch.rand(co, generator=g) * 0.4 + 0.8)
+    want = F.batch_norm(F.conv2d(x, w, None, 1, 1), bnp[2], bnp[3], bnp[0], bnp[1], False, 0.0, 1e-5)
+    r = torch.randn_like(want) if res else None
+    if res:
+        want = want + r
+    if act == 1:
+        want = F.relu(want)
+    wp, bias = capf.pack_conv_wino(w.cuda(), tuple(t.cuda() for t in bnp), variant=43)
+    got = capf.conv_nhwc_wino(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
+                              r.permute(0, 2, 3, 1).contiguous().cuda() if res else None).cpu().permute(0, 3, 1, 2)
+    err = (got - want).abs().max().item()
+    assert err < 1e-4 * max(1.0, want.abs().max().item()), err
+
+
 def test_grouped_winograd_launch_is_bit_identical_to_single_launches():
     from capf import lib as capf
     g = torch.Generator().manual_seed(3)
