@@ -470,13 +470,13 @@ __device__ __forceinline__ void wino_tile_h(const GemmArgs& p, const int bid, fl
     auto rd_a = [&](int q, int j) { dn[j] = *reinterpret_cast<const f32x4*>(a_ptr + j * HSUB + q * 4); };
     auto rd_b = [&](int q, int j, int buf) { uf[buf][j] = *reinterpret_cast<const f32x4*>(b_ptr + j * HSUB + q * 4); };
     // B^T d for this wave's two positions: pp = 0: (d0 - d2, d1 + d2); pp = 1 (dn = d1, d2, d3): (d2 - d1, d1 - d3)
+    float cf[2][3];                            // B^T rows of this wave's pair as wave-uniform scalars (no per-lane selects)
+    cf[0][0] = pp == 0 ? 1.f : -1.f; cf[0][1] = pp == 0 ? 0.f : 1.f; cf[0][2] = pp == 0 ? -1.f : 0.f;      // d0 - d2 | d2 - d1
+    cf[1][0] = pp == 0 ? 0.f : 1.f;  cf[1][1] = pp == 0 ? 1.f : 0.f; cf[1][2] = pp == 0 ? 1.f : -1.f;      // d1 + d2 | d1 - d3
     auto xform = [&](int which, int buf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x0 = dn[0][e], x1 = dn[1][e], x2 = dn[2][e];
-            if (which == 0) v[buf][0][e] = pp == 0 ? x0 - x2 : x1 - x0;
-            else v[buf][1][e] = pp == 0 ? x1 + x2 : x0 - x2;
-        }
+        for (int e = 0; e < 4; ++e)
+            v[buf][which][e] = (cf[which][0] * dn[0][e] + cf[which][1] * dn[1][e]) + cf[which][2] * dn[2][e];
     };
     auto first_frags = [&]() {
         const int q0 = fhalf ^ fsw;
@@ -540,28 +540,30 @@ __device__ __forceinline__ void wino_tile_h(const GemmArgs& p, const int bid, fl
     __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
 
     // partial output transform:  pp = 0: (s0, s1) = (m0 + m1, m1);  pp = 1: (m2, -(m2 + m3));  y0 = s0 + s0', y1 = s1 + s1'
+    const float q00 = 1.f, q01 = pp == 0 ? 1.f : 0.f, q10 = pp == 0 ? 0.f : -1.f, q11 = pp == 0 ? 1.f : -1.f;   // wave-uniform
     float* const xch = lds;                    // [sub][writer pp][4 slots][64 lanes] f32x4 = 16 KiB
     {
         float* dst = xch + (((sub * 2 + pp) * 4) * 64 + lane) * 4;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int g = 2 * (pp ^ 1) + k;    // a group the partner finishes
+        for (int g = 0; g < 4; ++g) {
+            if ((g >> 1) == pp) continue;      // (wave-uniform) a group this wave finishes itself
             f32x4 s0, s1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x = acc[0][4 * g + e], y = acc[1][4 * g + e];
-                s0[e] = pp == 0 ? x + y : x;
-                s1[e] = pp == 0 ? y : -(x + y);
+                s0[e] = q00 * x + q01 * y;
+                s1[e] = q10 * x + q11 * y;
             }
-            *reinterpret_cast<f32x4*>(dst + (2 * k + 0) * 64 * 4) = s0;
-            *reinterpret_cast<f32x4*>(dst + (2 * k + 1) * 64 * 4) = s1;
+            *reinterpret_cast<f32x4*>(dst + (2 * (g & 1) + 0) * 64 * 4) = s0;
+            *reinterpret_cast<f32x4*>(dst + (2 * (g & 1) + 1) * 64 * 4) = s1;
         }
     }
     __syncthreads();
     const float* src = xch + (((sub * 2 + (pp ^ 1)) * 4) * 64 + lane) * 4;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int g = 2 * pp + k;
+    for (int g = 0; g < 4; ++g) {
+        if ((g >> 1) != pp) continue;
+        const int k = g & 1;
         const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
         const f32x4 o0 = *reinterpret_cast<const f32x4*>(src + (2 * k + 0) * 64 * 4);
         const f32x4 o1 = *reinterpret_cast<const f32x4*>(src + (2 * k + 1) * 64 * 4);
@@ -569,7 +571,7 @@ __device__ __forceinline__ void wino_tile_h(const GemmArgs& p, const int bid, fl
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = acc[0][4 * g + e], y = acc[1][4 * g + e];
-            const float m_s0 = pp == 0 ? x + y : x, m_s1 = pp == 0 ? y : -(x + y);
+            const float m_s0 = q00 * x + q01 * y, m_s1 = q10 * x + q11 * y;
             // fixed order whichever wave finishes the group: (pair 0 partial) + (pair 1 partial)
             float s0 = (pp == 0 ? m_s0 + o0[e] : o0[e] + m_s0) + bv[k][e] + r0[k][e];
             float s1 = (pp == 0 ? m_s1 + o1[e] : o1[e] + m_s1) + bv[k][e] + r1[k][e];
@@ -726,17 +728,19 @@ __device__ __forceinline__ void wino43_tile(const GemmArgs& p, const int bid, fl
     auto rd_b = [&](int q, int j, int buf) { uf[buf][j] = *reinterpret_cast<const f32x4*>(b_ptr + j * HSUB + q * 4); };
     // one (position, k sub-step) unit of the input transform: which = 0, 1, 2 = this wave's first / second / third position
     // (triple 0: p0 p1 p2 on d0..d4; triple 1: p3 p4 p5 on d1..d5), 5 VALU each — small enough to ride in an MFMA shadow
+    // B^T rows of this wave's triple as wave-uniform scalars (SGPRs): no per-lane select between the two triples' formulas
+    float cf[3][5];
+    {
+        const float t0[3][5] = {{4.f, 0.f, -5.f, 0.f, 1.f}, {0.f, -4.f, -4.f, 1.f, 1.f}, {0.f, 4.f, -4.f, -1.f, 1.f}};     // p0 p1 p2 on d0..d4
+        const float t1[3][5] = {{-2.f, -1.f, 2.f, 1.f, 0.f}, {2.f, -1.f, -2.f, 1.f, 0.f}, {4.f, 0.f, -5.f, 0.f, 1.f}};     // p3 p4 p5 on d1..d5
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) cf[a][b] = pp == 0 ? t0[a][b] : t1[a][b];
+    }
     auto xform1 = [&](int which, int e, int buf) {
         const float x0 = dn[0][e], x1 = dn[1][e], x2 = dn[2][e], x3 = dn[3][e], x4 = dn[4][e];
-        if (pp == 0) {
-            if (which == 0) v[buf][0][e] = (4.0f * x0 - 5.0f * x2) + x4;
-            else if (which == 1) v[buf][1][e] = (x3 + x4) - 4.0f * (x1 + x2);
-            else v[buf][2][e] = 4.0f * (x1 - x2) + (x4 - x3);
-        } else {
-            if (which == 0) v[buf][0][e] = 2.0f * (x2 - x0) + (x3 - x1);
-            else if (which == 1) v[buf][1][e] = 2.0f * (x0 - x2) + (x3 - x1);
-            else v[buf][2][e] = (4.0f * x0 - 5.0f * x2) + x4;
-        }
+        v[buf][which][e] = ((cf[which][0] * x0 + cf[which][1] * x1) + (cf[which][2] * x2 + cf[which][3] * x3)) + cf[which][4] * x4;
     };
     auto xform = [&](int which, int buf) {
 #pragma unroll
@@ -815,38 +819,39 @@ __device__ __forceinline__ void wino43_tile(const GemmArgs& p, const int bid, fl
     // partial output transform of this wave's triple (s[o] = contribution to output pixel o):
     //   triple 0 (m0 m1 m2): m0 + (m1 + m2),  m1 - m2,        m1 + m2,        m1 - m2
     //   triple 1 (m3 m4 m5): m3 + m4,         2 (m3 - m4),    4 (m3 + m4),    8 (m3 - m4) + m5
-    auto partial = [&](int g, int o, int e) -> float {
-        const float a0 = acc[0][4 * g + e], a1 = acc[1][4 * g + e], a2 = acc[2][4 * g + e];
-        if (pp == 0) {
-            if (o == 0) return a0 + (a1 + a2);
-            if (o == 2) return a1 + a2;
-            return a1 - a2;
-        }
-        if (o == 0) return a0 + a1;
-        if (o == 1) return 2.0f * (a0 - a1);
-        if (o == 2) return 4.0f * (a0 + a1);
-        return 8.0f * (a0 - a1) + a2;
+    float qf[4][3];                            // A^T columns of this wave's triple, wave-uniform
+    {
+        const float t0[4][3] = {{1.f, 1.f, 1.f}, {0.f, 1.f, -1.f}, {0.f, 1.f, 1.f}, {0.f, 1.f, -1.f}};
+        const float t1[4][3] = {{1.f, 1.f, 0.f}, {2.f, -2.f, 0.f}, {4.f, 4.f, 0.f}, {8.f, -8.f, 1.f}};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) qf[a][b] = pp == 0 ? t0[a][b] : t1[a][b];
+    }
+    auto partial = [&](int g, int o, int e) -> float {      // g, o, e are compile-time after unrolling: static register indices
+        return (qf[o][0] * acc[0][4 * g + e] + qf[o][1] * acc[1][4 * g + e]) + qf[o][2] * acc[2][4 * g + e];
     };
     float* const xch = lds;                    // [sub][writer pp][8 slots][64 lanes] f32x4 = 32 KiB
     {
         float* dst = xch + (((sub * 2 + pp) * 8) * 64 + lane) * 4;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int g = 2 * (pp ^ 1) + k;    // a group the partner finishes
+        for (int g = 0; g < 4; ++g) {
+            if ((g >> 1) == pp) continue;      // (wave-uniform) a group this wave finishes itself
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 f32x4 sv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sv[e] = partial(g, o, e);
-                *reinterpret_cast<f32x4*>(dst + (4 * k + o) * 64 * 4) = sv;
+                *reinterpret_cast<f32x4*>(dst + (4 * (g & 1) + o) * 64 * 4) = sv;
             }
         }
     }
     __syncthreads();
     const float* src = xch + (((sub * 2 + (pp ^ 1)) * 8) * 64 + lane) * 4;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int g = 2 * pp + k;
+    for (int g = 0; g < 4; ++g) {
+        if ((g >> 1) != pp) continue;
+        const int k = g & 1;
         const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -891,7 +896,7 @@ __device__ __forceinline__ void wino_dispatch(const GemmArgs& p, int cfg, int bi
 #endif
 
 template <bool PP>
-__global__ __launch_bounds__(256) void igemm_wino_kernel(GemmArgs p, int cfg) {
+__global__ __launch_bounds__(256, 2) void igemm_wino_kernel(GemmArgs p, int cfg) {      // 2 blocks per CU: <= 256 registers per wave
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     wino_dispatch<PP>(p, cfg, xcd_remap_w(blockIdx.x, gridDim.x), wlds);
@@ -908,7 +913,7 @@ struct WinoGroupArgs {
 };
 
 template <bool PP>
-__global__ __launch_bounds__(256) void igemm_wino_group_kernel(WinoGroupArgs ga) {
+__global__ __launch_bounds__(256, 2) void igemm_wino_group_kernel(WinoGroupArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int b = blockIdx.x;
