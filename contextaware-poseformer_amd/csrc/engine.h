@@ -166,6 +166,7 @@ struct Engine {
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
     int wino_min_batch = 8;        // below this batch the Winograd-eligible convs run the direct kernel (B = 1: 305 vs 286 frames/s)
     bool wino_now(const Op& op, int batch) const { return op.wino && batch >= wino_min_batch; }
+    bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)

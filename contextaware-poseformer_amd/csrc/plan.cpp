@@ -125,7 +125,7 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     pk.wino = use_wino;
     // F(4,3) (half the MFMAs of the direct conv) where the row length allows four-pixel tiles, F(2,3) (two thirds) otherwise.
     // HRNet only: F(4,3) pays inside the grouped multi-branch launches (+3.2 % end to end), not for CPN's lone convs (-0.8 %).
-    if (use_wino) { pk.Kpad2 = pk.Kpad; pk.Kpad = ((x.W % 4 == 0 && wino_f43 && cfg.backbone == CAPF_HRNET && x.H * x.W >= wino_f43_min_hw && x.H * x.W <= wino_f43_max_hw) ? 18 : 12) * x.C; }
+    if (use_wino) { pk.Kpad2 = pk.Kpad; pk.Kpad = ((x.W % 4 == 0 && wino_f43 && (cfg.backbone == CAPF_HRNET || wino_f43_cpn) && x.H * x.W >= wino_f43_min_hw && x.H * x.W <= wino_f43_max_hw) ? 18 : 12) * x.C; }
     packs.push_back(pk);
 
     Op op;
@@ -856,6 +856,7 @@ bool Engine::build() {
     if (const char* wb = getenv("CAPF_WINO_MIN_BATCH")) wino_min_batch = atoi(wb);
     if (const char* wf = getenv("CAPF_WINO_F43")) wino_f43 = atoi(wf) != 0;               // A/B runs only
     if (const char* wf = getenv("CAPF_WINO_F43_MINHW")) wino_f43_min_hw = atoi(wf);
+    if (const char* wf = getenv("CAPF_WINO_F43_CPN")) wino_f43_cpn = atoi(wf) != 0;
     if (const char* wf = getenv("CAPF_WINO_F43_MAXHW")) wino_f43_max_hw = atoi(wf);
     Tensor img{EXT_IMAGES, cfg.height, cfg.width, 3};
     Tensor feats[4];
