@@ -18,6 +18,13 @@
 #include "kernels.h"
 
 namespace capf {
+#ifdef CAPF_DIAG   // (diagnosis build) per-block stamps {t_entry, t_prologue_done, t_loop_done, t_stores_issued, t_exit, realtime_entry, load_wait_ticks, realtime_exit}
+__device__ unsigned long long capf_bf16_timeline[8192 * 8];
+#define B16_STAMP(var) var = __builtin_amdgcn_s_memtime()
+#else
+#define B16_STAMP(var)
+#endif
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -74,6 +81,19 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CAPF_DIAG
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_w = 0, dbg_a = 0, dbg_b = 0;
+    const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    auto dbg_flush = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && blockIdx.x < 8192) {
+            unsigned long long* d = capf_bf16_timeline + (size_t)blockIdx.x * 8;
+            d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = dbg_t3; d[4] = __builtin_amdgcn_s_memtime();
+            d[5] = dbg_r0; d[6] = dbg_w; d[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+#endif
+    B16_STAMP(dbg_t0);
 
     const int nbn = (p.N + BN - 1) / BN;
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
@@ -189,7 +209,87 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
     const int fsw = (frow >> 1) & 7;
     const int fhalf = lane >> 5;
 
+    // Epilogue operands (residual rows, bias) in the coalesced epilogue's layout -- lane = 8 channels of one row, see below --
+    // are requested when the LAST chunk is: their latency (2-3 us under load, which used to be a quarter of a block's life at
+    // K = 9*48) hides behind that chunk's.
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const bool vec_ok = !OUTF32 && (p.N & 7) == 0 && (p.omap.S1 & 7) == 0 && (p.omap.off & 7) == 0 &&
+                        (!Rs || ((p.rmap.S1 & 7) == 0 && (p.rmap.off & 7) == 0));
+    const int er = lane >> 2, ec = (lane & 3) * 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rr[TM][TN][2];
+    f32x4 bb[TN][2];
+    auto prefetch_epilogue = [&]() {
+        if (!vec_ok) return;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + ec;
+            bb[j][0] = bb[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && (full || n < p.N)) {
+                bb[j][0] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                bb[j][1] = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = m0 + wm0 + i * 32 + h * 16 + er;
+                    rr[i][j][h] = u32x4{0u, 0u, 0u, 0u};
+                    if (Rs && (full || (m < p.M && n < p.N)))
+                        rr[i][j][h] = *reinterpret_cast<const u32x4*>(Rs + (long)m * p.rmap.S1 + p.rmap.off + n);
+                }
+        }
+    };
+
     constexpr int PER_STEP = (NLOAD + 1) / 2;
+    if constexpr (S == 1) {
+        // "ping-pong": ONE stage per block (24-32 KiB), so that 5-6 blocks are resident per CU.  A block alternates a load
+        // phase (all DMA instructions of a chunk, wait, barrier) and a compute phase (the chunk's MFMAs); the other resident
+        // blocks use the matrix pipe meanwhile.  At bf16 MFMA speed a 64-deep chunk is only 256 matrix cycles per wave
+        // against ~2500 cycles of load latency under traffic: what matters is how many chunks a CU has in flight (5 of 6
+        // slots here; 3 of 6 with the two-stage ring and three blocks).
+        bf16x8 af[2][TM], bfr[2][TN];
+        auto read_frags = [&](int step, int buf) {
+            const unsigned short* As = lds;
+            const unsigned short* Bs = As + BM * BKH;
+            const int q = ((step * 2) + fhalf) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[buf][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * BKH + q * 8]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[buf][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * BKH + q * 8]));
+        };
+        B16_STAMP(dbg_t1);
+        auto chunk = [&](int c) {
+            B16_STAMP(dbg_a);
+            prepare(c);
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) fire(i, 0);
+            wait_vmcnt_b<0>();
+            __builtin_amdgcn_s_barrier();
+#ifdef CAPF_DIAG
+            B16_STAMP(dbg_b);
+            dbg_w += dbg_b - dbg_a;
+#endif
+            read_frags(0, 0);
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                if (step < 3) read_frags(step + 1, (step + 1) & 1);
+                const int fb = step & 1;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[fb][j], af[fb][i], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // every wave has read the stage: the next chunk may overwrite it
+        };
+        for (int c = 0; c < nchunks - 1; ++c) chunk(c);
+        prefetch_epilogue();                           // (the last chunk is peeled so that these registers are not live in the loop)
+        if (nchunks > 0) chunk(nchunks - 1);
+    } else {
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) {
         prepare(s);
@@ -215,7 +315,7 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
     wait_vmcnt_b<(S - 2) * NLOAD>();
     __builtin_amdgcn_s_barrier();
     read_frags(0, 0, 0);
-    for (int c = 0; c < nchunks; ++c) {
+    auto ring_iter = [&](int c) {
         const int st_next = (st_read + 1 == S) ? 0 : st_read + 1;
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
@@ -244,24 +344,29 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
         }
         st_read = st_next;
         st_fill = (st_fill + 1 == S) ? 0 : st_fill + 1;
+    };
+    for (int c = 0; c < nchunks - 1; ++c) ring_iter(c);
+    prefetch_epilogue();
+    if (nchunks > 0) ring_iter(nchunks - 1);
     }
     wait_vmcnt_b<0>();
+    B16_STAMP(dbg_t2);
 
-    // ---- epilogue (transposed accumulator: lane = one row m, register group g = 4 consecutive channels).
-    // Every bias / residual load of the tile is issued before the first store (vmcnt retires in order).
-    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    long o_row[TM];
-    bool m_ok[TM];
-    f32x4 bv[TN][4];
+    // ---- epilogue.  Accumulator layout: lane = one row m (lane & 31), register group g = 4 consecutive channels
+    // (8 g + 4 (lane >> 5)).
+    if constexpr (OUTF32) {
+        // fp32 result + fp32 residual through the strided token maps (the lifter's proj / fc2): 16-byte stores per lane.
+        long o_row[TM];
+        bool m_ok[TM];
+        f32x4 bv[TN][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
-            bv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias && (full || n < p.N)) bv[j][g] = *reinterpret_cast<const f32x4*>(p.bias + n);
-        }
-    if (OUTF32) {
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                bv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && (full || n < p.N)) bv[j][g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            }
         f32x4 rf[TM][TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -290,41 +395,66 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                     for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + bv[j][g][e]) + rf[i][j][g][e];
                     if (m_ok[i] && (full || n < p.N)) *reinterpret_cast<f32x4*>(p.out + o_row[i] + n) = v;
                 }
-        return;
-    }
-    u16x4 rv[TM][TN][4];
+    } else {
+        // bf16 result, coalesced: in the accumulator layout a lane owns 4 channels of a row, i.e. 8-byte accesses at a row
+        // stride (16 B contiguous per row and instruction).  With K = 9*48 .. 9*384 a tile's K loop is only 7-54 chunks of
+        // 256 matrix cycles, and that epilogue -- with the residual's load latency in it -- was a quarter of a block's life
+        // (tools/bf16_timeline.py).  Instead each wave transposes its 32x32 fp32 blocks through its own 4.5 KiB of the (now
+        // idle) stage memory and finishes 8 channels of a row per lane: residual loads (prefetched above) and stores are 16 B
+        // per lane, 64 B contiguous per row, 16 rows per instruction.  Shapes the vector path cannot take (N % 8, unaligned
+        // strides) finish the same 8 channels element by element.
+        constexpr int EPS = 36;                            // padded row stride (floats): b128 accesses stay conflict-free
+        if (S != 1) __syncthreads();                       // ring schedule: other waves may still be reading the last stage
+        float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm0 + i * 32 + (lane & 31);
-        m_ok[i] = full || m < p.M;
-        o_row[i] = (long)m * p.omap.S1 + p.omap.off;
-        const long r_row = (long)m * p.rmap.S1 + p.rmap.off;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 32 + ec;
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
-                rv[i][j][g] = u16x4{0, 0, 0, 0};
-                if (Rs && m_ok[i] && (full || n < p.N)) rv[i][j][g] = *reinterpret_cast<const u16x4*>(Rs + r_row + n);
-            }
-    }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(&ep[(lane & 31) * EPS + 8 * g + 4 * (lane >> 5)]) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 16 + er, m = m0 + wm0 + i * 32 + row;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
+                    auto finish = [&](float t) {
+                        if (GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+                        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                        return (unsigned)f2bf(t);
+                    };
+                    if (vec_ok) {
+                        u32x4 o;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
-                u16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] + bv[j][g][e] + bf2f(rv[i][j][g][e]);
-                    if (GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
-                    if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-                    v[e] = f2bf(t);
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned rw = rr[i][j][h][q];
+                            const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+                            const float ba = q < 2 ? bb[j][0][2 * q] : bb[j][1][2 * q - 4];
+                            const float bc = q < 2 ? bb[j][0][2 * q + 1] : bb[j][1][2 * q - 3];
+                            o[q] = finish(xa + ba + __uint_as_float(rw << 16)) |
+                                   (finish(xb + bc + __uint_as_float(rw & 0xFFFF0000u)) << 16);
+                        }
+                        if (full || (m < p.M && n < p.N))
+                            *reinterpret_cast<u32x4*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = o;
+                    } else if (m < p.M) {
+                        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+                            const float x = e < 4 ? x0[e & 3] : x1[e & 3];
+                            const float bsv = p.bias ? p.bias[n + e] : 0.f;
+                            const float rsv = Rs ? bf2f(Rs[(long)m * p.rmap.S1 + p.rmap.off + n + e]) : 0.f;
+                            Out[(long)m * p.omap.S1 + p.omap.off + n + e] = (unsigned short)finish(x + bsv + rsv);
+                        }
+                    }
                 }
-                if (m_ok[i] && (full || n < p.N)) *reinterpret_cast<u16x4*>(Out + o_row[i] + n) = v;
             }
+    }
+#ifdef CAPF_DIAG
+    B16_STAMP(dbg_t3);
+    dbg_flush();
+#endif
 }
 #endif
 
@@ -336,7 +466,8 @@ __device__ __forceinline__ int xcd_remap_b(int b, int nblk) {   // see igemm_f32
 template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) unsigned short lds[S * (BM + BN) * BKH];
+    constexpr int HALVES = S * (BM + BN) * BKH < 4 * 32 * 36 * 2 ? 4 * 32 * 36 * 2 : S * (BM + BN) * BKH;   // >= the epilogue's 18 KiB
+    __shared__ __attribute__((aligned(16))) unsigned short lds[HALVES];
     igemm_bf16_tile<BM, BN, WM, WN, S, OUTF32, GELU>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
 #endif
 }
@@ -373,6 +504,35 @@ __global__ __launch_bounds__(256) void igemm_bf16_group_kernel(GroupArgsB ga) {
         default: igemm_bf16_tile<128, 32, 32, 32, CAPF_BF16_GROUP_STAGES>(p, bid, lds); break;
     }
 #endif
+}
+
+// ping-pong variant of the grouped kernel: one stage per block, 24 KiB, up to 5 blocks per CU (register cap 102)
+__global__ __launch_bounds__(256, 5) void igemm_bf16_group_pp_kernel(GroupArgsB ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned short lds[(128 + 64) * BKH];
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
+    const int l = b - ga.start[pi];
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int bid = (l & 7) * per_xcd + (l >> 3);
+    if (bid >= ga.tiles[pi]) return;
+    const GemmArgs& p = ga.g[pi];
+    switch (ga.cfg[pi]) {
+        case 0: igemm_bf16_tile<128, 64, 64, 32, 1>(p, bid, lds); break;
+        case 1: igemm_bf16_tile<64, 64, 32, 32, 1>(p, bid, lds); break;
+        default: igemm_bf16_tile<128, 32, 32, 32, 1>(p, bid, lds); break;
+    }
+#endif
+}
+
+// The ping-pong schedule needs other resident blocks to cover a block's load phase: it is used from this many tiles per
+// launch (8 per CU) and the ring schedule below.  Measured, HRNet-32 bf16 forward: ping-pong everywhere is 30 % slower at
+// batch 1 / 8; thresholds 512 / 1024 / 2048 / 4096 / never give 9489 / 9599 / 10144 / 10137 / 10066 frames/s at batch 32 and
+// 13699 / 13716 / 13713 / 13195 / 13052 at batch 64.
+static int pp_min_tiles() {
+    static const int v = [] { const char* e = getenv("CAPF_BF16_PP_MIN_TILES"); return e ? atoi(e) : 2048; }();
+    return v;
 }
 
 template <int BM, int BN, int WM, int WN, int S>
@@ -444,7 +604,8 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
-    hipLaunchKernelGGL(igemm_bf16_group_kernel, dim3(start), dim3(256), 0, s, ga);
+    if (start >= pp_min_tiles()) hipLaunchKernelGGL(igemm_bf16_group_pp_kernel, dim3(start), dim3(256), 0, s, ga);
+    else hipLaunchKernelGGL(igemm_bf16_group_kernel, dim3(start), dim3(256), 0, s, ga);
     return hipGetLastError();
 }
 
@@ -458,6 +619,13 @@ hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     a.fd_wo = make_fastdiv((unsigned)a.Wo);
     a.spread = 0ull;
     for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+    if (tiles128 >= pp_min_tiles()) {
+        if (a.N <= 32) return launch_cfg_b<128, 32, 32, 32, 1>(a, s);
+        if (a.N <= 64) return ((long)a.M >= 128L * 512) ? launch_cfg_b<128, 64, 64, 32, 1>(a, s) : launch_cfg_b<64, 64, 32, 32, 1>(a, s);
+        if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return launch_cfg_b<128, 128, 64, 64, 1>(a, s);
+        return launch_cfg_b<64, 64, 32, 32, 1>(a, s);
+    }
     if (a.N <= 32) return launch_cfg_b<128, 32, 32, 32, 3>(a, s);
     if (a.N <= 64) return ((long)a.M >= 128L * 512) ? launch_cfg_b<128, 64, 64, 32, 3>(a, s) : launch_cfg_b<64, 64, 32, 32, 3>(a, s);
     if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return launch_cfg_b<128, 128, 64, 64, 2>(a, s);
@@ -494,3 +662,10 @@ hipError_t launch_gemm_bf16_rows(const void* A_bf16, const void* W_bf16, const f
 }
 
 }  // namespace capf
+
+#ifdef CAPF_DIAG
+extern "C" int capf_debug_bf16_timeline(unsigned long long* dst, int blocks) {
+    if (blocks > 8192) blocks = 8192;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_bf16_timeline), (size_t)blocks * 64);
+}
+#endif

@@ -170,7 +170,11 @@ def test_linear_bf16_matches_torch_on_bf16_rounded_operands(M, N, K, gelu, res):
 
 BF16_CASES = [(32, 32, 3, 1, 64, 64, 2, 1, True), (64, 64, 3, 1, 32, 32, 2, 1, False), (48, 48, 3, 1, 24, 20, 1, 1, True),
               (256, 256, 3, 1, 8, 8, 3, 0, True), (64, 256, 1, 1, 16, 12, 2, 1, True), (96, 48, 1, 1, 10, 6, 2, 0, False),
-              (32, 64, 3, 2, 16, 12, 3, 1, False), (2048, 256, 1, 1, 4, 3, 1, 1, False), (128, 128, 3, 1, 5, 3, 7, 1, True)]
+              (32, 64, 3, 2, 16, 12, 3, 1, False), (2048, 256, 1, 1, 4, 3, 1, 1, False), (128, 128, 3, 1, 5, 3, 7, 1, True),
+              # Cout % 8 != 0: the epilogue's element-wise tail instead of its 16-byte path
+              (32, 36, 3, 1, 9, 7, 2, 1, True), (64, 20, 1, 1, 6, 5, 3, 0, False),
+              # >= 2048 tiles per launch: the ping-pong (one-stage) schedule, 128x64 and 128x128 tiles
+              (48, 48, 3, 1, 64, 64, 66, 1, True), (64, 128, 1, 1, 64, 64, 40, 1, True), (32, 32, 3, 1, 64, 64, 65, 0, False)]
 
 
 @pytest.mark.parametrize("ci,co,ks,st,H,W,B,act,res", BF16_CASES)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Per-block timeline of one bf16 conv launch (diagnosis build: CAPF_LIB=tools/ab/libcapf_diag.so CAPF_BF16_PP=1, GPU box)."""
+import argparse, ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "contextaware-poseformer_amd"))
+import numpy as np
+import torch
+from capf import lib as capf
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--res", type=int, default=64)
+ap.add_argument("--ch", type=int, default=48)
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--ks", type=int, default=3)
+a = ap.parse_args()
+x = torch.randn(a.batch, a.res, a.res, a.ch, device="cuda").bfloat16()
+w = torch.randn(a.ch, a.ch, a.ks, a.ks, device="cuda") * 0.05
+r = torch.randn(a.batch, a.res, a.res, a.ch, device="cuda").bfloat16()
+ww, bw = capf.pack_conv_bf16(w)
+for _ in range(10):
+    capf.conv_nhwc_bf16(x, ww, bw, a.ks, 1, 1, r)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    capf.conv_nhwc_bf16(x, ww, bw, a.ks, 1, 1, r)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 100.0
+flops = 2.0 * a.batch * a.res * a.res * a.ch * a.ch * a.ks * a.ks
+print(f"conv {a.batch}x{a.res}x{a.res}x{a.ch} ks{a.ks}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s")
+lib = capf.load_library()
+nb = 8192
+buf = np.zeros((nb, 8), dtype=np.uint64)
+assert lib.capf_debug_bf16_timeline(buf.ctypes.data_as(ctypes.c_void_p), nb) == 0
+t = buf[buf[:, 0] != 0].astype(np.int64)
+pro, loop, epi, drain, tot = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 4] - t[:, 0]
+rt = (t[:, 7].max() - t[:, 5].min()) / 100.0
+tick = tot.sum() / max(1, (t[:, 7] - t[:, 5]).sum()) * 100.0
+print(f"{t.shape[0]} blocks, span of the first 8192 blocks {rt:.1f} us, memtime ~{tick:.0f} ticks/us")
+for name, v in (("prologue", pro), ("K loop", loop), ("  of it load wait", t[:, 6]), ("epilogue", epi), ("store drain", drain), ("total", tot)):
+    print(f"  {name:18s} mean {v.mean() / tick:7.2f} us   p10 {np.percentile(v, 10) / tick:7.2f}   p90 {np.percentile(v, 90) / tick:7.2f}")
+print(f"  concurrency: {tot.sum() / tick / (rt * 256):.2f} blocks per CU on average")
