@@ -177,44 +177,61 @@ hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W,
 // ---- bilinear resize, align_corners=True (globalNet.py:40, refineNet.py:61) ----------------------
 // ATen upsample_bilinear2d: src = dst * (in-1)/(out-1) (0 if out == 1); i0 = (int)src, i1 = i0 + (i0 < in-1);
 // l1 = src - i0, l0 = 1 - l1;  out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).
-template <bool BF>
+template <bool BF, int V>      // V channels per lane: 4 (fp32: 16 B; bf16: 8 B) or 8 (bf16: 16 B)
 __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                 int C, int Ho, int Wo, float sh, float sw) {
-    const int C4 = C >> 2;
-    const long total = (long)B * Ho * Wo * C4;
+    const int CV = C / V;
+    const long total = (long)B * Ho * Wo * CV;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long pix = i / C4;
-        const int wo = (int)(pix % Wo);
-        pix /= Wo;
-        const int ho = (int)(pix % Ho);
-        const int b = (int)(pix / Ho);
+        const unsigned pix = (unsigned)(i / CV);                    // B * Ho * Wo < 2^31 (launcher checks)
+        const int cv = (int)(i - (long)pix * CV);
+        const unsigned row = pix / (unsigned)Wo;
+        const int wo = (int)(pix - row * (unsigned)Wo);
+        const int b = (int)(row / (unsigned)Ho), ho = (int)(row - (unsigned)b * (unsigned)Ho);
         const float fh = sh * ho, fw = sw * wo;
         const int h0 = (int)fh, w0 = (int)fw;
         const int h1 = h0 + (h0 < H - 1), w1 = w0 + (w0 < W - 1);
         const float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-        const long sb = (long)b * H * W * C4 + c4;
-        const f32x4 v00 = load4<BF>(in, sb + ((long)h0 * W + w0) * C4), v01 = load4<BF>(in, sb + ((long)h0 * W + w1) * C4);
-        const f32x4 v10 = load4<BF>(in, sb + ((long)h1 * W + w0) * C4), v11 = load4<BF>(in, sb + ((long)h1 * W + w1) * C4);
-        f32x4 r;
+        const long sb = ((long)b * H * W * CV + cv) * (V / 4);      // in units of 4 channels
+        const long o00 = sb + ((long)h0 * W + w0) * (C >> 2), o01 = sb + ((long)h0 * W + w1) * (C >> 2);
+        const long o10 = sb + ((long)h1 * W + w0) * (C >> 2), o11 = sb + ((long)h1 * W + w1) * (C >> 2);
+        if (V == 8) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* src = reinterpret_cast<const u32x4*>(in);
+            const u32x4 q00 = src[o00 >> 1], q01 = src[o01 >> 1], q10 = src[o10 >> 1], q11 = src[o11 >> 1];
+            u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            r[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
-        store4<BF>(out, i, r);
+            for (int e = 0; e < 4; ++e) {
+                const float lo = lh0 * (lw0 * __uint_as_float(q00[e] << 16) + lw1 * __uint_as_float(q01[e] << 16)) +
+                                 lh1 * (lw0 * __uint_as_float(q10[e] << 16) + lw1 * __uint_as_float(q11[e] << 16));
+                const float hi = lh0 * (lw0 * __uint_as_float(q00[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q01[e] & 0xFFFF0000u)) +
+                                 lh1 * (lw0 * __uint_as_float(q10[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q11[e] & 0xFFFF0000u));
+                o[e] = (unsigned)f2bf_e(lo) | ((unsigned)f2bf_e(hi) << 16);
+            }
+            reinterpret_cast<u32x4*>(out)[i] = o;
+        } else {
+            const f32x4 v00 = load4<BF>(in, o00), v01 = load4<BF>(in, o01), v10 = load4<BF>(in, o10), v11 = load4<BF>(in, o11);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                r[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
+            store4<BF>(out, i, r);
+        }
     }
 }
 
 hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
                                   hipStream_t s, int bf16) {
+    if ((long)B * Ho * Wo >= (1L << 31)) return hipErrorInvalidValue;
     const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    const long total = (long)B * Ho * Wo * (C >> 2);
+    const int V = (bf16 && C % 8 == 0) ? 8 : 4;
+    const long total = (long)B * Ho * Wo * (C / V);
     const long want = (total + 255) / 256;
-    if (bf16)
-        hipLaunchKernelGGL(bilinear_kernel<true>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
-    else
-    hipLaunchKernelGGL(bilinear_kernel<false>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
-                       W, C, Ho, Wo, sh, sw);
+    const dim3 grid((int)(want < 16384 ? want : 16384));
+    if (V == 8) hipLaunchKernelGGL((bilinear_kernel<true, 8>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
+    else if (bf16) hipLaunchKernelGGL((bilinear_kernel<true, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
+    else hipLaunchKernelGGL((bilinear_kernel<false, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
     return hipGetLastError();
 }
 

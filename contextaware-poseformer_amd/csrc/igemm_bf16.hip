@@ -472,6 +472,155 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
 #endif
 }
 
+// =====================================================================================================
+// Small-Cin stem (Cin = 3, k = 3 or 7) under compute_dtype = bf16: the fp32 image is gathered element-wise (K order
+// (kh, kw, c), like the fp32 igemm_f32_smallc kernel whose packed fp32 weights it shares), rounded to bf16 on the way into
+// a padded LDS tile, and multiplied on v_mfma_f32_32x32x16_bf16: 1/8 of the matrix cycles of the fp32 stem, which was
+// 1.1 ms of CPN's 9.7 ms at batch 128 (384x288) -- the gather is what remains.  Output bf16 NHWC.
+// =====================================================================================================
+[[maybe_unused]] static constexpr int SPITCH = 40;          // halves per LDS row: 32 k-values + 8 pad (80 B: 16-byte aligned fragment reads)
+
+__global__ __launch_bounds__(256) void igemm_bf16_smallc_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, BN = 64, WM = 64, WN = 32, SBK = 32;
+    constexpr int WAVES_N = BN / WN, TM = WM / 32, TN = WN / 32, RA = BM / 32, RB = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * SPITCH];
+    unsigned short* As = lds;
+    unsigned short* Bs = lds + BM * SPITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int srow = tid >> 3, kq = (tid & 7) * 4;
+
+    long a_base[RA];
+    int a_h0[RA], a_w0[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + srow + 32 * i;
+        a_base[i] = 0; a_h0[i] = -(1 << 20); a_w0[i] = 0;
+        if (m < p.M) {
+            const int b = fast_div_b(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
+            const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
+            a_base[i] = (long)b * p.H * p.W * p.Cin;
+            a_h0[i] = ho * p.stride - p.pad;
+            a_w0[i] = wo * p.stride - p.pad;
+        }
+    }
+    float a_reg[RA][4];
+    f32x4 b_reg[RB];
+    auto load_chunk = [&](int c) {
+        int dh[4], dw[4], doff[4];
+        bool kok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {          // the (kh, kw, c) of this thread's four k-values: the same for every row
+            const int ke = c * SBK + kq + e;
+            const int t = ke / p.Cin, c1 = ke - t * p.Cin;
+            dh[e] = t / p.ks;
+            dw[e] = t - dh[e] * p.ks;
+            doff[e] = (dh[e] * p.W + dw[e]) * p.Cin + c1;
+            kok[e] = ke < p.K;
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const long row = a_base[i] + ((long)a_h0[i] * p.W + a_w0[i]) * p.Cin;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hi = a_h0[i] + dh[e], wi = a_w0[i] + dw[e];
+                a_reg[i][e] = (kok[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? p.A[row + doff[e]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + srow + 32 * i;
+            b_reg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) b_reg[i] = *reinterpret_cast<const f32x4*>(p.Wp + (long)n * p.Kpad + c * SBK + kq);
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int nchunks = p.Kpad / SBK;          // the fp32 pack pads K to a multiple of 32
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<u32x2*>(&As[(srow + 32 * i) * SPITCH + kq]) =
+                u32x2{(unsigned)f2bf(a_reg[i][0]) | ((unsigned)f2bf(a_reg[i][1]) << 16),
+                      (unsigned)f2bf(a_reg[i][2]) | ((unsigned)f2bf(a_reg[i][3]) << 16)};
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<u32x2*>(&Bs[(srow + 32 * i) * SPITCH + kq]) =
+                u32x2{(unsigned)f2bf(b_reg[i][0]) | ((unsigned)f2bf(b_reg[i][1]) << 16),
+                      (unsigned)f2bf(b_reg[i][2]) | ((unsigned)f2bf(b_reg[i][3]) << 16)};
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int step = 0; step < SBK / 16; ++step) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * SPITCH + step * 16 + fhalf * 8]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + j * 32 + frow) * SPITCH + step * 16 + fhalf * 8]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // transposed accumulator (lane = row m, register group g = channels 8 g + 4 (lane >> 5) .. + 3): 8-byte stores
+    unsigned short* Out = reinterpret_cast<unsigned short*>(p.out);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + frow;
+        if (m >= p.M) continue;
+        const long o_row = (long)m * p.omap.S1 + p.omap.off;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + j * 32 + 4 * fhalf + 8 * g;
+                if (n >= p.N) continue;
+                u16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * g + e] + (p.bias ? p.bias[n + e] : 0.f);
+                    if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = f2bf(t);
+                }
+                *reinterpret_cast<u16x4*>(Out + o_row + n) = v;
+            }
+    }
+#endif
+}
+
+// fp32 NHWC image (Cin % 4 != 0), fp32 packed weights [N][Kpad32], bf16 NHWC result; no residual.
+bool gemm_bf16_smallc_ok(const GemmArgs& a) {
+    return a.conv && a.out_bf16 && !a.res && a.omap.G == 1 && a.N % 4 == 0 && a.omap.S1 % 4 == 0 && a.omap.off % 4 == 0 &&
+           a.Kpad % 32 == 0 && a.act != ACT_GELU;
+}
+
+hipError_t launch_gemm_bf16_smallc(const GemmArgs& a_in, hipStream_t s) {
+    if (!gemm_bf16_smallc_ok(a_in)) return hipErrorInvalidValue;
+    GemmArgs a = a_in;
+    a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
+    a.fd_wo = make_fastdiv((unsigned)a.Wo);
+    hipLaunchKernelGGL(igemm_bf16_smallc_kernel, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // Grouped launch (see igemm_f32.hip "Grouped launch"): up to MAXG independent bf16 convs in one grid.
 struct GroupArgsB {
     GemmArgs g[MAXG];

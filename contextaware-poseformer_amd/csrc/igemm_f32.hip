@@ -814,6 +814,12 @@ static TileCfg pick_tile(const GemmArgs& a) {
     return pick;
 }
 
+// compute_dtype = bf16 (the op writes bf16): the stem runs on the bf16 MFMA too (igemm_bf16.hip); CAPF_STEM_BF16=0 keeps it fp32
+static bool stem_on_bf16(const GemmArgs& a) {
+    static const int on = [] { const char* e = getenv("CAPF_STEM_BF16"); return e ? atoi(e) : 1; }();
+    return on && gemm_bf16_smallc_ok(a);
+}
+
 const char* gemm_f32_kernel_name(const GemmArgs& a) {
     static char buf[N_TILES][2][48];
     static bool init = false;
@@ -823,7 +829,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
             for (int m = 0; m < 2; ++m) snprintf(buf[t][m], sizeof(buf[t][m]), "igemm_f32<%s,%s>", kTileNames[t], modes[m]);
         init = true;
     }
-    if (a.conv && a.Cin % 4 != 0) return "igemm_f32_smallc<w4,128x64>";
+    if (a.conv && a.Cin % 4 != 0) return stem_on_bf16(a) ? "igemm_bf16_smallc<w4,128x64>" : "igemm_f32_smallc<w4,128x64>";
     return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
 
@@ -1007,6 +1013,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a.conv) {
         if (!prep_conv(a)) return hipErrorInvalidValue;
         if (a.Cin % 4 != 0) {
+            if (stem_on_bf16(a)) return launch_gemm_bf16_smallc(a, s);
             dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64)), block(256);
             hipLaunchKernelGGL((igemm_f32_smallc_kernel<128, 64, 64, 32>), grid, block, 0, s, a);
             return hipGetLastError();
