@@ -14,7 +14,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
-    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
+    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
 ]
 
@@ -96,6 +96,9 @@ def load_library():
     lib.capf_fliptest_fuse.argtypes = [P, P, c_int, P]
     lib.capf_op_pack_conv_bf16.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 8
+    lib.capf_op_conv_bf16_rh_width.argtypes = [c_int]
+    lib.capf_op_pack_conv_bf16_rh.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
+    lib.capf_op_conv_bf16_rh.argtypes = [P, P, P, P, P, P] + [c_int] * 6
     lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -477,6 +480,36 @@ def conv_nhwc_bf16(x, wp, bias, ks, stride=1, act=0, residual=None):
     rc = lib.capf_op_conv_bf16(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, ks, stride, act)
     if rc:
         raise CapfError(f"capf_op_conv_bf16 failed ({rc})")
+    return y
+
+
+def pack_conv_bf16_rh(w, bn=None, eps=1e-5):
+    """3x3 weights for the row-halo bf16 conv -> (bf16 [Cout, 9 * Cin] in (kh, Cin / cw, kw, cw) order, fp32 bias, cw)."""
+    import torch
+    lib = load_library()
+    co, ci, ks, _ = w.shape
+    cw = lib.capf_op_conv_bf16_rh_width(ci)
+    if ks != 3 or not cw:
+        raise CapfError(f"row-halo conv needs a 3x3 kernel and Cin % 32 == 0 (got ks={ks}, Cin={ci})")
+    wp = torch.empty(co, 9 * ci, device=w.device, dtype=torch.bfloat16)
+    bias = torch.empty(co, device=w.device)
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    rc = lib.capf_op_pack_conv_bf16_rh(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci)
+    if rc:
+        raise CapfError(f"capf_op_pack_conv_bf16_rh failed ({rc})")
+    return wp, bias, cw
+
+
+def conv_nhwc_bf16_rh(x, wp, bias, act=0, residual=None):
+    """x [B,H,W,Cin] cuda bf16 NHWC -> [B,H,W,Cout] bf16 (3x3, stride 1, pad 1)."""
+    import torch
+    lib = load_library()
+    B, H, W, ci = x.shape
+    co = wp.shape[0]
+    y = torch.empty(B, H, W, co, device=x.device, dtype=torch.bfloat16)
+    rc = lib.capf_op_conv_bf16_rh(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, act)
+    if rc:
+        raise CapfError(f"capf_op_conv_bf16_rh failed ({rc})")
     return y
 
 

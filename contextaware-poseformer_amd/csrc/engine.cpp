@@ -35,6 +35,10 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
         if (pk.kind == 0 && pk.bf16) {
             HIP_TRY(launch_pack_conv_bf16(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks, pk.Kpad, s));
+            if (pk.rh)
+                HIP_TRY(launch_pack_conv_bf16_rh(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
+                                                 params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w2_off, B, pk.N, pk.Cin,
+                                                 bf16_rh_width(pk.Cin), s));
         } else if (pk.kind == 0 && pk.wino) {
             HIP_TRY(launch_pack_conv_wino(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s, pk.Kpad == 18 * pk.Cin ? 43 : 23));
@@ -84,6 +88,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.out = ptr(op.out);
     a.M = (int)(op.rows_per_frame * batch);
     a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
+    if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
@@ -694,6 +699,38 @@ int capf_op_conv_bf16(void* stream, const void* x, const void* wp, const float* 
     a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
     a.act = act;
     return capf::launch_gemm_bf16(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
+}
+
+static capf::GemmArgs rh_args(const void* x, const void* wp, const float* bias, const void* residual, void* y, int B, int H,
+                              int W, int Cin, int Cout, int act) {
+    capf::GemmArgs a{};
+    a.A = static_cast<const float*>(x); a.Wp = static_cast<const float*>(wp); a.bias = bias;
+    a.res = static_cast<const float*>(residual); a.out = static_cast<float*>(y);
+    a.Ho = H; a.Wo = W;
+    a.M = B * H * W; a.N = Cout; a.K = 9 * Cin; a.Kpad = 9 * Cin;
+    a.conv = 1; a.Cin = Cin; a.H = H; a.W = W; a.ks = 3; a.stride = 1; a.pad = 1;
+    a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
+    a.act = act;
+    return a;
+}
+
+int capf_op_conv_bf16_rh_width(int Cin) {
+    capf::GemmArgs a = rh_args(nullptr, nullptr, nullptr, nullptr, nullptr, 1, 8, 8, Cin, 8, 0);
+    return capf::gemm_bf16_rh_cw(a);
+}
+
+int capf_op_pack_conv_bf16_rh(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
+                              const float* var, float eps, void* wp, float* bias, int Cout, int Cin) {
+    const int cw = capf_op_conv_bf16_rh_width(Cin);
+    if (!cw) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_pack_conv_bf16_rh(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, cw,
+                                          static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_bf16_rh(void* stream, const void* x, const void* wp, const float* bias, const void* residual, void* y, int B,
+                         int H, int W, int Cin, int Cout, int act) {
+    const capf::GemmArgs a = rh_args(x, wp, bias, residual, y, B, H, W, Cin, Cout, act);
+    return capf::launch_gemm_bf16_rh(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
 }
 
 int capf_op_linear_bf16(void* stream, const void* x_bf16, const void* w_bf16, const float* bias, const float* residual, void* y,

@@ -53,6 +53,7 @@ struct Pack {
     int Kpad2 = 0;
     bool direct = false;           // linear with Kpad == K and no concat: use the parameter in place
     bool bf16 = false;             // conv weights packed as bf16 (Kpad % 64 == 0)
+    bool rh = false;               // bf16 3x3 stride-1 conv: a second copy in the row-halo layout ([N][9 * Cin] bf16) at w2_off
     bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
 };
 
@@ -169,6 +170,7 @@ struct Engine {
     bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)
+    bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)
     bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)
     int lanes = 2;                 // fork/join regions: 0 in program order, 1 on side streams, 2 as grouped launches (capf_set_lanes)

@@ -458,6 +458,210 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
 }
 #endif
 
+// =====================================================================================================
+// "Row-halo" tile for 3x3 / stride 1 / pad 1 convs (the BasicBlock convs: >90 % of the bf16 FLOPs of HRNet).
+// The implicit GEMM above stages a fresh [BM x 64] A chunk for every tap, so an activation travels L2 -> LDS nine times;
+// at bf16 MFMA speed that operand path, not the matrix pipe, is the bound.  Here the K order is
+// (kh, channel chunk, kw, c) and ONE staged A tile serves the three kw taps of a (kh, channel chunk): the tile is 128
+// consecutive flat pixels m0-1 .. m0+126 of the row shifted by kh-1, output pixel m0+i reads staged rows i, i+1, i+2, and
+// the two taps that would wrap around an image row (w = 0 with kw = 0, w = W-1 with kw = 2) are zeroed per lane in the
+// fragment registers.  126 outputs per tile (1.6 % idle MFMA rows) keep the staged tile at exactly 128 rows = whole DMA
+// rounds.  Per 192-deep "superchunk" a block stages 128 x CW + 3 x 64 x CW halves instead of 3 x (128 + 64) x 64: 44 % fewer
+// bytes and DMA instructions, a third of the load phases and barriers, and no K padding (9 * 48 = 432 is used as is).
+// CW = channels per chunk: 64, 48 or 32 (Cin % CW == 0); weights packed by launch_pack_conv_bf16_rh as
+// [N][kh][Cin / CW][kw][CW].  Ping-pong schedule only (one stage of 320 * CW halves: 40 / 30 / 20 KiB).
+// =====================================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)
+// TN = 32-column blocks per tile (tile = 126 output pixels x 32 TN channels); the four waves split the 128 staged rows, each
+// computing 32 rows x 32 TN columns (1 A + TN B fragment reads per TN MFMAs).  LDS: (128 + 96 TN) x CW halves, at least the
+// epilogue's 18 KiB.
+template <int CW, int TN>
+__device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int bid, unsigned short* __restrict__ lds) {
+    constexpr int BMO = 126, BN = 32 * TN;
+    constexpr int QPR = CW / 8;                            // 16-byte quads per LDS row
+    constexpr int KS = CW / 16;                            // MFMA k-steps per tap
+    constexpr int RA = QPR / 2;                            // DMA rounds (256 quads each) of the 128 x CW A tile
+    constexpr int NBQ = 3 * BN * QPR;                      // quads of the 3 x BN x CW weight tile
+    constexpr int RB = (NBQ + 255) / 256;
+    constexpr int BOFF = 128 * CW;                         // halves
+    static_assert(CW == 64 || CW == 48 || CW == 32, "chunk width");
+
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(p.A);
+    const unsigned short* Wp = reinterpret_cast<const unsigned short*>(p.Wp);
+    const unsigned short* Rs = reinterpret_cast<const unsigned short*>(p.res);
+    unsigned short* Out = reinterpret_cast<unsigned short*>(p.out);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbn = (p.N + BN - 1) / BN;
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * BMO, n0 = tile_n * BN;
+    const int HW = p.H * p.W, Kp = 9 * p.Cin, ncc = p.Cin / CW;
+    auto swz = [](int row) { return QPR == 8 ? (row >> 1) & 7 : (QPR == 4 ? (row >> 2) & 3 : 0); };
+
+    // ---- operand fetch: LDS-DMA with block-uniform descriptors (see igemm_bf16_tile); the descriptor of A starts one
+    // pixel and one image row before the tile so that every (row, kh) offset is non-negative
+    constexpr unsigned OOB = 0x80000000u;
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + ((long)m0 - 1 - p.W) * p.Cin), 0, 0x7FFFFF00u, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * Kp), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)Kp * 2u, 0x00020000);
+    unsigned a_voff[RA], a_ok[RA];                         // a_ok bit kh: staged row (pixel, shifted by kh-1) is real data
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int q = r * 256 + tid, j = q / QPR, pq = q - j * QPR;
+        const int mj = m0 - 1 + j;
+        a_voff[r] = (unsigned)(j * p.Cin + ((pq ^ swz(j)) * 8)) * 2u;
+        a_ok[r] = 0u;
+        if (mj >= 0 && mj < p.M) {
+            const int b = fast_div_b(mj, p.fd_hw), rem = mj - b * HW;
+            const int h = fast_div_b(rem, p.fd_wo);
+            a_ok[r] = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < p.H ? 4u : 0u);
+        }
+    }
+    unsigned b_voff[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int q = r * 256 + tid;
+        const int kw = q / (BN * QPR), rem = q - kw * (BN * QPR);
+        const int n = rem / QPR, pq = rem - n * QPR;
+        b_voff[r] = (q < NBQ) ? (unsigned)(n * Kp + kw * CW + ((pq ^ swz(n)) * 8)) * 2u : OOB;
+    }
+    auto fire = [&](int kh, int cc) {
+        const unsigned soff_a = __builtin_amdgcn_readfirstlane((unsigned)(kh * p.W * p.Cin + cc * CW) * 2u);
+        const unsigned soff_b = __builtin_amdgcn_readfirstlane((unsigned)((kh * ncc + cc) * 3 * CW) * 2u);
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(lds + (r * 256 + wave * 64) * 8), 16,
+                                                     ((a_ok[r] >> kh) & 1u) ? a_voff[r] : OOB, soff_a, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r * 256 + wave * 64 < NBQ)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(lds + BOFF + (r * 256 + wave * 64) * 8), 16,
+                                                         b_voff[r], soff_b, 0, 0);
+    };
+    // the accumulators start at the bias (transposed layout: register 4 g + e of block j = channel n0 + 32 j + 8 g + 4 fhalf + e),
+    // so the epilogue needs no bias operand; the loads retire behind the first superchunk's
+    const int wm0 = wave * 32;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + j * 32 + 8 * g + 4 * fhalf;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bv[e];
+        }
+    bool zl, zr;                                           // this lane's output pixel sits on the left / right image border
+    {
+        const int m = m0 + wm0 + frow;
+        const int w = m - fast_div_b(m, p.fd_wo) * p.W;    // (fd_wo divides by W: Wo == W here)
+        zl = w == 0;
+        zr = w == p.W - 1;
+    }
+    const int b_sw = swz(frow);                            // (weight rows j * 32 + frow: the swizzle only looks at frow's bits)
+
+    // residual rows in the coalesced epilogue's layout, requested with the last superchunk (see igemm_bf16_tile)
+    const bool vec_ok = (p.N & 7) == 0 && (p.omap.S1 & 7) == 0 && (p.omap.off & 7) == 0 &&
+                        (!Rs || ((p.rmap.S1 & 7) == 0 && (p.rmap.off & 7) == 0));
+    const int er = lane >> 2, ec = (lane & 3) * 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rr[TN][2];
+    auto row_ok = [&](int i_local, int m) { return i_local < BMO && m < p.M; };
+    auto prefetch_epilogue = [&]() {
+        if (!vec_ok) return;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int il = wm0 + h * 16 + er, m = m0 + il, n = n0 + j * 32 + ec;
+                rr[j][h] = u32x4{0u, 0u, 0u, 0u};
+                if (Rs && row_ok(il, m) && n < p.N)
+                    rr[j][h] = *reinterpret_cast<const u32x4*>(Rs + (long)m * p.rmap.S1 + p.rmap.off + n);
+            }
+    };
+
+    bf16x8 af[2], bfr[2][TN];
+    auto read_frags = [&](int u, int buf) {                // u = kw * KS + k-step
+        const int kw = u / KS, st = u - kw * KS;
+        const int lq = st * 2 + fhalf;
+        const int r = wm0 + frow + kw;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(r * QPR + (lq ^ swz(r))) * 8]);
+        if ((kw == 0 && zl) || (kw == 2 && zr)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        af[buf] = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bfr[buf][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
+                                                         &lds[BOFF + ((kw * BN + j * 32 + frow) * QPR + (lq ^ b_sw)) * 8]));
+    };
+    auto superchunk = [&](int kh, int cc) {
+        fire(kh, cc);
+        wait_vmcnt_b<0>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, 0);
+#pragma unroll
+        for (int u = 0; u < 3 * KS; ++u) {
+            if (u + 1 < 3 * KS) read_frags(u + 1, (u + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u & 1][j], af[u & 1], acc[j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every wave has read the stage: the next superchunk may overwrite it
+    };
+    const int nsc = 3 * ncc;
+    int kh = 0, cc = 0;
+    for (int sc = 0; sc < nsc - 1; ++sc) {
+        superchunk(kh, cc);
+        if (++cc == ncc) { cc = 0; ++kh; }
+    }
+    prefetch_epilogue();                                   // (last superchunk peeled: these registers are not live in the loop)
+    superchunk(kh, cc);
+
+    // ---- epilogue: the coalesced bf16 epilogue of igemm_bf16_tile (32x32 blocks transposed through the idle stage)
+    constexpr int EPS = 36;
+    float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
+    auto finish = [&](float t) {
+        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+        return (unsigned)f2bf(t);
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + ec;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(&ep[(lane & 31) * EPS + 8 * g + 4 * (lane >> 5)]) =
+                f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 16 + er, il = wm0 + row, m = m0 + il;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
+            if (!row_ok(il, m)) continue;
+            if (vec_ok) {
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned rw = rr[j][h][q];
+                    const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+                    o[q] = finish(xa + __uint_as_float(rw << 16)) | (finish(xb + __uint_as_float(rw & 0xFFFF0000u)) << 16);
+                }
+                if (n < p.N) *reinterpret_cast<u32x4*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = o;
+            } else {
+                for (int e = 0; e < 8 && n + e < p.N; ++e) {
+                    const float x = e < 4 ? x0[e & 3] : x1[e & 3];
+                    const float rsv = Rs ? bf2f(Rs[(long)m * p.rmap.S1 + p.rmap.off + n + e]) : 0.f;
+                    Out[(long)m * p.omap.S1 + p.omap.off + n + e] = (unsigned short)finish(x + rsv);
+                }
+            }
+        }
+    }
+}
+#endif
+
 __device__ __forceinline__ int xcd_remap_b(int b, int nblk) {   // see igemm_f32.hip :: xcd_remap
     const int q = nblk >> 3, r = nblk & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -621,6 +825,96 @@ hipError_t launch_gemm_bf16_smallc(const GemmArgs& a_in, hipStream_t s) {
     return hipGetLastError();
 }
 
+static constexpr int rh_lds_halves(int cw, int tn) { return (128 + 96 * tn) * cw < 9216 ? 9216 : (128 + 96 * tn) * cw; }
+
+template <int CW, int TN>
+__global__ __launch_bounds__(256, 4) void igemm_bf16_rh_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned short lds[rh_lds_halves(CW, TN)];
+    igemm_bf16_rh_tile<CW, TN>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
+#endif
+}
+
+// 32-column blocks per row-halo tile for N output channels at chunk width cw: 32 channels -> 1, multiples of 96 -> 3 (no padded
+// columns; the 48-wide chunks keep 3 x 96 x 48 weights at 27 KiB), else 2
+static int rh_tn(int N, int cw) { return N <= 32 ? 1 : ((N % 96 == 0 && cw == 48) ? 3 : 2); }
+
+// chunk width of the row-halo kernel for Cin input channels (a multiple of 64, 48 or 32), 0 = not supported
+int bf16_rh_width(int Cin) {
+    static const int force = [] { const char* e = getenv("CAPF_BF16_RH_CW"); return e ? atoi(e) : 0; }();   // tuning only
+    if (force && Cin % force == 0 && (force == 64 || force == 48 || force == 32)) return force;
+    return Cin % 64 == 0 ? 64 : (Cin % 48 == 0 ? 48 : (Cin % 32 == 0 ? 32 : 0));
+}
+
+// ... that the engine should use: the kernel wins where a chunk is 64 channels wide, or 48 with one chunk per tap row.
+// Measured against the ping-pong direct kernel at >= 2048 tiles (tools/bf16_timeline.py, TFLOP/s direct -> row-halo):
+// 64 ch 64x64 598 -> 673, 64 ch 32x32 587 -> 666, 128 ch 756 -> 830, 192 ch 582 -> 671, 256 ch 772 -> 776, 48 ch 358 -> 383;
+// 96 ch (two 48-wide chunks, 64-wide tiles compute 128 columns for 96) 469 -> 443, 32 ch (64-wide tile for 32 columns) 342 -> 322.
+int bf16_rh_preferred(int Cin) { return Cin % 64 == 0 || Cin == 48; }
+
+// ... for a conv: 0 unless it is 3x3 / stride 1 / pad 1 with plain row maps
+int gemm_bf16_rh_cw(const GemmArgs& a) {
+    if (!a.conv || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W || a.N % 4 != 0 || a.act == ACT_GELU ||
+        a.omap.G != 1 || (a.res && a.rmap.G != 1) || a.rscale || a.M <= 0 || (double)a.M * a.Cin * 2.0 >= 2.0e9)
+        return 0;
+    return bf16_rh_width(a.Cin);
+}
+
+static void prep_rh(GemmArgs& a) {
+    a.fd_hw = make_fastdiv((unsigned)(a.H * a.W));
+    a.fd_wo = make_fastdiv((unsigned)a.W);
+}
+
+// Wp = weights packed by launch_pack_conv_bf16_rh for the SAME chunk width gemm_bf16_rh_cw(a) returns
+hipError_t launch_gemm_bf16_rh(const GemmArgs& a_in, hipStream_t s) {
+    const int cw = gemm_bf16_rh_cw(a_in);
+    if (!cw) return hipErrorInvalidValue;
+    GemmArgs a = a_in;
+    prep_rh(a);
+    const int tn = rh_tn(a.N, cw);
+    const dim3 grid(((a.M + 125) / 126) * ((a.N + 32 * tn - 1) / (32 * tn)));
+    switch (cw * 10 + tn) {
+        case 641: hipLaunchKernelGGL((igemm_bf16_rh_kernel<64, 1>), grid, dim3(256), 0, s, a); break;
+        case 642: hipLaunchKernelGGL((igemm_bf16_rh_kernel<64, 2>), grid, dim3(256), 0, s, a); break;
+        case 481: hipLaunchKernelGGL((igemm_bf16_rh_kernel<48, 1>), grid, dim3(256), 0, s, a); break;
+        case 482: hipLaunchKernelGGL((igemm_bf16_rh_kernel<48, 2>), grid, dim3(256), 0, s, a); break;
+        case 483: hipLaunchKernelGGL((igemm_bf16_rh_kernel<48, 3>), grid, dim3(256), 0, s, a); break;
+        case 321: hipLaunchKernelGGL((igemm_bf16_rh_kernel<32, 1>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((igemm_bf16_rh_kernel<32, 2>), grid, dim3(256), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+// BN fold + re-layout of a 3x3 conv weight for the row-halo kernel: Wp[n][((kh * (Cin / CW) + cc) * 3 + kw) * CW + c] =
+// bf16(w[n][cc * CW + c][kh][kw] * gamma[n] / sqrt(var[n] + eps));  bias as launch_pack_conv
+__global__ void pack_conv_bf16_rh_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                         unsigned short* __restrict__ Wp, float* __restrict__ bias, int Cout, int Cin, int CW) {
+    const long total = (long)Cout * 9 * Cin;
+    const int ncc = Cin / CW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (9 * Cin));
+        int k = (int)(i - (long)n * 9 * Cin);
+        const bool first = k == 0;
+        const int c = k % CW; k /= CW;
+        const int kw = k % 3; k /= 3;
+        const int cc = k % ncc, kh = k / ncc;
+        const float sc = gamma ? gamma[n] / sqrtf(var[n] + eps) : 1.f;
+        Wp[i] = f2bf(w[(((long)n * Cin + cc * CW + c) * 3 + kh) * 3 + kw] * sc);
+        if (first && bias) bias[n] = gamma ? beta[n] - mean[n] * sc : 0.f;
+    }
+}
+
+hipError_t launch_pack_conv_bf16_rh(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                                    float eps, void* Wp_bf16, float* bias, int Cout, int Cin, int CW, hipStream_t s) {
+    if ((CW != 64 && CW != 48 && CW != 32) || Cin % CW != 0) return hipErrorInvalidValue;
+    const long total = (long)Cout * 9 * Cin;
+    const long want = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_conv_bf16_rh_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, w, gamma, beta, mean, var,
+                       eps, static_cast<unsigned short*>(Wp_bf16), bias, Cout, Cin, CW);
+    return hipGetLastError();
+}
+
 // Grouped launch (see igemm_f32.hip "Grouped launch"): up to MAXG independent bf16 convs in one grid.
 struct GroupArgsB {
     GemmArgs g[MAXG];
@@ -675,6 +969,35 @@ __global__ __launch_bounds__(256, 5) void igemm_bf16_group_pp_kernel(GroupArgsB 
 #endif
 }
 
+// ping-pong grouped kernel for launches that contain row-halo problems (cfg 3.. = (chunk width, 32-column blocks) (64,2) (64,1)
+// (48,2) (48,3) (48,1) (32,2) (32,1)); the stage size is the largest any problem of the launch needs (dynamic LDS, 18-40 KiB)
+__global__ __launch_bounds__(256, 4) void igemm_bf16_group_rh_kernel(GroupArgsB ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_dyn[];
+    unsigned short* lds = lds_dyn;
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
+    const int l = b - ga.start[pi];
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int bid = (l & 7) * per_xcd + (l >> 3);
+    if (bid >= ga.tiles[pi]) return;
+    const GemmArgs& p = ga.g[pi];
+    switch (ga.cfg[pi]) {
+        case 0: igemm_bf16_tile<128, 64, 64, 32, 1>(p, bid, lds); break;
+        case 1: igemm_bf16_tile<64, 64, 32, 32, 1>(p, bid, lds); break;
+        case 2: igemm_bf16_tile<128, 32, 32, 32, 1>(p, bid, lds); break;
+        case 3: igemm_bf16_rh_tile<64, 2>(p, bid, lds); break;
+        case 4: igemm_bf16_rh_tile<64, 1>(p, bid, lds); break;
+        case 5: igemm_bf16_rh_tile<48, 2>(p, bid, lds); break;
+        case 6: igemm_bf16_rh_tile<48, 3>(p, bid, lds); break;
+        case 7: igemm_bf16_rh_tile<48, 1>(p, bid, lds); break;
+        case 8: igemm_bf16_rh_tile<32, 2>(p, bid, lds); break;
+        default: igemm_bf16_rh_tile<32, 1>(p, bid, lds); break;
+    }
+#endif
+}
+
 // The ping-pong schedule needs other resident blocks to cover a block's load phase: it is used from this many tiles per
 // launch (8 per CU) and the ring schedule below.  Measured, HRNet-32 bf16 forward: ping-pong everywhere is 30 % slower at
 // batch 1 / 8; thresholds 512 / 1024 / 2048 / 4096 / never give 9489 / 9599 / 10144 / 10137 / 10066 frames/s at batch 32 and
@@ -692,6 +1015,7 @@ static hipError_t launch_cfg_b(const GemmArgs& a, hipStream_t s) {
 }
 
 const char* gemm_bf16_kernel_name(const GemmArgs& a) {
+    if (a.Wp2 && gemm_bf16_rh_cw(a) && (long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= pp_min_tiles()) return "igemm_bf16_rh<w4,126x64,conv>";
     if (a.N <= 32) return "igemm_bf16<w4,128x32,conv>";
     if (a.N <= 64) return ((long)a.M >= 128L * 512) ? "igemm_bf16<w4,128x64,conv>" : "igemm_bf16<w4,64x64,conv>";
     if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return "igemm_bf16<w4,128x128,conv>";
@@ -737,6 +1061,22 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
         it[i] = Item{i, cfg, ((a.M + BMs[cfg] - 1) / BMs[cfg]) * ((a.N + BNs[cfg] - 1) / BNs[cfg]),
                      chunks * (BMs[cfg] * BNs[cfg] / 4096.0)};
     }
+    // ping-pong launches (>= pp_min_tiles tiles at the tile sizes above): 3x3 stride-1 problems that carry the row-halo
+    // weight layout move to that tile (126 x 64 outputs)
+    int tiles_small = 0, nrh = 0, lds_halves = (128 + 64) * BKH;
+    for (int i = 0; i < n; ++i) tiles_small += (it[i].tiles + 7) & ~7;
+    if (tiles_small >= pp_min_tiles())
+        for (int i = 0; i < n; ++i) {
+            const GemmArgs& a = list[it[i].idx];
+            const int cw = a.Wp2 ? gemm_bf16_rh_cw(a) : 0;
+            if (!cw) continue;
+            const int tn = rh_tn(a.N, cw);
+            it[i].cfg = cw == 64 ? (tn == 2 ? 3 : 4) : (cw == 48 ? (tn == 2 ? 5 : (tn == 3 ? 6 : 7)) : (tn == 2 ? 8 : 9));
+            it[i].tiles = ((a.M + 125) / 126) * ((a.N + 32 * tn - 1) / (32 * tn));
+            it[i].cost = (9.0 * a.Cin / BKH) * tn;
+            if (rh_lds_halves(cw, tn) > lds_halves) lds_halves = rh_lds_halves(cw, tn);
+            ++nrh;
+        }
     for (int i = 1; i < n; ++i)
         for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
     GroupArgsB ga;
@@ -745,6 +1085,7 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
     for (int i = 0; i < n; ++i) {
         GemmArgs a = list[it[i].idx];
         prep_conv_b(a);
+        if (it[i].cfg >= 3) { a.Wp = a.Wp2; a.Kpad = 9 * a.Cin; }       // (row-halo tile)
         ga.g[i] = a;
         ga.cfg[i] = it[i].cfg;
         ga.tiles[i] = it[i].tiles;
@@ -753,7 +1094,8 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
-    if (start >= pp_min_tiles()) hipLaunchKernelGGL(igemm_bf16_group_pp_kernel, dim3(start), dim3(256), 0, s, ga);
+    if (nrh) hipLaunchKernelGGL(igemm_bf16_group_rh_kernel, dim3(start), dim3(256), (size_t)lds_halves * 2, s, ga);
+    else if (start >= pp_min_tiles()) hipLaunchKernelGGL(igemm_bf16_group_pp_kernel, dim3(start), dim3(256), 0, s, ga);
     else hipLaunchKernelGGL(igemm_bf16_group_kernel, dim3(start), dim3(256), 0, s, ga);
     return hipGetLastError();
 }
@@ -770,6 +1112,11 @@ hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
     if (tiles128 >= pp_min_tiles()) {
+        if (a.Wp2 && gemm_bf16_rh_cw(a)) {
+            a.Wp = a.Wp2;
+            a.Kpad = 9 * a.Cin;
+            return launch_gemm_bf16_rh(a, s);
+        }
         if (a.N <= 32) return launch_cfg_b<128, 32, 32, 32, 1>(a, s);
         if (a.N <= 64) return ((long)a.M >= 128L * 512) ? launch_cfg_b<128, 64, 64, 32, 1>(a, s) : launch_cfg_b<64, 64, 32, 32, 1>(a, s);
         if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 512) return launch_cfg_b<128, 128, 64, 64, 1>(a, s);

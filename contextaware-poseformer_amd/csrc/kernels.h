@@ -26,6 +26,8 @@ FastDiv make_fastdiv(unsigned d);
 struct GemmArgs {
     const float* A;
     const float* Wp;    // packed weights [N][Kpad], K-contiguous, zero padded to Kpad (multiple of 32)
+    const float* Wp2;   // bf16 3x3 stride-1 convs: the same weights in the row-halo layout ([N][9 * Cin], igemm_bf16.hip), or
+                        // nullptr; launch_gemm_bf16 / _group switch to that kernel for launches of >= 2048 tiles
     const float* bias;  // [N] or nullptr
     const float* res;   // residual, addressed by rmap, or nullptr
     float* out;         // addressed by omap
@@ -84,6 +86,14 @@ hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
 bool gemm_bf16_groupable(const GemmArgs& a);
 hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s);   // bf16 twin of launch_gemm_f32_group
 const char* gemm_bf16_kernel_name(const GemmArgs& a);
+// row-halo variant of the 3x3 / stride-1 bf16 conv (one staged A tile serves the three kw taps): chunk width 64 / 48 / 32 or
+// 0 = not eligible; weights packed by launch_pack_conv_bf16_rh ([N][9 * Cin], K order (kh, Cin / CW, kw, CW))
+int bf16_rh_width(int Cin);
+int bf16_rh_preferred(int Cin);
+int gemm_bf16_rh_cw(const GemmArgs& a);
+hipError_t launch_gemm_bf16_rh(const GemmArgs& a, hipStream_t s);
+hipError_t launch_pack_conv_bf16_rh(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                                    float eps, void* Wp_bf16, float* bias, int Cout, int Cin, int CW, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);

@@ -126,6 +126,9 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     // F(4,3) (half the MFMAs of the direct conv) where the row length allows four-pixel tiles, F(2,3) (two thirds) otherwise.
     // HRNet only: F(4,3) pays inside the grouped multi-branch launches (+3.2 % end to end), not for CPN's lone convs (-0.8 %).
     if (use_wino) { pk.Kpad2 = pk.Kpad; pk.Kpad = ((x.W % 4 == 0 && wino_f43 && (cfg.backbone == CAPF_HRNET || wino_f43_cpn) && x.H * x.W >= wino_f43_min_hw && x.H * x.W <= wino_f43_max_hw) ? 18 : 12) * x.C; }
+    // bf16: the 3x3 stride-1 convs also keep their weights in the row-halo layout (igemm_bf16.hip: one staged activation tile
+    // for the three kw taps); launches of >= 2048 tiles run that kernel, smaller ones the ring kernel on the standard layout
+    if (use_bf16 && use_rh && ks == 3 && stride == 1 && bf16_rh_width(x.C) && Cout % 4 == 0) { pk.rh = true; pk.Kpad2 = 9 * x.C; }
     packs.push_back(pk);
 
     Op op;
@@ -853,6 +856,7 @@ bool Engine::build() {
     }
     if (const char* fz = getenv("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;      // A/B runs only
     if (const char* wz = getenv("CAPF_WINO")) use_wino = atoi(wz) != 0;                  // A/B runs only
+    if (const char* rz = getenv("CAPF_BF16_RH")) use_rh = atoi(rz) != 0;                 // A/B runs only
     if (const char* wb = getenv("CAPF_WINO_MIN_BATCH")) wino_min_batch = atoi(wb);
     if (const char* wf = getenv("CAPF_WINO_F43")) wino_f43 = atoi(wf) != 0;               // A/B runs only
     if (const char* wf = getenv("CAPF_WINO_F43_MINHW")) wino_f43_min_hw = atoi(wf);
@@ -917,6 +921,10 @@ bool Engine::build() {
         if (pk.wino) {
             pk.w2_off = off;
             off += round64((size_t)pk.N * pk.Kpad2);
+        }
+        if (pk.rh) {
+            pk.w2_off = off;
+            off += round64(((size_t)pk.N * pk.Kpad2 + 1) / 2);
         }
         pk.b_off = off;
         off += round64((size_t)pk.N);

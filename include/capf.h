@@ -229,6 +229,15 @@ int capf_op_conv_bf16(void* stream, const void* x_nhwc_bf16, const void* w_packe
                       const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout,
                       int ks, int stride, int act);
 
+/* "Row-halo" variant of the 3x3 / stride-1 / pad-1 bf16 conv (what capf_forward runs for the BasicBlock convs of a bf16 model
+ * from 2048 tiles per launch): K order (kh, Cin / cw, kw, cw) so that one staged activation tile serves the three kw taps.
+ * cw = capf_op_conv_bf16_rh_width(Cin) (64, 48 or 32; 0 = Cin not supported); w_packed is bf16 [Cout][9 * Cin].            */
+int capf_op_conv_bf16_rh_width(int Cin);
+int capf_op_pack_conv_bf16_rh(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
+                              const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);
+int capf_op_conv_bf16_rh(void* stream, const void* x_nhwc_bf16, const void* w_packed_bf16, const float* bias,
+                         const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout, int act);
+
 /* nn.Linear on the bf16 MFMA path (the lifter's qkv / proj / fc1 / fc2 under compute_dtype = CAPF_BF16, pose_dformer.py:15-59):
  * x bf16 [M,K], w bf16 [N,K] (K % 64 == 0), bias fp32; gelu_bf16_out = 0: y fp32 [M,N] = x w^T + bias (+ fp32 residual);
  * gelu_bf16_out = 1: y bf16 [M,N] = GELU(x w^T + bias) (exact erf).  fp32 accumulation in both.                        */

@@ -457,3 +457,34 @@ def test_abi_error_codes_on_a_device_handle():
     assert f2(2) < 0 and b"workspace" in e2.lib.capf_last_error(e2.h)
     with pytest.raises(CapfError):
         e2._check(f2(2), "forward")
+
+
+RH_CASES = [(64, 64, 32, 32, 2, 1, True), (48, 48, 24, 20, 1, 1, True), (32, 32, 16, 12, 3, 0, False), (96, 96, 9, 7, 2, 1, True),
+            (128, 256, 5, 3, 7, 1, False), (192, 192, 8, 8, 2, 1, True), (64, 36, 7, 5, 2, 1, True), (48, 48, 64, 64, 3, 1, True),
+            (32, 32, 1, 1, 5, 1, True), (64, 64, 2, 130, 1, 0, False)]
+
+
+@pytest.mark.parametrize("ci,co,H,W,B,act,res", RH_CASES)
+def test_conv_bf16_row_halo_matches_torch_on_bf16_rounded_operands(ci, co, H, W, B, act, res):
+    """The row-halo 3x3 kernel (one staged activation tile for the three kw taps, border taps zeroed in registers) against
+    fp32 F.conv2d of the SAME bf16-rounded operands; tiles of 126 pixels straddle image rows and images in every case."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(ci + co * 3 + H * 7 + W)
+    x = torch.randn(B, ci, H, W, generator=g).bfloat16()
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+           torch.rand(co, generator=g) * 0.4 + 0.8)
+    wp, bias, cw = capf.pack_conv_bf16_rh(w.cuda(), tuple(t.cuda() for t in bnp))
+    assert cw == (64 if ci % 64 == 0 else 48 if ci % 48 == 0 else 32)
+    w_fold = wp.float().cpu().view(co, 3, ci // cw, 3, cw).permute(0, 2, 4, 1, 3).reshape(co, ci, 3, 3)   # what the kernel multiplies
+    want = F.conv2d(x.float(), w_fold, bias.cpu(), 1, 1)
+    r = torch.randn_like(want).bfloat16() if res else None
+    if res:
+        want = want + r.float()
+    if act == 1:
+        want = F.relu(want)
+    got = capf.conv_nhwc_bf16_rh(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
+                                 r.permute(0, 2, 3, 1).contiguous().cuda() if res else None)
+    got = got.float().cpu().permute(0, 3, 1, 2)
+    tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
+    assert (got - want).abs().max().item() <= tol

@@ -12,10 +12,26 @@ ap.add_argument("--res", type=int, default=64)
 ap.add_argument("--ch", type=int, default=48)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--ks", type=int, default=3)
+ap.add_argument("--rh", action="store_true", help="time the row-halo kernel instead (no timeline)")
 a = ap.parse_args()
 x = torch.randn(a.batch, a.res, a.res, a.ch, device="cuda").bfloat16()
 w = torch.randn(a.ch, a.ch, a.ks, a.ks, device="cuda") * 0.05
 r = torch.randn(a.batch, a.res, a.res, a.ch, device="cuda").bfloat16()
+if a.rh:
+    ww, bw, cw = capf.pack_conv_bf16_rh(w)
+    for _ in range(10):
+        capf.conv_nhwc_bf16_rh(x, ww, bw, 1, r)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        capf.conv_nhwc_bf16_rh(x, ww, bw, 1, r)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100.0
+    flops = 2.0 * a.batch * a.res * a.res * a.ch * a.ch * 9
+    print(f"row-halo conv {a.batch}x{a.res}x{a.res}x{a.ch} cw{cw}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s")
+    sys.exit(0)
 ww, bw = capf.pack_conv_bf16(w)
 for _ in range(10):
     capf.conv_nhwc_bf16(x, ww, bw, a.ks, 1, 1, r)
