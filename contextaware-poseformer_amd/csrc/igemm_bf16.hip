@@ -475,15 +475,15 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
 // TN = 32-column blocks per tile (tile = 126 output pixels x 32 TN channels); the four waves split the 128 staged rows, each
 // computing 32 rows x 32 TN columns (1 A + TN B fragment reads per TN MFMAs).  LDS: (128 + 96 TN) x CW halves, at least the
 // epilogue's 18 KiB.
-template <int CW, int TN>
+template <int CW, int TM, int TN>
 __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int bid, unsigned short* __restrict__ lds) {
-    constexpr int BMO = 126, BN = 32 * TN;
+    constexpr int BMS = 128 * TM, BMO = BMS - 2, BN = 32 * TN;     // staged rows, output pixels, output channels per tile
     constexpr int QPR = CW / 8;                            // 16-byte quads per LDS row
     constexpr int KS = CW / 16;                            // MFMA k-steps per tap
-    constexpr int RA = QPR / 2;                            // DMA rounds (256 quads each) of the 128 x CW A tile
+    constexpr int RA = TM * QPR / 2;                       // DMA rounds (256 quads each) of the BMS x CW A tile
     constexpr int NBQ = 3 * BN * QPR;                      // quads of the 3 x BN x CW weight tile
     constexpr int RB = (NBQ + 255) / 256;
-    constexpr int BOFF = 128 * CW;                         // halves
+    constexpr int BOFF = BMS * CW;                         // halves
     static_assert(CW == 64 || CW == 48 || CW == 32, "chunk width");
 
     const unsigned short* A = reinterpret_cast<const unsigned short*>(p.A);
@@ -492,6 +492,11 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     unsigned short* Out = reinterpret_cast<unsigned short*>(p.out);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CAPF_DIAG
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_w = 0, dbg_a = 0, dbg_b = 0;
+    const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    B16_STAMP(dbg_t0);
     const int nbn = (p.N + BN - 1) / BN;
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
     const int m0 = tile_m * BMO, n0 = tile_n * BN;
@@ -540,9 +545,9 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     };
     // the accumulators start at the bias (transposed layout: register 4 g + e of block j = channel n0 + 32 j + 8 g + 4 fhalf + e),
     // so the epilogue needs no bias operand; the loads retire behind the first superchunk's
-    const int wm0 = wave * 32;
+    const int wm0 = wave * 32 * TM;
     const int frow = lane & 31, fhalf = lane >> 5;
-    f32x16 acc[TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -551,14 +556,17 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bv[e];
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = bv[e];
         }
-    bool zl, zr;                                           // this lane's output pixel sits on the left / right image border
-    {
-        const int m = m0 + wm0 + frow;
+    bool zl[TM], zr[TM];                                   // this lane's output pixel sits on the left / right image border
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + frow;
         const int w = m - fast_div_b(m, p.fd_wo) * p.W;    // (fd_wo divides by W: Wo == W here)
-        zl = w == 0;
-        zr = w == p.W - 1;
+        zl[i] = w == 0;
+        zr[i] = w == p.W - 1;
     }
     const int b_sw = swz(frow);                            // (weight rows j * 32 + frow: the swizzle only looks at frow's bits)
 
@@ -567,45 +575,58 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
                         (!Rs || ((p.rmap.S1 & 7) == 0 && (p.rmap.off & 7) == 0));
     const int er = lane >> 2, ec = (lane & 3) * 8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 rr[TN][2];
+    u32x4 rr[TM][TN][2];
     auto row_ok = [&](int i_local, int m) { return i_local < BMO && m < p.M; };
     auto prefetch_epilogue = [&]() {
         if (!vec_ok) return;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int il = wm0 + h * 16 + er, m = m0 + il, n = n0 + j * 32 + ec;
-                rr[j][h] = u32x4{0u, 0u, 0u, 0u};
-                if (Rs && row_ok(il, m) && n < p.N)
-                    rr[j][h] = *reinterpret_cast<const u32x4*>(Rs + (long)m * p.rmap.S1 + p.rmap.off + n);
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int il = wm0 + i * 32 + h * 16 + er, m = m0 + il, n = n0 + j * 32 + ec;
+                    rr[i][j][h] = u32x4{0u, 0u, 0u, 0u};
+                    if (Rs && row_ok(il, m) && n < p.N)
+                        rr[i][j][h] = *reinterpret_cast<const u32x4*>(Rs + (long)m * p.rmap.S1 + p.rmap.off + n);
+                }
     };
 
-    bf16x8 af[2], bfr[2][TN];
+    bf16x8 af[2][TM], bfr[2][TN];
     auto read_frags = [&](int u, int buf) {                // u = kw * KS + k-step
         const int kw = u / KS, st = u - kw * KS;
         const int lq = st * 2 + fhalf;
-        const int r = wm0 + frow + kw;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(r * QPR + (lq ^ swz(r))) * 8]);
-        if ((kw == 0 && zl) || (kw == 2 && zr)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        af[buf] = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm0 + i * 32 + frow + kw;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(r * QPR + (lq ^ swz(r))) * 8]);
+            if ((kw == 0 && zl[i]) || (kw == 2 && zr[i])) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            af[buf][i] = __builtin_bit_cast(bf16x8, v);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             bfr[buf][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(
                                                          &lds[BOFF + ((kw * BN + j * 32 + frow) * QPR + (lq ^ b_sw)) * 8]));
     };
+    B16_STAMP(dbg_t1);
     auto superchunk = [&](int kh, int cc) {
+        B16_STAMP(dbg_a);
         fire(kh, cc);
         wait_vmcnt_b<0>();
         __builtin_amdgcn_s_barrier();
+#ifdef CAPF_DIAG
+        B16_STAMP(dbg_b);
+        dbg_w += dbg_b - dbg_a;
+#endif
         read_frags(0, 0);
 #pragma unroll
         for (int u = 0; u < 3 * KS; ++u) {
             if (u + 1 < 3 * KS) read_frags(u + 1, (u + 1) & 1);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u & 1][j], af[u & 1], acc[j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u & 1][j], af[u & 1][i], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // every wave has read the stage: the next superchunk may overwrite it
@@ -619,6 +640,7 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     prefetch_epilogue();                                   // (last superchunk peeled: these registers are not live in the loop)
     superchunk(kh, cc);
 
+    B16_STAMP(dbg_t2);
     // ---- epilogue: the coalesced bf16 epilogue of igemm_bf16_tile (32x32 blocks transposed through the idle stage)
     constexpr int EPS = 36;
     float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
@@ -627,17 +649,19 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
         return (unsigned)f2bf(t);
     };
 #pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + ec;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(&ep[(lane & 31) * EPS + 8 * g + 4 * (lane >> 5)]) =
-                f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int row = h * 16 + er, il = wm0 + row, m = m0 + il;
+            const int row = h * 16 + er, il = wm0 + i * 32 + row, m = m0 + il;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
             if (!row_ok(il, m)) continue;
@@ -645,7 +669,7 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
                 u32x4 o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const unsigned rw = rr[j][h][q];
+                    const unsigned rw = rr[i][j][h][q];
                     const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
                     o[q] = finish(xa + __uint_as_float(rw << 16)) | (finish(xb + __uint_as_float(rw & 0xFFFF0000u)) << 16);
                 }
@@ -659,6 +683,15 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
             }
         }
     }
+#ifdef CAPF_DIAG
+    B16_STAMP(dbg_t3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = capf_bf16_timeline + (size_t)blockIdx.x * 8;
+        d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = dbg_t3; d[4] = __builtin_amdgcn_s_memtime();
+        d[5] = dbg_r0; d[6] = dbg_w; d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 #endif
 
@@ -825,13 +858,13 @@ hipError_t launch_gemm_bf16_smallc(const GemmArgs& a_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-static constexpr int rh_lds_halves(int cw, int tn) { return (128 + 96 * tn) * cw < 9216 ? 9216 : (128 + 96 * tn) * cw; }
+static constexpr int rh_lds_halves(int cw, int tm, int tn) { return (128 * tm + 96 * tn) * cw < 9216 ? 9216 : (128 * tm + 96 * tn) * cw; }
 
-template <int CW, int TN>
-__global__ __launch_bounds__(256, 4) void igemm_bf16_rh_kernel(GemmArgs p) {
+template <int CW, int TM, int TN>
+__global__ __launch_bounds__(256, TM == 1 ? 4 : 3) void igemm_bf16_rh_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) unsigned short lds[rh_lds_halves(CW, TN)];
-    igemm_bf16_rh_tile<CW, TN>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
+    __shared__ __attribute__((aligned(16))) unsigned short lds[rh_lds_halves(CW, TM, TN)];
+    igemm_bf16_rh_tile<CW, TM, TN>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
 #endif
 }
 
@@ -872,16 +905,15 @@ hipError_t launch_gemm_bf16_rh(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
     prep_rh(a);
     const int tn = rh_tn(a.N, cw);
+    // TM = 2 (254-pixel tiles, wave tile 64 x 32 TN: a third less LDS traffic per MFMA, 2-3 blocks per CU) measured equal or slower
+    // on every shape (48 ch 411 -> 398 TFLOP/s, 64 ch 666 -> 527 at CW 64 / 627 at CW 32, 128 ch 806 -> 793): not instantiated
     const dim3 grid(((a.M + 125) / 126) * ((a.N + 32 * tn - 1) / (32 * tn)));
+#define RH_CASE(CW_, TN_) case CW_ * 10 + TN_: hipLaunchKernelGGL((igemm_bf16_rh_kernel<CW_, 1, TN_>), grid, dim3(256), 0, s, a); break;
     switch (cw * 10 + tn) {
-        case 641: hipLaunchKernelGGL((igemm_bf16_rh_kernel<64, 1>), grid, dim3(256), 0, s, a); break;
-        case 642: hipLaunchKernelGGL((igemm_bf16_rh_kernel<64, 2>), grid, dim3(256), 0, s, a); break;
-        case 481: hipLaunchKernelGGL((igemm_bf16_rh_kernel<48, 1>), grid, dim3(256), 0, s, a); break;
-        case 482: hipLaunchKernelGGL((igemm_bf16_rh_kernel<48, 2>), grid, dim3(256), 0, s, a); break;
-        case 483: hipLaunchKernelGGL((igemm_bf16_rh_kernel<48, 3>), grid, dim3(256), 0, s, a); break;
-        case 321: hipLaunchKernelGGL((igemm_bf16_rh_kernel<32, 1>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((igemm_bf16_rh_kernel<32, 2>), grid, dim3(256), 0, s, a); break;
+        RH_CASE(64, 1) RH_CASE(64, 2) RH_CASE(48, 1) RH_CASE(48, 2) RH_CASE(48, 3) RH_CASE(32, 1) RH_CASE(32, 2)
+        default: return hipErrorInvalidValue;
     }
+#undef RH_CASE
     return hipGetLastError();
 }
 
@@ -987,13 +1019,13 @@ __global__ __launch_bounds__(256, 4) void igemm_bf16_group_rh_kernel(GroupArgsB 
         case 0: igemm_bf16_tile<128, 64, 64, 32, 1>(p, bid, lds); break;
         case 1: igemm_bf16_tile<64, 64, 32, 32, 1>(p, bid, lds); break;
         case 2: igemm_bf16_tile<128, 32, 32, 32, 1>(p, bid, lds); break;
-        case 3: igemm_bf16_rh_tile<64, 2>(p, bid, lds); break;
-        case 4: igemm_bf16_rh_tile<64, 1>(p, bid, lds); break;
-        case 5: igemm_bf16_rh_tile<48, 2>(p, bid, lds); break;
-        case 6: igemm_bf16_rh_tile<48, 3>(p, bid, lds); break;
-        case 7: igemm_bf16_rh_tile<48, 1>(p, bid, lds); break;
-        case 8: igemm_bf16_rh_tile<32, 2>(p, bid, lds); break;
-        default: igemm_bf16_rh_tile<32, 1>(p, bid, lds); break;
+        case 3: igemm_bf16_rh_tile<64, 1, 2>(p, bid, lds); break;
+        case 4: igemm_bf16_rh_tile<64, 1, 1>(p, bid, lds); break;
+        case 5: igemm_bf16_rh_tile<48, 1, 2>(p, bid, lds); break;
+        case 6: igemm_bf16_rh_tile<48, 1, 3>(p, bid, lds); break;
+        case 7: igemm_bf16_rh_tile<48, 1, 1>(p, bid, lds); break;
+        case 8: igemm_bf16_rh_tile<32, 1, 2>(p, bid, lds); break;
+        default: igemm_bf16_rh_tile<32, 1, 1>(p, bid, lds); break;
     }
 #endif
 }
@@ -1074,7 +1106,7 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
             it[i].cfg = cw == 64 ? (tn == 2 ? 3 : 4) : (cw == 48 ? (tn == 2 ? 5 : (tn == 3 ? 6 : 7)) : (tn == 2 ? 8 : 9));
             it[i].tiles = ((a.M + 125) / 126) * ((a.N + 32 * tn - 1) / (32 * tn));
             it[i].cost = (9.0 * a.Cin / BKH) * tn;
-            if (rh_lds_halves(cw, tn) > lds_halves) lds_halves = rh_lds_halves(cw, tn);
+            if (rh_lds_halves(cw, 1, tn) > lds_halves) lds_halves = rh_lds_halves(cw, 1, tn);
             ++nrh;
         }
     for (int i = 1; i < n; ++i)
