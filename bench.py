@@ -274,6 +274,7 @@ def main():
                 kc_work.copy_(kc0)
                 # the PRODUCT schedule, one event pair per launch (a grouped launch carries several convs)
                 ms, leader = eng.forward_profile_launches(img, k2d, kc_work, out_buf, stream.cuda_stream)
+                variants = eng.profile_variants()
                 members = {}
                 for i, l in enumerate(leader):
                     if l >= 0:
@@ -281,7 +282,9 @@ def main():
                 for l, ops_ in members.items():
                     kern = table[l][1]
                     if len(ops_) > 1 and kern.startswith("igemm"):
-                        kern = "igemm_bf16_group" if kern.startswith("igemm_bf16") else ("igemm_wino_group" if kern.startswith("igemm_wino") else "igemm_f32_group")
+                        # (the grouped bf16 launch has three device kernels: name the one this launch ran, as rocprofv3 will)
+                        kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh")[max(0, variants[l])] if kern.startswith("igemm_bf16")
+                                else ("igemm_wino_group" if kern.startswith("igemm_wino") else "igemm_f32_group"))
                     if not kern or table[l][0].startswith("copy."):
                         continue
                     e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0])

@@ -12,7 +12,7 @@ F32, BF16 = 0, 1
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
-    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_tensor", "capf_forward_stats",
+    "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_forward_profile_variants", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
@@ -71,6 +71,7 @@ def load_library():
     lib.capf_set_lanes.argtypes = [H, c_int]
     lib.capf_tensor.argtypes = [H, c_char_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int)]
     lib.capf_forward_stats.argtypes = [H, c_int, POINTER(c_int64), POINTER(c_double)]
+    lib.capf_forward_profile_variants.argtypes = [H, POINTER(c_int32), c_int]
     lib.capf_num_ops.argtypes = [H]
     lib.capf_op_info.argtypes = [H, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double)]
     lib.capf_op_bytes.argtypes = [H, c_int, c_int, POINTER(c_double)]
@@ -322,6 +323,13 @@ class Engine:
                                                            c_void_p(k2d.data_ptr()), c_void_p(kcrop.data_ptr()), B,
                                                            c_void_p(out.data_ptr()), ms, leader, n), "forward_profile_launches")
         return list(ms), list(leader)
+
+    def profile_variants(self):
+        """After forward_profile_launches: the device kernel of every grouped bf16 launch, by leader op (-1 elsewhere)."""
+        n = self.lib.capf_num_ops(self.h)
+        v = (c_int32 * n)()
+        self._check(self.lib.capf_forward_profile_variants(self.h, v, n), "forward_profile_variants")
+        return list(v)
 
     def stats(self, batch):
         n, f = c_int64(), c_double()

@@ -242,7 +242,11 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
                 if (n == 0) return CAPF_OK;
                 if (log) HIP_TRY(log->mark(s, members, n));
                 if (pass == 0) HIP_TRY(launch_gemm_f32_group(group, n, s));
-                else if (pass == 1) HIP_TRY(launch_gemm_bf16_group(group, n, s));
+                else if (pass == 1) {
+                    int v = -1;
+                    HIP_TRY(launch_gemm_bf16_group(group, n, s, &v));
+                    if (log && !log->op_variant.empty()) log->op_variant[members[0]] = v;
+                }
                 else HIP_TRY(launch_gemm_wino_group(group, n, s));
                 n = 0;
                 return CAPF_OK;
@@ -937,13 +941,21 @@ int capf_forward_profile_launches(capf_handle* h, void* stream, const float* ima
     e.invalidate_train();
     capf::LaunchLog log;
     log.op_leader.assign(n, -1);
+    log.op_variant.assign(n, -1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = e.run(s, batch, 0, n, nullptr, &log);
+    e.last_variants = log.op_variant;
     if (rc == CAPF_OK && hipStreamSynchronize(s) != hipSuccess) rc = CAPF_ERR_HIP;
     for (int i = 0; i < n; ++i) { op_ms[i] = 0.f; op_leader[i] = log.op_leader[i]; }
     for (size_t k = 0; k < log.leader.size() && rc == CAPF_OK; ++k)
         if (hipEventElapsedTime(&op_ms[log.leader[k]], log.ev[k], log.ev[k + 1]) != hipSuccess) rc = CAPF_ERR_HIP;
     return rc;
+}
+
+int capf_forward_profile_variants(const capf_handle* h, int32_t* op_variant, int n_ops) {
+    if (!h || !op_variant || n_ops < (int)h->e.last_variants.size()) return CAPF_ERR_INVALID;
+    for (size_t i = 0; i < h->e.last_variants.size(); ++i) op_variant[i] = h->e.last_variants[i];
+    return CAPF_OK;
 }
 
 int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops) {

@@ -121,6 +121,7 @@ struct LaunchLog {
     std::vector<hipEvent_t> ev;
     std::vector<int> leader;
     std::vector<int> op_leader;
+    std::vector<int> op_variant;       // per leader op: which device kernel a grouped bf16 launch chose (kernels.h), -1 otherwise
     hipError_t mark(hipStream_t s, const int* members, int n) {
         hipEvent_t e;
         hipError_t r = hipEventCreate(&e);
@@ -170,6 +171,7 @@ struct Engine {
     bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)
+    std::vector<int> last_variants;   // capf_forward_profile_launches: grouped-bf16 kernel variant per leader op
     bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)
     bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)

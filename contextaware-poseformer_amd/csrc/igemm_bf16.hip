@@ -1071,7 +1071,8 @@ static void prep_conv_b(GemmArgs& a) {
 
 bool gemm_bf16_groupable(const GemmArgs& a) { return bf16_ok(a) && a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale; }
 
-hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
+hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s, int* variant) {
+    if (variant) *variant = -1;
     if (n <= 0) return hipSuccess;
     if (n == 1) return launch_gemm_bf16(list[0], s);
     if (n > MAXG) return hipErrorInvalidValue;
@@ -1126,6 +1127,7 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; }
+    if (variant) *variant = nrh ? 2 : (start >= pp_min_tiles() ? 1 : 0);
     if (nrh) hipLaunchKernelGGL(igemm_bf16_group_rh_kernel, dim3(start), dim3(256), (size_t)lds_halves * 2, s, ga);
     else if (start >= pp_min_tiles()) hipLaunchKernelGGL(igemm_bf16_group_pp_kernel, dim3(start), dim3(256), 0, s, ga);
     else hipLaunchKernelGGL(igemm_bf16_group_kernel, dim3(start), dim3(256), 0, s, ga);

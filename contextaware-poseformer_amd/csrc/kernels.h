@@ -84,7 +84,9 @@ hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float
 // bf16 conv (igemm_bf16.hip): A / res / out bf16 NHWC, Wp bf16 [N][Kpad], Kpad % 64 == 0, bias fp32
 hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
 bool gemm_bf16_groupable(const GemmArgs& a);
-hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s);   // bf16 twin of launch_gemm_f32_group
+// bf16 twin of launch_gemm_f32_group; *variant (optional) = the device kernel it chose: 0 ring (igemm_bf16_group_kernel),
+// 1 ping-pong (igemm_bf16_group_pp_kernel), 2 ping-pong with row-halo tiles (igemm_bf16_group_rh_kernel), -1 single launch
+hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s, int* variant = nullptr);
 const char* gemm_bf16_kernel_name(const GemmArgs& a);
 // row-halo variant of the 3x3 / stride-1 bf16 conv (one staged A tile serves the three kw taps): chunk width 64 / 48 / 32 or
 // 0 = not eligible; weights packed by launch_pack_conv_bf16_rh ([N][9 * Cin], K order (kh, Cin / CW, kw, CW))

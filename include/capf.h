@@ -179,6 +179,10 @@ int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, in
 
 /* Number of kernel launches and algorithmic FLOPs (2*MAC of convs + GEMMs) of one forward at
  * `batch`; used by bench.py for the roofline line. */
+/* after capf_forward_profile_launches: for every leader op of a grouped bf16 conv launch, which device kernel the launch ran
+ * (0 igemm_bf16_group_kernel: ring schedule, 1 igemm_bf16_group_pp_kernel: ping-pong, 2 igemm_bf16_group_rh_kernel: ping-pong
+ * with row-halo tiles); -1 for every other op.  Lets bench.py name launches the way rocprofv3 does.                         */
+int capf_forward_profile_variants(const capf_handle* h, int32_t* op_variant, int n_ops);
 int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops);
 
 /* ---- stateless operator entry points (op-level parity tests and micro-benchmarks) ---------------

@@ -18,26 +18,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.match(r"void capf::igemm_f32_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+),", name)
+    m = re.match(r"(?:void )?capf::igemm_f32_kernel<(\d+), (\d+), (\d+), \d+, \d+, \d+, (\d+),", name)
     if m:
         nw, bm, bn, mode = m.groups()
         return f"igemm_f32<w{nw},{bm}x{bn},{'conv' if mode == '1' else 'rows'}>"
-    m = re.match(r"void capf::igemm_bf16_kernel<(\d+), (\d+),", name)
+    m = re.match(r"(?:void )?capf::igemm_bf16_kernel<(\d+), (\d+),", name)
     if m:
         return f"igemm_bf16<w4,{m.group(1)}x{m.group(2)},conv>"
-    m = re.match(r"void capf::igemm_wino_group_kernel", name)
+    m = re.match(r"(?:void )?capf::igemm_wino_group_kernel", name)
     if m:
         return "igemm_wino_group"
-    m = re.match(r"void capf::igemm_wino_kernel", name)
+    m = re.match(r"(?:void )?capf::igemm_wino_kernel", name)
     if m:
         return "igemm_wino<w4,F(2,3)/F(4,3)>"
-    m = re.match(r"void capf::igemm_f32_group_kernel", name)
+    m = re.match(r"(?:void )?capf::igemm_f32_group_kernel", name)
     if m:
         return "igemm_f32_group"
-    m = re.match(r"void capf::igemm_bf16_group_kernel", name)
+    m = re.match(r"(?:void )?capf::igemm_bf16_group_(pp|rh)_kernel", name)
+    if m:
+        return "igemm_bf16_group_" + m.group(1)
+    m = re.match(r"(?:void )?capf::igemm_bf16_rh_kernel", name)
+    if m:
+        return "igemm_bf16_rh<w4,126x64,conv>"
+    m = re.match(r"(?:void )?capf::igemm_bf16_smallc_kernel", name)
+    if m:
+        return "igemm_bf16_smallc<w4,128x64>"
+    m = re.match(r"(?:void )?capf::igemm_bf16_group_kernel", name)
     if m:
         return "igemm_bf16_group"
-    m = re.match(r"void capf::igemm_f32_smallc_kernel", name)
+    m = re.match(r"(?:void )?capf::igemm_f32_smallc_kernel", name)
     if m:
         return "igemm_f32_smallc<w4,128x64>"
     m = re.match(r"(?:void )?capf::(\w+?)(?:_kernel)?[<(]", name)
