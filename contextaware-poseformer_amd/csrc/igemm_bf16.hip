@@ -879,11 +879,10 @@ int bf16_rh_width(int Cin) {
     return Cin % 64 == 0 ? 64 : (Cin % 48 == 0 ? 48 : (Cin % 32 == 0 ? 32 : 0));
 }
 
-// ... that the engine should use: the kernel wins where a chunk is 64 channels wide, or 48 with one chunk per tap row.
-// Measured against the ping-pong direct kernel at >= 2048 tiles (tools/bf16_timeline.py, TFLOP/s direct -> row-halo):
-// 64 ch 64x64 598 -> 673, 64 ch 32x32 587 -> 666, 128 ch 756 -> 830, 192 ch 582 -> 671, 256 ch 772 -> 776, 48 ch 358 -> 383;
-// 96 ch (two 48-wide chunks, 64-wide tiles compute 128 columns for 96) 469 -> 443, 32 ch (64-wide tile for 32 columns) 342 -> 322.
-int bf16_rh_preferred(int Cin) { return Cin % 64 == 0 || Cin == 48; }
+// Measured against the ping-pong direct kernel at >= 2048 tiles (tools/bf16_timeline.py, TFLOP/s direct -> row-halo, final tile
+// shapes): 64 ch 598 -> 666, 128 ch 756 -> 830, 192 ch 582 -> 671, 256 ch 772 -> 776, 48 ch 358 -> 411, 96 ch 469 -> 546, 32 ch
+// 342 -> 472.  Inside a grouped launch every eligible problem takes the row-halo tile: mixing the two tile families in one grid
+// measured slower (HRNet-48 batch 256: 10730 vs 11200 frames/s) than moving all of them.
 
 // ... for a conv: 0 unless it is 3x3 / stride 1 / pad 1 with plain row maps
 int gemm_bf16_rh_cw(const GemmArgs& a) {

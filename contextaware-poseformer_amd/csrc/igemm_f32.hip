@@ -981,13 +981,15 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 0; ga.splits[i] = 1; }
-#ifdef CAPF_DIAG
-    static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
-    if (abl == 7) hipLaunchKernelGGL((igemm_f32_group_kernel<7>), dim3(start), dim3(256), 0, s, ga);
-    else
-#endif
     bool any_split = false;
     for (int i = 0; i < n; ++i) any_split |= ga.splits[i] > 1;
+#ifdef CAPF_DIAG
+    static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
+    if (abl == 7 && !any_split) {
+        hipLaunchKernelGGL((igemm_f32_group_kernel<7>), dim3(start), dim3(256), 0, s, ga);
+        return hipGetLastError();
+    }
+#endif
     if (any_split) hipLaunchKernelGGL((igemm_f32_group_kernel<0, true>), dim3(start), dim3(256), 0, s, ga);
     else hipLaunchKernelGGL((igemm_f32_group_kernel<0>), dim3(start), dim3(256), 0, s, ga);
     return hipGetLastError();

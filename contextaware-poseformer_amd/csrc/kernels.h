@@ -91,7 +91,6 @@ const char* gemm_bf16_kernel_name(const GemmArgs& a);
 // row-halo variant of the 3x3 / stride-1 bf16 conv (one staged A tile serves the three kw taps): chunk width 64 / 48 / 32 or
 // 0 = not eligible; weights packed by launch_pack_conv_bf16_rh ([N][9 * Cin], K order (kh, Cin / CW, kw, CW))
 int bf16_rh_width(int Cin);
-int bf16_rh_preferred(int Cin);
 int gemm_bf16_rh_cw(const GemmArgs& a);
 hipError_t launch_gemm_bf16_rh(const GemmArgs& a, hipStream_t s);
 hipError_t launch_pack_conv_bf16_rh(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
