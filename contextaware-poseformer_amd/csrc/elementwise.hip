@@ -9,11 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 // 4 consecutive channels of an NHWC tensor stored as fp32 (16 B) or bf16 (8 B); arithmetic is always fp32
-__device__ __forceinline__ unsigned short f2bf_e(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf_e(float f) { return to_bf16(f); }
 template <bool BF>
 __device__ __forceinline__ f32x4 load4(const float* base, long i4) {
     if (!BF) return reinterpret_cast<const f32x4*>(base)[i4];
@@ -26,10 +22,8 @@ __device__ __forceinline__ f32x4 load4(const float* base, long i4) {
 template <bool BF>
 __device__ __forceinline__ void store4(float* base, long i4, f32x4 v) {
     if (!BF) { reinterpret_cast<f32x4*>(base)[i4] = v; return; }
-    u16x4 h;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = f2bf_e(v[e]);
-    reinterpret_cast<u16x4*>(base)[i4] = h;
+    typedef unsigned u32x2_e __attribute__((ext_vector_type(2)));
+    reinterpret_cast<u32x2_e*>(base)[i4] = u32x2_e{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
 
 // ---- BN fold + re-layout of a conv weight (eval-mode BatchNorm, pose_hrnet.py:72-75 etc.) ---------
@@ -206,7 +200,7 @@ __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict_
                                  lh1 * (lw0 * __uint_as_float(q10[e] << 16) + lw1 * __uint_as_float(q11[e] << 16));
                 const float hi = lh0 * (lw0 * __uint_as_float(q00[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q01[e] & 0xFFFF0000u)) +
                                  lh1 * (lw0 * __uint_as_float(q10[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q11[e] & 0xFFFF0000u));
-                o[e] = (unsigned)f2bf_e(lo) | ((unsigned)f2bf_e(hi) << 16);
+                o[e] = pack_bf16x2(lo, hi);
             }
             reinterpret_cast<u32x4*>(out)[i] = o;
         } else {

@@ -36,11 +36,7 @@ static constexpr int BKH = 64;     // K chunk in bf16 elements = 128 B per tile 
 __device__ __forceinline__ int fast_div_b(int n, FastDiv d) {
     return (int)((__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift);
 }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return to_bf16(f); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -425,7 +421,7 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                     auto finish = [&](float t) {
                         if (GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
                         if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-                        return (unsigned)f2bf(t);
+                        return t;
                     };
                     if (vec_ok) {
                         u32x4 o;
@@ -435,8 +431,7 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                             const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
                             const float ba = q < 2 ? bb[j][0][2 * q] : bb[j][1][2 * q - 4];
                             const float bc = q < 2 ? bb[j][0][2 * q + 1] : bb[j][1][2 * q - 3];
-                            o[q] = finish(xa + ba + __uint_as_float(rw << 16)) |
-                                   (finish(xb + bc + __uint_as_float(rw & 0xFFFF0000u)) << 16);
+                            o[q] = pack_bf16x2(finish(xa + ba + __uint_as_float(rw << 16)), finish(xb + bc + __uint_as_float(rw & 0xFFFF0000u)));
                         }
                         if (full || (m < p.M && n < p.N))
                             *reinterpret_cast<u32x4*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = o;
@@ -445,7 +440,7 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                             const float x = e < 4 ? x0[e & 3] : x1[e & 3];
                             const float bsv = p.bias ? p.bias[n + e] : 0.f;
                             const float rsv = Rs ? bf2f(Rs[(long)m * p.rmap.S1 + p.rmap.off + n + e]) : 0.f;
-                            Out[(long)m * p.omap.S1 + p.omap.off + n + e] = (unsigned short)finish(x + bsv + rsv);
+                            Out[(long)m * p.omap.S1 + p.omap.off + n + e] = f2bf(finish(x + bsv + rsv));
                         }
                     }
                 }
@@ -644,10 +639,7 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     // ---- epilogue: the coalesced bf16 epilogue of igemm_bf16_tile (32x32 blocks transposed through the idle stage)
     constexpr int EPS = 36;
     float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
-    auto finish = [&](float t) {
-        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-        return (unsigned)f2bf(t);
-    };
+    auto finish = [&](float t) { return p.act == ACT_RELU ? fmaxf(t, 0.f) : t; };
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -671,14 +663,14 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
                 for (int q = 0; q < 4; ++q) {
                     const unsigned rw = rr[i][j][h][q];
                     const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
-                    o[q] = finish(xa + __uint_as_float(rw << 16)) | (finish(xb + __uint_as_float(rw & 0xFFFF0000u)) << 16);
+                    o[q] = pack_bf16x2(finish(xa + __uint_as_float(rw << 16)), finish(xb + __uint_as_float(rw & 0xFFFF0000u)));
                 }
                 if (n < p.N) *reinterpret_cast<u32x4*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = o;
             } else {
                 for (int e = 0; e < 8 && n + e < p.N; ++e) {
                     const float x = e < 4 ? x0[e & 3] : x1[e & 3];
                     const float rsv = Rs ? bf2f(Rs[(long)m * p.rmap.S1 + p.rmap.off + n + e]) : 0.f;
-                    Out[(long)m * p.omap.S1 + p.omap.off + n + e] = (unsigned short)finish(x + rsv);
+                    Out[(long)m * p.omap.S1 + p.omap.off + n + e] = f2bf(finish(x + rsv));
                 }
             }
         }
@@ -791,13 +783,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_smallc_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
             *reinterpret_cast<u32x2*>(&As[(srow + 32 * i) * SPITCH + kq]) =
-                u32x2{(unsigned)f2bf(a_reg[i][0]) | ((unsigned)f2bf(a_reg[i][1]) << 16),
-                      (unsigned)f2bf(a_reg[i][2]) | ((unsigned)f2bf(a_reg[i][3]) << 16)};
+                u32x2{pack_bf16x2(a_reg[i][0], a_reg[i][1]), pack_bf16x2(a_reg[i][2], a_reg[i][3])};
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             *reinterpret_cast<u32x2*>(&Bs[(srow + 32 * i) * SPITCH + kq]) =
-                u32x2{(unsigned)f2bf(b_reg[i][0]) | ((unsigned)f2bf(b_reg[i][1]) << 16),
-                      (unsigned)f2bf(b_reg[i][2]) | ((unsigned)f2bf(b_reg[i][3]) << 16)};
+                u32x2{pack_bf16x2(b_reg[i][0], b_reg[i][1]), pack_bf16x2(b_reg[i][2], b_reg[i][3])};
         __syncthreads();
         if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll

@@ -757,9 +757,7 @@ __global__ __launch_bounds__(256) void igemm_f32_smallc_kernel(GemmArgs p) {
                     if (p.res) v += p.res[rowmap(p.rmap, m) + n];
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                     if (p.out_bf16) {
-                        unsigned u = __float_as_uint(v);
-                        u += 0x7FFFu + ((u >> 16) & 1u);
-                        reinterpret_cast<unsigned short*>(p.out)[rowmap(p.omap, m) + n] = (unsigned short)(u >> 16);
+                        reinterpret_cast<unsigned short*>(p.out)[rowmap(p.omap, m) + n] = to_bf16(v);
                     } else
                     p.out[rowmap(p.omap, m) + n] = v;
                 }

@@ -5,6 +5,20 @@
 
 namespace capf {
 
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction);
+// the software form (5 integer ops per value) made the bf16 epilogues VALU-bound.  Host passes never call these.
+__host__ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {          // lo in bits 0-15
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+#else
+    (void)lo; (void)hi;
+    return 0u;
+#endif
+}
+__host__ __device__ __forceinline__ unsigned short to_bf16(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
+
 // addr(m) = (m / G) * S1 + (m % G) * S2 + off   (elements).  G == 1 -> plain leading dimension S1.
 struct RowMap {
     int G;

@@ -124,11 +124,7 @@ hipError_t launch_sample_ref(const float* feat, const float* ref, float* S, int*
 }
 
 // ---- LayerNorm, one wave per row (two-pass, like ATen's CPU kernel) -------------------------------
-__device__ __forceinline__ unsigned short f2bf_l(float f) {     // round-to-nearest-even, like every bf16 store of the path
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf_l(float f) { return to_bf16(f); }    // round-to-nearest-even, like every bf16 store of the path
 // OB: the normalised rows are written as bf16 (the A operand of a bf16 MFMA projection, compute_dtype = bf16)
 template <int MAXV, bool OB = false>
 __global__ void layernorm_kernel(const float* __restrict__ in, RowMap imap, const float* __restrict__ add,
@@ -265,8 +261,8 @@ __device__ __forceinline__ void st4(float* out, long idx, f32x4 v) {
     if (!OB) { *reinterpret_cast<f32x4*>(out + idx) = v; return; }
     unsigned short* o = reinterpret_cast<unsigned short*>(out) + idx;
     uint2 pk;
-    pk.x = (unsigned)f2bf_l(v[0]) | ((unsigned)f2bf_l(v[1]) << 16);
-    pk.y = (unsigned)f2bf_l(v[2]) | ((unsigned)f2bf_l(v[3]) << 16);
+    pk.x = pack_bf16x2(v[0], v[1]);
+    pk.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(o) = pk;
 }
 

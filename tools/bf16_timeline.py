@@ -12,11 +12,14 @@ ap.add_argument("--res", type=int, default=64)
 ap.add_argument("--ch", type=int, default=48)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--ks", type=int, default=3)
+ap.add_argument("--cout", type=int, default=0, help="output channels (default: --ch)")
+ap.add_argument("--width", type=int, default=0, help="image width (default: --res)")
 ap.add_argument("--rh", action="store_true", help="time the row-halo kernel instead (no timeline)")
 a = ap.parse_args()
-x = torch.randn(a.batch, a.res, a.res, a.ch, device="cuda").bfloat16()
-w = torch.randn(a.ch, a.ch, a.ks, a.ks, device="cuda") * 0.05
-r = torch.randn(a.batch, a.res, a.res, a.ch, device="cuda").bfloat16()
+co, wd = a.cout or a.ch, a.width or a.res
+x = torch.randn(a.batch, a.res, wd, a.ch, device="cuda").bfloat16()
+w = torch.randn(co, a.ch, a.ks, a.ks, device="cuda") * 0.05
+r = torch.randn(a.batch, a.res, wd, co, device="cuda").bfloat16()
 if a.rh:
     ww, bw, cw = capf.pack_conv_bf16_rh(w)
     for _ in range(10):
@@ -29,7 +32,7 @@ if a.rh:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100.0
-    flops = 2.0 * a.batch * a.res * a.res * a.ch * a.ch * 9
+    flops = 2.0 * a.batch * a.res * wd * a.ch * co * 9
     print(f"row-halo conv {a.batch}x{a.res}x{a.res}x{a.ch} cw{cw}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s")
     if not hasattr(capf.load_library(), "capf_debug_bf16_timeline"):
         sys.exit(0)
@@ -44,9 +47,10 @@ for _ in range(0 if a.rh else 10):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100.0
-flops = 2.0 * a.batch * a.res * a.res * a.ch * a.ch * a.ks * a.ks
+flops = 2.0 * a.batch * a.res * wd * a.ch * co * a.ks * a.ks
+hbm = 2.0 * a.batch * a.res * wd * (a.ch + 2 * co)
 if not a.rh:
-    print(f"conv {a.batch}x{a.res}x{a.res}x{a.ch} ks{a.ks}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s")
+    print(f"conv {a.batch}x{a.res}x{wd}x{a.ch}->{co} ks{a.ks}: {us:.1f} us  {flops / us / 1e6:.1f} TFLOP/s  {hbm / us / 1e6:.2f} TB/s (in + residual + out)")
 lib = capf.load_library()
 nb = 8192
 buf = np.zeros((nb, 8), dtype=np.uint64)
