@@ -88,42 +88,66 @@ hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad,
 
 // ---- HRNet fuse: out = relu(sum_i nearest_up(in_i))  (pose_hrnet.py:294-301, nn.Upsample nearest) --
 // Input i has resolution (H >> shift_i, W >> shift_i); nearest upsampling by 2^s reads (h>>s, w>>s).
-template <bool BF>
+// V channels per lane: 4 (fp32 16 B, bf16 8 B) or 8 (bf16, 16 B); pixel arithmetic in 32 bits (B * H * W < 2^31, launcher checks)
+template <bool BF, int V>
 __global__ void fuse_sum_kernel(FuseSumArgs a) {
-    const int C4 = a.C >> 2;
-    const long total = (long)a.B * a.H * a.W * C4;
+    constexpr int Q = V / 4;                                  // 4-channel groups per lane
+    const int CV = a.C / V, C4 = a.C >> 2;
+    const long total = (long)a.B * a.H * a.W * CV;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long pix = i / C4;
-        const int w = (int)(pix % a.W);
-        pix /= a.W;
-        const int h = (int)(pix % a.H);
-        const int b = (int)(pix / a.H);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const unsigned pix = (unsigned)(i / CV);
+        const int cv = (int)(i - (long)pix * CV);
+        const unsigned row = pix / (unsigned)a.W;
+        const int w = (int)(pix - row * (unsigned)a.W);
+        const int b = (int)(row / (unsigned)a.H), h = (int)(row - (unsigned)b * (unsigned)a.H);
+        f32x4 acc[Q];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < a.n_in) {
                 const int s = a.shift[k];
                 const int hs = a.H >> s, ws = a.W >> s;
-                const long off = ((((long)b * hs + (h >> s)) * ws + (w >> s)) * C4 + c4);
-                const f32x4 v = load4<BF>(a.in[k], off);
-                acc = k == 0 ? v : acc + v;          // same order as the reference: ((x0 + x1) + x2) + x3
+                const long off = ((((long)b * hs + (h >> s)) * ws + (w >> s)) * C4 + cv * Q);
+                if (V == 8) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 q = reinterpret_cast<const u32x4*>(a.in[k])[off >> 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {               // same order as the reference: ((x0 + x1) + x2) + x3
+                        const float lo = __uint_as_float(q[e] << 16), hi = __uint_as_float(q[e] & 0xFFFF0000u);
+                        acc[e >> 1][(e & 1) * 2] = k == 0 ? lo : acc[e >> 1][(e & 1) * 2] + lo;
+                        acc[e >> 1][(e & 1) * 2 + 1] = k == 0 ? hi : acc[e >> 1][(e & 1) * 2 + 1] + hi;
+                    }
+                } else {
+                    const f32x4 v = load4<BF>(a.in[k], off);
+                    acc[0] = k == 0 ? v : acc[0] + v;
+                }
             }
         }
         if (a.relu) {
-            acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f);
-            acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                acc[q][0] = fmaxf(acc[q][0], 0.f); acc[q][1] = fmaxf(acc[q][1], 0.f);
+                acc[q][2] = fmaxf(acc[q][2], 0.f); acc[q][3] = fmaxf(acc[q][3], 0.f);
+            }
         }
-        store4<BF>(a.out, i, acc);
+        if (V == 8) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            reinterpret_cast<u32x4*>(a.out)[i] = u32x4{pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[0][2], acc[0][3]),
+                                                       pack_bf16x2(acc[Q - 1][0], acc[Q - 1][1]), pack_bf16x2(acc[Q - 1][2], acc[Q - 1][3])};
+        } else {
+            store4<BF>(a.out, i, acc[0]);
+        }
     }
 }
 
 hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s) {
-    const long total = (long)a.B * a.H * a.W * (a.C >> 2);
+    if ((long)a.B * a.H * a.W >= (1L << 31)) return hipErrorInvalidValue;
+    const int V = (a.bf16 && a.C % 8 == 0) ? 8 : 4;
+    const long total = (long)a.B * a.H * a.W * (a.C / V);
     const long want = (total + 255) / 256;
-    const int blocks = (int)(want < 4096 ? want : 4096);
-    if (a.bf16) hipLaunchKernelGGL(fuse_sum_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fuse_sum_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+    const int blocks = (int)(want < 16384 ? want : 16384);
+    if (V == 8) hipLaunchKernelGGL((fuse_sum_kernel<true, 8>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.bf16) hipLaunchKernelGGL((fuse_sum_kernel<true, 4>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((fuse_sum_kernel<false, 4>), dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
