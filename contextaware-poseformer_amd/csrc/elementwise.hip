@@ -152,43 +152,51 @@ hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s) {
 }
 
 // ---- 3x3 stride-2 pad-1 max pool (networks/resnet.py:104, :140) ----------------------------------
-template <bool BF>
+template <bool BF, int V>      // V channels per lane: 4, or 8 for bf16 (16-byte accesses)
 __global__ void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                int C, int Ho, int Wo) {
-    const int C4 = C >> 2;
-    const long total = (long)B * Ho * Wo * C4;
+    constexpr int Q = V / 4;
+    const int CV = C / V, C4 = C >> 2;
+    const long total = (long)B * Ho * Wo * CV;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long pix = i / C4;
-        const int wo = (int)(pix % Wo);
-        pix /= Wo;
-        const int ho = (int)(pix % Ho);
-        const int b = (int)(pix / Ho);
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const unsigned pix = (unsigned)(i / CV);                   // B * Ho * Wo < 2^31 (launcher checks)
+        const int cv = (int)(i - (long)pix * CV);
+        const unsigned row = pix / (unsigned)Wo;
+        const int wo = (int)(pix - row * (unsigned)Wo);
+        const int b = (int)(row / (unsigned)Ho), ho = (int)(row - (unsigned)b * (unsigned)Ho);
+        f32x4 m[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) m[q] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int kh = 0; kh < 3; ++kh) {
             const int hi = ho * 2 - 1 + kh;
             if ((unsigned)hi >= (unsigned)H) continue;
             for (int kw = 0; kw < 3; ++kw) {
                 const int wi = wo * 2 - 1 + kw;
                 if ((unsigned)wi >= (unsigned)W) continue;
-                const f32x4 v = load4<BF>(in, (((long)b * H + hi) * W + wi) * C4 + c4);
-                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]);
-                m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                const long off = (((long)b * H + hi) * W + wi) * C4 + cv * Q;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const f32x4 v = load4<BF>(in, off + q);
+                    m[q][0] = fmaxf(m[q][0], v[0]); m[q][1] = fmaxf(m[q][1], v[1]);
+                    m[q][2] = fmaxf(m[q][2], v[2]); m[q][3] = fmaxf(m[q][3], v[3]);
+                }
             }
         }
-        store4<BF>(out, i, m);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) store4<BF>(out, i * Q + q, m[q]);
     }
 }
 
 hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
                                hipStream_t s, int bf16) {
-    const long total = (long)B * Ho * Wo * (C >> 2);
+    if ((long)B * Ho * Wo >= (1L << 31)) return hipErrorInvalidValue;
+    const int V = (bf16 && C % 8 == 0) ? 8 : 4;
+    const long total = (long)B * Ho * Wo * (C / V);
     const long want = (total + 255) / 256;
-    if (bf16)
-        hipLaunchKernelGGL(maxpool_kernel<true>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo);
-    else
-    hipLaunchKernelGGL(maxpool_kernel<false>, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, in, out, B, H,
-                       W, C, Ho, Wo);
+    const dim3 grid((int)(want < 16384 ? want : 16384));
+    if (V == 8) hipLaunchKernelGGL((maxpool_kernel<true, 8>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo);
+    else if (bf16) hipLaunchKernelGGL((maxpool_kernel<true, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL((maxpool_kernel<false, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo);
     return hipGetLastError();
 }
 

@@ -833,18 +833,155 @@ __global__ __launch_bounds__(256) void igemm_bf16_smallc_kernel(GemmArgs p) {
 #endif
 }
 
+// Stem, second version (Cin = 3, k = 7 or 3): for a fixed (output pixel, kh) the 3 k input values are CONTIGUOUS in the NHWC
+// image (and in the (kh, kw, c)-ordered weights), so a thread fetches one such run with 16-byte loads (dword-aligned
+// addresses) instead of 21 / 9 scalar gathers, zeroes what lies outside the image, and writes it as bf16 into an LDS tile
+// whose K axis is (kh, 24 | 16): the whole K of a 128 x 64 tile is staged once (no chunk loop), then 11 / 3 MFMA k-steps.
+template <int KS, int BM>
+__global__ __launch_bounds__(256) void igemm_bf16_stem_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BN = 64, WM = BM / 2, WN = 32, TM = WM / 32;
+    constexpr int RUN = KS * 3;                      // contiguous floats per (pixel, kh)
+    constexpr int NX4 = (RUN + 3) / 4;               // 16-byte loads per run
+    constexpr int PKH = (RUN + 7) / 8 * 8;           // halves per kh in LDS (24 / 16)
+    constexpr int KP = (KS * PKH + 15) / 16 * 16;    // staged K (176 / 48)
+    constexpr int PITCH = KP + 8;                    // halves per LDS row: 16-byte aligned, conflict-free b128 reads
+    __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * PITCH];
+    unsigned short* As = lds;
+    unsigned short* Bs = lds + BM * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long total = (long)(p.M / (p.Ho * p.Wo)) * p.H * p.W * 3;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    auto put_run = [&](unsigned short* dst, const float (&v)[NX4 * 4], int kh) {     // RUN values (+ zero padding) -> LDS as bf16
+        unsigned pk[PKH / 2];
+#pragma unroll
+        for (int e = 0; e < PKH / 2; ++e)
+            pk[e] = pack_bf16x2(2 * e < NX4 * 4 ? v[2 * e] : 0.f, 2 * e + 1 < NX4 * 4 ? v[2 * e + 1] : 0.f);
+#pragma unroll
+        for (int q = 0; q < PKH / 8; ++q)
+            *reinterpret_cast<u32x4*>(dst + kh * PKH + q * 8) = u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+        if (KP > KS * PKH && kh == KS - 1)                                         // the tail of the last k-step
+            *reinterpret_cast<u32x4*>(dst + KS * PKH) = u32x4{0u, 0u, 0u, 0u};
+    };
+    for (int t = tid; t < BM * KS; t += 256) {               // activation runs: consecutive lanes = consecutive pixels
+        const int kh = t / BM, row = t - kh * BM;
+        const int m = m0 + row;
+        float v[NX4 * 4];
+#pragma unroll
+        for (int e = 0; e < NX4 * 4; ++e) v[e] = 0.f;
+        if (m < p.M) {
+            const int b = fast_div_b(m, p.fd_hw), rem = m - b * p.Ho * p.Wo;
+            const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
+            const int hi = ho * p.stride - p.pad + kh, wi0 = wo * p.stride - p.pad;
+            if ((unsigned)hi < (unsigned)p.H) {
+                const long src = (((long)b * p.H + hi) * p.W + wi0) * 3;
+#pragma unroll
+                for (int x = 0; x < NX4; ++x) {
+                    const long o = src + 4 * x;
+                    if (o >= 0 && o + 4 <= total) {
+                        __builtin_memcpy(&v[4 * x], p.A + o, 16);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (o + e >= 0 && o + e < total) v[4 * x + e] = p.A[o + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NX4 * 4; ++e)
+                    if (e >= RUN || (unsigned)(wi0 + e / 3) >= (unsigned)p.W) v[e] = 0.f;
+            }
+        }
+        put_run(As + row * PITCH, v, kh);
+    }
+    for (int t = tid; t < BN * KS; t += 256) {               // weight runs from the fp32 pack [N][Kpad], K order (kh, kw, c)
+        const int kh = t / BN, n = t - kh * BN;
+        float v[NX4 * 4];
+#pragma unroll
+        for (int e = 0; e < NX4 * 4; ++e) v[e] = 0.f;
+        if (n0 + n < p.N) {
+            const float* src = p.Wp + (long)(n0 + n) * p.Kpad + kh * RUN;          // (kh * RUN + 4 NX4 <= Kpad: launcher checks)
+#pragma unroll
+            for (int x = 0; x < NX4; ++x) __builtin_memcpy(&v[4 * x], src + 4 * x, 16);
+#pragma unroll
+            for (int e = RUN; e < NX4 * 4; ++e) v[e] = 0.f;
+        }
+        put_run(Bs + n * PITCH, v, kh);
+    }
+    __syncthreads();
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int step = 0; step < KP / 16; ++step) {
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + frow) * PITCH + step * 16 + fhalf * 8]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + i * 32 + frow) * PITCH + step * 16 + fhalf * 8]));
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[i], 0, 0, 0);
+        }
+    }
+    // transposed accumulator (lane = row m, register group g = channels 8 g + 4 fhalf .. + 3): 8-byte stores
+    unsigned short* Out = reinterpret_cast<unsigned short*>(p.out);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn0 + 4 * fhalf + 8 * g;
+        if (n >= p.N) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 32 + frow;
+            if (m >= p.M) continue;
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t[e] = acc[i][4 * g + e] + bv[e];
+                if (p.act == ACT_RELU) t[e] = fmaxf(t[e], 0.f);
+            }
+            *reinterpret_cast<u32x2*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = u32x2{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+        }
+    }
+#endif
+}
+
 // fp32 NHWC image (Cin % 4 != 0), fp32 packed weights [N][Kpad32], bf16 NHWC result; no residual.
 bool gemm_bf16_smallc_ok(const GemmArgs& a) {
     return a.conv && a.out_bf16 && !a.res && a.omap.G == 1 && a.N % 4 == 0 && a.omap.S1 % 4 == 0 && a.omap.off % 4 == 0 &&
            a.Kpad % 32 == 0 && a.act != ACT_GELU;
 }
 
+static int stem_runs_ks(const GemmArgs& a) {     // 7 / 3: the run-based stem kernel applies; 0: the element-wise gather kernel
+    static const int v2 = [] { const char* e = getenv("CAPF_STEM_V2"); return e ? atoi(e) : 1; }();     // A/B runs only
+    if (!v2 || a.Cin != 3 || a.pad != a.ks / 2 || a.K != a.ks * a.ks * 3) return 0;
+    if (a.ks == 7 && a.Kpad >= 6 * 21 + 24) return 7;
+    if (a.ks == 3 && a.Kpad >= 2 * 9 + 12) return 3;
+    return 0;
+}
+
+const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a) { return stem_runs_ks(a) ? "igemm_bf16_stem<w4,128x64>" : "igemm_bf16_smallc<w4,128x64>"; }
+
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a_in, hipStream_t s) {
     if (!gemm_bf16_smallc_ok(a_in)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
     a.fd_wo = make_fastdiv((unsigned)a.Wo);
-    hipLaunchKernelGGL(igemm_bf16_smallc_kernel, dim3(((a.M + 127) / 128) * ((a.N + 63) / 64)), dim3(256), 0, s, a);
+    const dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64));
+    // (64-pixel tiles -- 47 KiB, three blocks per CU for the 7x7 -- measured slower: 0.50 -> 0.59 ms for CPN, 0.30 -> 0.35 for HRNet)
+    const int ks = stem_runs_ks(a);
+    if (ks == 7) hipLaunchKernelGGL((igemm_bf16_stem_kernel<7, 128>), grid, dim3(256), 0, s, a);
+    else if (ks == 3) hipLaunchKernelGGL((igemm_bf16_stem_kernel<3, 128>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(igemm_bf16_smallc_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -827,7 +827,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
             for (int m = 0; m < 2; ++m) snprintf(buf[t][m], sizeof(buf[t][m]), "igemm_f32<%s,%s>", kTileNames[t], modes[m]);
         init = true;
     }
-    if (a.conv && a.Cin % 4 != 0) return stem_on_bf16(a) ? "igemm_bf16_smallc<w4,128x64>" : "igemm_f32_smallc<w4,128x64>";
+    if (a.conv && a.Cin % 4 != 0) return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : "igemm_f32_smallc<w4,128x64>";
     return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
 

@@ -111,6 +111,7 @@ hipError_t launch_pack_conv_bf16_rh(const float* w, const float* gamma, const fl
                                     float eps, void* Wp_bf16, float* bias, int Cout, int Cin, int CW, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
+const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);
 // lifter projections on the bf16 MFMA path (igemm_bf16.hip): A bf16 [M][K], W bf16 [N][Kpad]; gelu_bf16_out = 0: fp32 out
 // (+ fp32 residual) through the row maps; 1: GELU then bf16 out [M][N]
