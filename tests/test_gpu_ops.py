@@ -344,6 +344,40 @@ def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
         assert torch.equal(a, b)
 
 
+def test_row_halo_engine_path_agrees_with_the_direct_bf16_kernels(monkeypatch):
+    """Batch 48 HRNet-32 bf16: the grouped branch launches have >= 2048 tiles, so the engine runs the row-halo kernel
+    (capf_forward_profile_variants reports igemm_bf16_group_rh_kernel for them); a second engine planned with
+    CAPF_BF16_RH=0 runs the direct kernels.  Different K order and bias placement, same bf16 operands: the four context
+    maps agree to the noise two bf16 evaluations with different summation orders accumulate over ~50 layers (measured 5-8e-3,
+    the same size as either run's distance from the fp32 oracle)."""
+    import copy, contextlib, io
+    from capf import synth
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    img, k2d, kc = synth.synth_inputs(48, 256, 256, seed=16)
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    maps, variants = [], []
+    for rh in ("1", "0"):
+        monkeypatch.setenv("CAPF_BF16_RH", rh)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = CA_PF(cfg, compute_dtype="bf16").eval()
+        synth.load_synthetic(model, seed=4, bn_mode="random")
+        model = model.cuda()
+        with torch.no_grad():
+            out = model(img, k2d, kc.clone())
+            eng = model.engine_for(img)
+            eng.forward_profile_launches(img, k2d, kc.clone(), torch.empty_like(out), torch.cuda.current_stream().cuda_stream)
+        variants.append(set(v for v in eng.profile_variants() if v >= 0))
+        maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
+    assert 2 in variants[0] and 2 not in variants[1]
+    for a, b in zip(*maps):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"row-halo vs direct: relative L2 {rel:.2e}")
+        assert rel < 1.5e-2
+
+
 def test_conv_fuzz_against_torch():
     """Seeded random conv shapes (ragged M and N, odd image sizes, stride 1 / 2, 1x1 / 3x3 / 5x5, channel counts
     that are and are not multiples of 32, with and without bias / residual / ReLU) against PyTorch on the CPU, and
