@@ -828,6 +828,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
         init = true;
     }
     if (a.conv && a.Cin % 4 != 0) return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : "igemm_f32_smallc<w4,128x64>";
+    if (gemm_f32_pw_ok(a)) return gemm_f32_pw_kernel_name();
     return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
 
@@ -996,6 +997,7 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
+    if (gemm_f32_pw_ok(a_in)) return launch_gemm_f32_pw(a_in, s);
     if (a_in.splits <= 1 && worth_splitting(a_in)) return launch_gemm_f32_group(&a_in, 1, s);
     GemmArgs a = a_in;
     a.split_ws = nullptr; a.split_cnt = nullptr;                           // (the in-kernel reduction belongs to the grouped kernel)

@@ -76,6 +76,11 @@ static constexpr int MAXG = 8;
 bool gemm_f32_groupable(const GemmArgs& a);
 hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_f32_kernel_name(const GemmArgs& a);   // which template instantiation launch_gemm_f32 picks
+// fp32 pointwise (1x1 / stride 1) conv for the HBM-bound bottleneck convs of layer1 (igemm_f32_pw.hip): ping-pong schedule,
+// coalesced epilogue with prefetched residual; launch_gemm_f32 routes eligible problems (>= 2048 tiles) to it
+bool gemm_f32_pw_ok(const GemmArgs& a);
+hipError_t launch_gemm_f32_pw(const GemmArgs& a, hipStream_t s);
+const char* gemm_f32_pw_kernel_name();
 
 // Winograd F(2,3)-along-W variant of the 3x3 / stride-1 / pad-1 fp32 conv (igemm_wino.hip): same GemmArgs as the direct conv,
 // Wp = weights packed by launch_pack_conv_wino ([N][12 * Cin]); needs Cin % 32 == 0, even W, N % 4 == 0

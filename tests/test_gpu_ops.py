@@ -522,3 +522,29 @@ def test_conv_bf16_row_halo_matches_torch_on_bf16_rounded_operands(ci, co, H, W,
     got = got.float().cpu().permute(0, 3, 1, 2)
     tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
     assert (got - want).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("ci,co,res", [(64, 256, True), (256, 64, False), (96, 72, True), (32, 8, False)])
+def test_pointwise_fp32_kernel_is_bit_identical_to_the_general_kernel(ci, co, res):
+    """igemm_f32_pw (1x1 convs with >= 2048 tiles: ping-pong schedule, coalesced epilogue) against the general implicit GEMM:
+    the same frames in a batch small enough to stay on the general kernel give the same bits, and both match F.conv2d."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    H = W = 64
+    B = 66 if co <= 64 else 20                     # ceil(B*4096/128) * ceil(co/64) >= 2048
+    x = torch.randn(B, H, W, ci, generator=g)
+    w = torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5
+    bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+           torch.rand(co, generator=g) * 0.4 + 0.8)
+    r = torch.randn(B, H, W, co, generator=g) if res else None
+    wp, bias = capf.pack_conv(w.cuda(), tuple(t.cuda() for t in bnp))
+    big = capf.conv_nhwc(x.cuda(), wp, bias, 1, 1, 1, r.cuda() if res else None)
+    nb = 3                                          # 3 frames: 96 row tiles, the general kernel
+    small = capf.conv_nhwc(x[:nb].contiguous().cuda(), wp, bias, 1, 1, 1, r[:nb].contiguous().cuda() if res else None)
+    assert torch.equal(big[:nb], small)
+    w_fold = wp[:, :ci].cpu().view(co, ci, 1, 1)
+    want = F.conv2d(x.permute(0, 3, 1, 2), w_fold, bias.cpu())
+    if res:
+        want = want + r.permute(0, 3, 1, 2)
+    want = F.relu(want).permute(0, 2, 3, 1)
+    assert (big.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())

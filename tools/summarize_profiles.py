@@ -31,6 +31,9 @@ def short(name):
     m = re.match(r"(?:void )?capf::igemm_wino_kernel", name)
     if m:
         return "igemm_wino<w4,F(2,3)/F(4,3)>"
+    m = re.match(r"(?:void )?capf::igemm_f32_pw_kernel", name)
+    if m:
+        return "igemm_f32_pw<w4,128x64>"
     m = re.match(r"(?:void )?capf::igemm_f32_group_kernel", name)
     if m:
         return "igemm_f32_group"
