@@ -14,7 +14,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_forward_profile_variants", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
-    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
+    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_op_conv_bf16_group", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
 ]
 
@@ -519,6 +519,34 @@ def conv_nhwc_bf16_rh(x, wp, bias, act=0, residual=None):
     if rc:
         raise CapfError(f"capf_op_conv_bf16_rh failed ({rc})")
     return y
+
+
+def conv_nhwc_bf16_group(problems):
+    """problems: list of (x, wp, bias, ks, stride, act, residual, wp_row_halo or None), all bf16 NHWC -> (outputs, variant)."""
+    import torch
+    lib = load_library()
+    n = len(problems)
+    descs = (ConvDesc * n)()
+    rh = (c_void_p * n)()
+    outs = []
+    for i, (x, wp, bias, ks, stride, act, res, wrh) in enumerate(problems):
+        B, H, W, ci = x.shape
+        co = wp.shape[0]
+        pad = ks // 2
+        ho, wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y = torch.empty(B, ho, wo, co, device=x.device, dtype=torch.bfloat16)
+        outs.append(y)
+        d = descs[i]
+        d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
+        d.residual = res.data_ptr() if res is not None else None
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, co, ks, stride, act
+        rh[i] = wrh.data_ptr() if wrh is not None else None
+    variant = c_int32(-1)
+    lib.capf_op_conv_bf16_group.argtypes = [c_void_p, c_int, POINTER(ConvDesc), POINTER(c_void_p), POINTER(c_int32)]
+    rc = lib.capf_op_conv_bf16_group(_stream(problems[0][0]), n, descs, rh, byref(variant))
+    if rc:
+        raise CapfError(f"capf_op_conv_bf16_group failed ({rc})")
+    return outs, variant.value
 
 
 def linear(x, w, bias=None, act=0, residual=None):

@@ -737,6 +737,29 @@ int capf_op_conv_bf16_rh(void* stream, const void* x, const void* wp, const floa
     return capf::launch_gemm_bf16_rh(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
 }
 
+int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* d, const void* const* w_rh, int32_t* variant) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i) {
+        capf::GemmArgs a{};
+        const int pad = d[i].ks / 2;
+        a.A = d[i].x; a.Wp = d[i].w_packed; a.bias = d[i].bias; a.res = d[i].residual; a.out = d[i].y;
+        a.Wp2 = w_rh ? static_cast<const float*>(w_rh[i]) : nullptr;
+        a.Ho = (d[i].H + 2 * pad - d[i].ks) / d[i].stride + 1;
+        a.Wo = (d[i].W + 2 * pad - d[i].ks) / d[i].stride + 1;
+        a.M = d[i].B * a.Ho * a.Wo; a.N = d[i].Cout; a.K = d[i].ks * d[i].ks * d[i].Cin; a.Kpad = (a.K + 63) / 64 * 64;
+        a.conv = 1; a.Cin = d[i].Cin; a.H = d[i].H; a.W = d[i].W; a.ks = d[i].ks; a.stride = d[i].stride; a.pad = pad;
+        a.omap = capf::row_ld(d[i].Cout); a.rmap = capf::row_ld(d[i].Cout); a.amap = capf::row_ld(0);
+        a.act = d[i].act;
+        if (!capf::gemm_bf16_groupable(a)) return CAPF_ERR_UNSUPPORTED;
+        g[i] = a;
+    }
+    int v = -1;
+    const hipError_t e = capf::launch_gemm_bf16_group(g, n, static_cast<hipStream_t>(stream), &v);
+    if (variant) *variant = v;
+    return e == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_op_linear_bf16(void* stream, const void* x_bf16, const void* w_bf16, const float* bias, const float* residual, void* y,
                         int M, int N, int K, int gelu_bf16_out) {
     if (!x_bf16 || !w_bf16 || !y || K % 64 != 0) return CAPF_ERR_INVALID;

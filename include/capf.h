@@ -242,6 +242,12 @@ int capf_op_pack_conv_bf16_rh(void* stream, const float* w_oihw, const float* ga
 int capf_op_conv_bf16_rh(void* stream, const void* x_nhwc_bf16, const void* w_packed_bf16, const float* bias,
                          const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout, int act);
 
+/* Up to 8 independent bf16 convs in one grid (what capf_forward issues per dependency level of the HRNet branches of a bf16 model):
+ * capf_conv_desc with bf16 x / w_packed / residual / y.  w_row_halo[i] (optional array, entries may be NULL): the same weights
+ * from capf_op_pack_conv_bf16_rh; launches of >= 2048 tiles then run the row-halo tiles for those problems, exactly as the
+ * engine does.  *variant (optional) = the device kernel chosen (see capf_forward_profile_variants).                           */
+int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* convs, const void* const* w_row_halo, int32_t* variant);
+
 /* nn.Linear on the bf16 MFMA path (the lifter's qkv / proj / fc1 / fc2 under compute_dtype = CAPF_BF16, pose_dformer.py:15-59):
  * x bf16 [M,K], w bf16 [N,K] (K % 64 == 0), bias fp32; gelu_bf16_out = 0: y fp32 [M,N] = x w^T + bias (+ fp32 residual);
  * gelu_bf16_out = 1: y bf16 [M,N] = GELU(x w^T + bias) (exact erf).  fp32 accumulation in both.                        */

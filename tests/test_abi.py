@@ -154,7 +154,10 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     assert table["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_wino<")
     small = {name: kern for name, kern, _ in eng.op_table(4)}
     assert small["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
-    assert table["backbone.layer1.0.conv3"] == "igemm_f32<w4,128x128,conv>"
+    # layer1's HBM-bound 1x1 bottleneck convs: the pointwise kernel from 2048 tiles per launch, the general tile below
+    assert table["backbone.layer1.0.conv3"] == "igemm_f32_pw<w4,128x64>"
+    assert table["backbone.layer1.1.conv1"] == "igemm_f32_pw<w4,128x64>"
+    assert {name: kern for name, kern, _ in eng.op_table(8)}["backbone.layer1.0.conv3"].startswith("igemm_f32<")
     big = {name: kern for name, kern, _ in eng.op_table(512)}
     assert big["joint0.qkv"] in ("igemm_f32<w4,128x128,rows>", "igemm_f32<w4,128x64,rows>")
 

@@ -548,3 +548,34 @@ def test_pointwise_fp32_kernel_is_bit_identical_to_the_general_kernel(ci, co, re
         want = want + r.permute(0, 3, 1, 2)
     want = F.relu(want).permute(0, 2, 3, 1)
     assert (big.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("chans,B", [((48, 96, 192, 384), 40), ((32, 64, 128, 256), 40), ((48, 96), 6)])
+def test_grouped_bf16_launch_with_row_halo_tiles_matches_torch(chans, B):
+    """One grouped bf16 launch of the four HRNet branch convs (3x3, stride 1, residual, ReLU) the way the engine issues them:
+    at B = 40 the launch has >= 2048 tiles and runs igemm_bf16_group_rh_kernel (row-halo tiles of every chunk width and column
+    count, padded tile ids, mixed problems in one grid); at B = 6 it stays on the ring kernel.  Every output against fp32
+    F.conv2d of the same bf16-rounded operands."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(sum(chans) + B)
+    probs, wants = [], []
+    for i, c in enumerate(chans):
+        r = 64 >> i
+        x = torch.randn(B, c, r, r, generator=g).bfloat16()
+        w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+        bnp = (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+               torch.rand(c, generator=g) * 0.4 + 0.8)
+        res = torch.randn(B, c, r, r, generator=g).bfloat16()
+        bn_dev = tuple(t.cuda() for t in bnp)
+        wp, bias = capf.pack_conv_bf16(w.cuda(), bn_dev)
+        wrh, bias2, cw = capf.pack_conv_bf16_rh(w.cuda(), bn_dev)
+        assert torch.equal(bias, bias2)
+        w_fold = wp[:, :9 * c].float().cpu().view(c, 3, 3, c).permute(0, 3, 1, 2).contiguous()
+        wants.append(F.relu(F.conv2d(x.float(), w_fold, bias.cpu(), 1, 1) + res.float()))
+        probs.append((x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, 3, 1, 1, res.permute(0, 2, 3, 1).contiguous().cuda(), wrh))
+    outs, variant = capf.conv_nhwc_bf16_group(probs)
+    assert variant == (2 if B >= 40 else 0)
+    for y, want in zip(outs, wants):
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
+        assert (got - want).abs().max().item() <= tol
