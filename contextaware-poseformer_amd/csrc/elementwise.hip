@@ -86,6 +86,22 @@ hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad,
     return hipGetLastError();
 }
 
+__global__ void pack_linear_quad_kernel(const float* __restrict__ w, float* __restrict__ Wq, int N, int K, int n0, int Ntot) {
+    const long total = (long)N * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i - (long)n * K);
+        Wq[((long)(k >> 2) * Ntot + n0 + n) * 4 + (k & 3)] = w[i];
+    }
+}
+
+hipError_t launch_pack_linear_quad(const float* w, float* Wq, int N, int K, int n0, int Ntot, hipStream_t s) {
+    if (K % 4 != 0) return hipErrorInvalidValue;
+    const long total = (long)N * K;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_linear_quad_kernel, dim3(blocks), dim3(256), 0, s, w, Wq, N, K, n0, Ntot);
+    return hipGetLastError();
+}
+
 // ---- HRNet fuse: out = relu(sum_i nearest_up(in_i))  (pose_hrnet.py:294-301, nn.Upsample nearest) --
 // Input i has resolution (H >> shift_i, W >> shift_i); nearest upsampling by 2^s reads (h>>s, w>>s).
 // V channels per lane: 4 (fp32 16 B, bf16 8 B) or 8 (bf16, 16 B); pixel arithmetic in 32 bits (B * H * W < 2^31, launcher checks)

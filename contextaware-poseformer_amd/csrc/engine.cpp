@@ -58,6 +58,14 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                 HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
                 n0 += n;
             }
+        } else if (pk.quad) {            // fused lifter kernels: Wq[k / 4][n][4], the linears concatenated along n
+            int n0 = 0;
+            for (int i = 0; i < pk.n_lin; ++i) {
+                const int n = (int)params[pk.w[i]].shape[0];
+                HIP_TRY(launch_pack_linear_quad(params[pk.w[i]].ptr, W, n, pk.K, n0, pk.N, s));
+                HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+                n0 += n;
+            }
         } else {
             int n0 = 0;
             for (int i = 0; i < pk.n_lin; ++i) {
@@ -182,7 +190,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             for (int l = 0; l < op.i1; ++l) {
                 a.feat[l] = ptr(op.in[l]);
                 a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.Cl[l] = op.lvlC[l];
-                a.fw[l] = params[op.pw[l]].ptr; a.fb[l] = params[op.pb[l]].ptr;
+                a.fw[l] = pack_arena + packs[op.pq[l]].w_off; a.fb[l] = params[op.pb[l]].ptr;
                 a.sampled[l] = ptr(op.outs[l]);
                 a.idx[l] = reinterpret_cast<int*>(ptr(op.idxs[l]));
             }
@@ -198,7 +206,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             for (int l = 0; l < op.i1; ++l) {
                 a.feat[l] = ptr(op.in[l]);
                 a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.Cl[l] = op.lvlC[l];
-                a.Wp[l] = params[op.pw[l]].ptr; a.bp[l] = params[op.pb[l]].ptr;
+                a.Wp[l] = pack_arena + packs[op.pq[l]].w_off; a.bp[l] = params[op.pb[l]].ptr;
             }
             a.Wao = pack_arena + pk.w_off; a.bao = pack_arena + pk.b_off; a.ldw = pk.Kpad;
             a.ln_g = params[op.p0].ptr; a.ln_b = params[op.p1].ptr; a.eps = op.eps;

@@ -51,6 +51,7 @@ struct Pack {
     size_t w_off = 0, b_off = 0;   // element offsets inside the pack arena
     size_t w2_off = 0;             // wino packs: the direct-kernel layout [N][Kpad2] as well (small batches run the direct kernel)
     int Kpad2 = 0;
+    bool quad = false;             // linear for the fused lifter kernels: Wq[k / 4][n][4] (lanes n read consecutive 16-byte quads)
     bool direct = false;           // linear with Kpad == K and no concat: use the parameter in place
     bool bf16 = false;             // conv weights packed as bf16 (Kpad % 64 == 0)
     bool rh = false;               // bf16 3x3 stride-1 conv: a second copy in the row-halo layout ([N][9 * Cin] bf16) at w2_off
@@ -86,6 +87,7 @@ struct Op {
     int lvlH[4] = {0, 0, 0, 0}, lvlW[4] = {0, 0, 0, 0}, lvlC[4] = {0, 0, 0, 0};
     int outs[4] = {-1, -1, -1, -1};
     int idxs[4] = {-1, -1, -1, -1};          // OP_EMBED: corner-index tap buffers
+    int pq[4] = {-1, -1, -1, -1};   // ... and their quad-interleaved packs
     int pw[4] = {-1, -1, -1, -1}, pb[4] = {-1, -1, -1, -1};   // per-level linear parameters (OP_EMBED feat_embed, OP_CTX_ATTN embed_proj)
     int ln_w = -1, ln_b = -1;                // OP_GEMM rows mode: LayerNorm the A rows on the fly (parameter indices), eps in `eps`
     double flops_per_frame = 0.0;

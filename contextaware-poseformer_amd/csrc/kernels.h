@@ -118,6 +118,9 @@ bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_linear(const float* w, float* Wp, int N, int K, int Kpad, hipStream_t s);
+// quad-interleaved pack for the fused lifter kernels: Wq[(k / 4) * Ntot + n0 + n][k % 4] = w[n][k]  (K % 4 == 0): lane n of a
+// wave reads the 16-byte quad next to lane n - 1's instead of a row K floats away
+hipError_t launch_pack_linear_quad(const float* w, float* Wq, int N, int K, int n0, int Ntot, hipStream_t s);
 // lifter projections on the bf16 MFMA path (igemm_bf16.hip): A bf16 [M][K], W bf16 [N][Kpad]; gelu_bf16_out = 0: fp32 out
 // (+ fp32 residual) through the row maps; 1: GELU then bf16 out [M][N]
 hipError_t launch_gemm_bf16_rows(const void* A_bf16, const void* W_bf16, const float* bias, int M, int N, int K, int Kpad,
@@ -187,7 +190,7 @@ hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 struct CtxAttnArgs {
     const float* feat[4]; int H[4], W[4], Cl[4];
     const float* Wp[4]; const float* bp[4]; // embed_proj[l] weight [C/NH, Cl], bias [C/NH]
-    const float* Wao; const float* bao;     // [attention_weights | sampling_offsets] rows [3*NH*NS][ldw], bias
+    const float* Wao; const float* bao;     // [attention_weights | sampling_offsets] quad-interleaved: Wq[C / 4][3*NH*NS][4]; bias
     int ldw;
     const float* ln_g; const float* ln_b; float eps;
     const float* ref;            // [BJ, 2]

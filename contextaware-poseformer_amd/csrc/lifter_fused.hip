@@ -127,10 +127,10 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
         float acc[EG];
 #pragma unroll
         for (int g = 0; g < EG; ++g) acc[g] = 0.f;
-        const float* wr = Wl + (long)j * Cl;
+        const float* wr = Wl + (long)j * 4;                      // quad-interleaved pack: Wq[c / 4][j][4]
 #pragma unroll 8
         for (int c = 0; c < Cl; c += 4) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + (long)c * C);
 #pragma unroll
             for (int g = 0; g < EG; ++g) {
                 const f32x4 s = *reinterpret_cast<const f32x4*>(&S[l][g][c]);
@@ -227,11 +227,11 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     // ---- 3*NK dot products of length C: lane k < 48 owns output k of [attention_weights | sampling_offsets]
     if (lane < 3 * CTX_NK) {
-        const float* wr = a.Wao + (long)lane * a.ldw;
+        const float* wr = a.Wao + (long)lane * 4;               // quad-interleaved pack: Wq[c / 4][3 * NK outputs][4]
         float acc = 0.f;
 #pragma unroll 16
         for (int c = 0; c < C; c += 4) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + (long)c * (3 * CTX_NK));
             const f32x4 t = *reinterpret_cast<const f32x4*>(q + c);
             acc += ((t[0] * w[0] + t[1] * w[1]) + t[2] * w[2]) + t[3] * w[3];
         }
@@ -296,10 +296,10 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
         float acc[CTX_NH];
 #pragma unroll
         for (int t = 0; t < CTX_NH; ++t) acc[t] = 0.f;
-        const float* wr = Wp + (long)j * Cl;
+        const float* wr = Wp + (long)j * 4;                     // quad-interleaved pack: Wq[c / 4][HD][4]
 #pragma unroll 8
         for (int c = 0; c < Cl; c += 4) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + (long)c * HD);
 #pragma unroll
             for (int t = 0; t < CTX_NH; ++t) {
                 const int h = hs + t * nhs;

@@ -417,9 +417,10 @@ static void reg_ln(Engine& e, const std::string& p, int C) {
     e.add_param(p + ".bias", CAPF_P_LN_B, {C});
 }
 
-static int make_linear_pack(Engine& e, const std::vector<std::string>& names, bool as_bf16 = false) {
+static int make_linear_pack(Engine& e, const std::vector<std::string>& names, bool as_bf16 = false, bool quad = false) {
     Pack pk;
     pk.kind = 1;
+    pk.quad = quad;
     pk.n_lin = (int)names.size();
     int N = 0, K = 0;
     for (int i = 0; i < pk.n_lin; ++i) {
@@ -431,7 +432,8 @@ static int make_linear_pack(Engine& e, const std::vector<std::string>& names, bo
     pk.N = N;
     pk.K = K;
     pk.Kpad = as_bf16 ? round64(K) : round32(K);
-    pk.direct = !as_bf16 && (pk.n_lin == 1 && pk.Kpad == K);
+    if (quad) pk.Kpad = K;                     // (K % 4 == 0: embed dims and level channel counts)
+    pk.direct = !as_bf16 && !quad && (pk.n_lin == 1 && pk.Kpad == K);
     pk.bf16 = as_bf16;                         // bf16 copy [N][Kpad] for the bf16 MFMA projections (compute_dtype = bf16)
     e.packs.push_back(pk);
     return (int)e.packs.size() - 1;
@@ -579,6 +581,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
             use(feats[l].buf);
             op.pw[l] = pidx(*this, V + ".feat_embed." + ls + ".weight");
             op.pb[l] = pidx(*this, V + ".feat_embed." + ls + ".bias");
+            op.pq[l] = make_linear_pack(*this, {V + ".feat_embed." + ls}, false, true);
             op.outs[l] = new_buffer((size_t)J * Cl[l], "sampled" + ls);
             op.idxs[l] = new_buffer((size_t)J * 2, "idx" + ls);
             name_tensor(*this, "sampled" + ls, op.outs[l], {-1, J, Cl[l]});
@@ -637,12 +640,12 @@ void Engine::build_lifter(const Tensor feats[4]) {
             const std::string p = V + ".context_blocks." + std::to_string(i);
             const std::string n = "ctx" + std::to_string(i);
             const int pk_ao = make_linear_pack(*this, {p + ".attention_weights", p + ".sampling_offsets"});
-            ctx_ao_pack.push_back(pk_ao);
+            ctx_ao_pack.push_back(pk_ao);                   // (row layout: the training step's GEMMs, train.cpp)
             if (fused_lifter) {
                 Op op;
                 op.kind = OP_CTX_ATTN;
                 op.name = n + ".attn";
-                op.pack = pk_ao;
+                op.pack = make_linear_pack(*this, {p + ".attention_weights", p + ".sampling_offsets"}, false, true);
                 op.out = X;
                 use(X);
                 op.p0 = pidx(*this, p + ".norm1.weight");
@@ -654,6 +657,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
                     use(feats[l].buf);
                     op.pw[l] = pidx(*this, p + ".embed_proj." + std::to_string(l) + ".weight");
                     op.pb[l] = pidx(*this, p + ".embed_proj." + std::to_string(l) + ".bias");
+                    op.pq[l] = make_linear_pack(*this, {p + ".embed_proj." + std::to_string(l)}, false, true);
                     op.flops_per_frame += 2.0 * J * NH * (double)HD * Cl[l];
                 }
                 op.flops_per_frame += 2.0 * J * L * (double)C * 3 * NH * NS;
