@@ -222,6 +222,7 @@ def main():
         cdist.broadcast_state_(model.volume_net)                             # DDP ctor broadcast (C1)
         flat_p = flatten_(model.volume_net)
         opt = FusedAdamW(flat_p, lr=6.4e-4, weight_decay=0.1)                # train.py:345, human36m.yaml:58
+        model.flat_grad_only = True                                          # gradient -> all-reduce -> AdamW on the flat buffer
         crit = MPJPE()
 
         def step():

@@ -154,70 +154,136 @@ hipError_t launch_layernorm_bwd(const float* dy, const float* xhat, const float*
 
 // ---- deterministic column reduction:  dst[c] = sum_r A[amap(r) + c] * B(r, c) -----------------------
 // B absent -> 1; bmode 1: B[bmap(r) + c]; bmode 2: B[bmap(r)] (one scalar per row).
-// Stage 1: grid (C/64, chunks), 256 threads = 4 row lanes x 64 columns, fixed row order per lane and a
-// fixed 4-way LDS reduce; stage 2 sums the chunk partials in order.  No atomics.
+// Stage 1: grid (C/64, chunks), 256 threads = 16 row lanes x 16 column quads, fixed row order per lane and a
+// fixed 16-way LDS reduce; stage 2 sums the chunk partials in order.  No atomics.
 // `partial2` (optional): the plain column sums of A as a second result of the same pass (LayerNorm: d(gamma) =
 // sum dY * xhat and d(beta) = sum dY read dY once).
-__global__ void colreduce_kernel(const float* __restrict__ A, RowMap amap, const float* __restrict__ Bm, RowMap bmap,
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ A, RowMap amap, const float* __restrict__ Bm, RowMap bmap,
                                  int bmode, float* __restrict__ partial, float* __restrict__ partial2, int rows, int C,
                                  int rows_per_chunk) {
-    __shared__ float red[2][4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    // 256 threads = 16 row lanes x 16 column quads (64 columns, 16-byte loads); four rows in flight per lane
+    __shared__ float red[2][16][64];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cq * 4;
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
-    float acc = 0.f, acc2 = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load4 = [&](const float* p, float (&v)[4], bool vec) {
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = col + e < C ? p[e] : 0.f;
+        }
+    };
+    const bool avec = col + 4 <= C && ((amap.S1 | amap.S2 | amap.off) & 3) == 0 && ((size_t)A & 15) == 0;
+    const bool bvec = bmode == 1 && col + 4 <= C && ((bmap.S1 | bmap.S2 | bmap.off) & 3) == 0 && ((size_t)Bm & 15) == 0;
     if (col < C) {
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const float a = A[rowmap_t(amap, r) + col];
-            float v = a;
-            if (bmode == 1) v *= Bm[rowmap_t(bmap, r) + col];
-            else if (bmode == 2) v *= Bm[rowmap_t(bmap, r)];
-            acc += v;
-            acc2 += a;
+        for (int r = r0 + rl; r < r1; r += 64) {              // same row order per lane whatever the unrolling: r, r+16, r+32, ...
+            float a[4][4], b[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + 16 * u;
+                if (rr < r1) {
+                    load4(A + rowmap_t(amap, rr) + col, a[u], avec);
+                    if (bmode == 1) load4(Bm + rowmap_t(bmap, rr) + col, b[u], bvec);
+                    else if (bmode == 2) { const float sc = Bm[rowmap_t(bmap, rr)]; b[u][0] = b[u][1] = b[u][2] = b[u][3] = sc; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + 16 * u < r1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[e] += bmode ? a[u][e] * b[u][e] : a[u][e];
+                        acc2[e] += a[u][e];
+                    }
+                }
         }
     }
-    red[0][rl][threadIdx.x & 63] = acc;
-    red[1][rl][threadIdx.x & 63] = acc2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][rl][cq * 4 + e] = acc[e];
+        red[1][rl][cq * 4 + e] = acc2[e];
+    }
     __syncthreads();
-    if (rl == 0 && col < C) {
-        partial[(long)blockIdx.y * C + col] = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-        if (partial2)
-            partial2[(long)blockIdx.y * C + col] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    if (threadIdx.x < 128) {                                  // fixed 16-way reduce, one output column per thread
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float* dstp = which ? partial2 : partial;
+        if (dstp && blockIdx.x * 64 + c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[which][k][c];
+            dstp[(long)blockIdx.y * C + blockIdx.x * 64 + c] = t;
+        }
     }
 }
 
-// stage 2: 64 columns x 4 chunk lanes per block; each lane sums every 4th chunk partial in order, then a fixed
-// 4-way LDS reduce
+// stage 2: 64 columns per block as 16 column quads x 16 chunk lanes; each lane sums every 16th chunk partial in order (four
+// 16-byte loads in flight), then a fixed 16-way LDS reduce
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int chunks, int C,
                                                               float* __restrict__ dst, long dst_stride, int accumulate,
                                                               const float* __restrict__ partial2, float* __restrict__ dst2) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
-    float s = 0.f, s2 = 0.f;
-    if (c < C) {
-        for (int k = kl; k < chunks; k += 4) s += partial[(long)k * C + c];
-        if (dst2)
-            for (int k = kl; k < chunks; k += 4) s2 += partial2[(long)k * C + c];
+    __shared__ float red[2][16][64];
+    const int cq = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cq * 4;
+    const bool vec = col + 4 <= C && (C & 3) == 0;
+    auto sum_col = [&](const float* src, float (&acc)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = 0.f;
+        if (col >= C) return;
+        for (int k = kl; k < chunks; k += 64) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + 16 * u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = 0.f;
+                if (kk < chunks) {
+                    const float* q = src + (long)kk * C + col;
+                    if (vec) { const float4 t = *reinterpret_cast<const float4*>(q); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+                    else { for (int e = 0; e < 4; ++e) if (col + e < C) v[u][e] = q[e]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
+        }
+    };
+    float s1[4], s2[4];
+    sum_col(partial, s1);
+    if (dst2) sum_col(partial2, s2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][kl][cq * 4 + e] = s1[e];
+        red[1][kl][cq * 4 + e] = dst2 ? s2[e] : 0.f;
     }
-    red[0][kl][threadIdx.x & 63] = s;
-    red[1][kl][threadIdx.x & 63] = s2;
     __syncthreads();
-    if (kl == 0 && c < C) {
-        const float t = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-        float* d = dst + (long)c * dst_stride;
-        *d = accumulate ? *d + t : t;
-        if (dst2) dst2[c] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (c < C && (which == 0 || dst2)) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[which][k][threadIdx.x & 63];
+            if (which == 0) {
+                float* d = dst + (long)c * dst_stride;
+                *d = accumulate ? *d + t : t;
+            } else {
+                dst2[c] = t;
+            }
+        }
     }
 }
 
-// scratch must hold (dst2 ? 2 : 1) * chunks * C floats; chunks is chosen so that the first stage has ~1024 blocks
+// scratch must hold (dst2 ? 2 : 1) * chunks * C floats; chunks is chosen so that the first stage has ~2048 blocks
 hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
                             float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s, float* dst2,
                             size_t scratch_elems) {
     const int colblocks = (C + 63) / 64, nout = dst2 ? 2 : 1;
-    int chunks = (1024 + colblocks - 1) / colblocks;
-    chunks = std::min(std::min(chunks, 128), std::max(1, rows / 32));
+    int chunks = (2048 + colblocks - 1) / colblocks;
+    chunks = std::min(std::min(chunks, 512), std::max(1, rows / 64));
     if (scratch_elems) chunks = std::min<long>(chunks, std::max<long>(1, (long)(scratch_elems / ((size_t)C * nout))));
     else chunks = std::min(chunks, 64);
     const int rpc = (rows + chunks - 1) / chunks;

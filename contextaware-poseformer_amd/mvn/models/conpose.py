@@ -45,6 +45,8 @@ class _LifterStep(torch.autograd.Function):
         stream = torch.cuda.current_stream(grad_out.device).cuda_stream
         eng.backward(grad_out.contiguous(), flat, stream, ctx.masks)
         ctx.owner.last_flat_grad = flat
+        if ctx.owner.flat_grad_only:      # the caller consumes last_flat_grad itself (capf.optim.FusedAdamW + capf.dist)
+            return (None,) * (7 + len(ctx.names))
         grads = tuple(flat[layout[n][0]: layout[n][0] + layout[n][1]].view(shp) for n, shp in zip(ctx.names, ctx.shapes))
         return (None,) * 7 + grads
 
@@ -77,6 +79,10 @@ class CA_PF(nn.Module):
 
         self.drop_path_rate = 0.2   # PoseTransformer(drop_path_rate=0.2), dpr = linspace(0, rate, levels) (pose_dformer.py:147,187)
         self.last_flat_grad = None  # flat fp32 gradient of volume_net.* written by the last backward
+        # True: backward leaves the gradient in last_flat_grad ONLY and sets no .grad (autograd would clone each of the 191 slices
+        # into its parameter's .grad: 191 small device copies per step that a flat optimizer never reads; they overlap the rest of
+        # the step -- no measurable change of a 512-frame step, the point is not to materialise a second copy of the gradient)
+        self.flat_grad_only = False
         self._engines = {}          # (device index, H, W) -> Engine
         # Parameter-change tracking.  `_generation` counts events that may have replaced parameter STORAGE or frozen
         # (backbone) VALUES: load_state_dict on the model or either child, .to()/._apply, params_changed().  Every engine

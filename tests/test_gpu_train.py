@@ -86,3 +86,29 @@ def test_droppath_masks_scale_branches():
     _, pred_nodrop, _ = _train_step("w32_256x256_b2", drop_path=0.0)
     assert torch.isfinite(pred_drop).all() and torch.isfinite(loss)
     assert (pred_drop - pred_nodrop).abs().max().item() > 1e-4
+
+
+def test_flat_grad_only_leaves_the_same_gradient_in_the_flat_buffer():
+    """CA_PF.flat_grad_only: backward writes last_flat_grad and sets no .grad (what bench.py's fused-AdamW step uses); the flat
+    buffer holds exactly the slices the default mode hands to autograd."""
+    from capf import synth
+    from mvn.models.loss import MPJPE
+    case = CASES["w32_256x256_b2"]
+    img, k2d, kc = case_inputs(case)
+    _, _, _, gt = synth.synth_inputs(case["B"], case["H"], case["W"], seed=case["iseed"], crop_range=case["crop"], with_gt=True)
+    flats = []
+    for only in (False, True):
+        model, _ = make_model(case["backbone"], device="cuda", wseed=case["wseed"], bn=case["bn"])
+        model.train(); model.backbone.eval(); model.volume_net.train()
+        model.drop_path_rate = 0.0
+        model.flat_grad_only = only
+        MPJPE()(model(img.cuda(), k2d.cuda(), kc.clone().cuda()), gt.cuda()).backward()
+        torch.cuda.synchronize()
+        assert all((p.grad is None) == only for p in model.volume_net.parameters())
+        flats.append(model.last_flat_grad.clone())
+        if not only:
+            layout, _ = model.engine_for(img.cuda()).grad_layout_cached()
+            for n, p in model.volume_net.named_parameters():
+                off, cnt = layout["volume_net." + n] if ("volume_net." + n) in layout else layout[n]
+                assert torch.equal(p.grad.reshape(-1), flats[0][off: off + cnt])
+    assert torch.equal(flats[0], flats[1])
