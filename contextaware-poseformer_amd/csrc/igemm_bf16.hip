@@ -11,8 +11,16 @@
 //     path, not on the matrix pipe (the bf16 peak is 16x the fp32 one): what matters is bytes, and every
 //     activation byte is half of what the fp32 path moves.
 //   * the accumulator is kept transposed (weights as the MFMA A operand) so each lane owns 4 consecutive
-//     output channels: bias in as 16 B, residual in / result out as 8-byte (4 x bf16) accesses.
-//   * bf16 rounding is round-to-nearest-even, done once, in the epilogue.
+//     output channels; the bf16 epilogue transposes 32x32 blocks through the idle stage so that residual loads (prefetched
+//     with the last chunk) and stores are 16 B per lane, 64 B contiguous per row.
+//   * bf16 rounding is round-to-nearest-even, done once, in the epilogue (v_cvt_pk_bf16_f32).
+// Kernels in this file (DESIGN.md 4.1b has the measurements behind each):
+//   igemm_bf16_tile      the general tile; S >= 2: ring of S stages (launches below 2048 tiles, the lifter's projections),
+//                        S == 1: ping-pong schedule (one stage, load phase / compute phase, 5 blocks per CU)
+//   igemm_bf16_rh_tile   3x3 / stride-1 "row-halo" tile: one staged activation tile for the three kw taps
+//   igemm_bf16_group_kernel / _pp_kernel / _rh_kernel   up to 8 independent convs in one grid (ring / ping-pong / ping-pong
+//                        with row-halo tiles); igemm_bf16_kernel / igemm_bf16_rh_kernel: one conv
+//   igemm_bf16_stem_kernel (+ igemm_bf16_smallc_kernel)   Cin = 3 stem under compute_dtype = bf16
 #include <stdlib.h>
 
 #include "kernels.h"
