@@ -204,3 +204,30 @@ def test_integration_stub_struct_matches_the_header_and_the_binding():
     assert ctypes.sizeof(CapfConfig) == 4 * 22
     ctor = re.search(r"c = capf_config\(([^\n]*)\)\s+#", doc).group(1)
     assert len(re.sub(r"\([^)]*\)", "T", ctor).split(",")) == len(bound)
+
+
+def test_hot_kernels_do_not_spill_registers():
+    """Build guard: a spilling MFMA kernel still produces right answers, 5-8x slower (scratch traffic and slow dispatch) --
+    the grouped bf16 kernel once went from 16600 to 2000 frames/s that way.  Compile the conv / GEMM sources to assembly for
+    gfx950 and require vgpr_spill_count == 0 for every kernel."""
+    import concurrent.futures, re, shutil, subprocess, tempfile
+    hipcc = shutil.which("hipcc")
+    if hipcc is None:
+        pytest.skip("hipcc not on PATH")
+    csrc = os.path.join(ROOT, "contextaware-poseformer_amd", "csrc")
+
+    def spills(name):
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, name + ".s")
+            subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                            "-S", "--cuda-device-only", os.path.join(csrc, name + ".hip"), "-o", out],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            text = open(out).read()
+        names = re.findall(r"^\s+\.name:\s+(\S+)", text, flags=re.M)
+        counts = [int(v) for v in re.findall(r"^\s+\.vgpr_spill_count:\s+(\d+)", text, flags=re.M)]
+        assert len(names) == len(counts) and counts
+        return [(n, c) for n, c in zip(names, counts) if c]
+
+    with concurrent.futures.ThreadPoolExecutor(4) as ex:
+        bad = sum(ex.map(spills, ["igemm_bf16", "igemm_f32", "igemm_f32_pw", "igemm_wino"]), [])
+    assert not bad, f"kernels with register spills: {bad}"
