@@ -579,3 +579,38 @@ def test_grouped_bf16_launch_with_row_halo_tiles_matches_torch(chans, B):
         got = y.float().cpu().permute(0, 3, 1, 2)
         tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
         assert (got - want).abs().max().item() <= tol
+
+
+def test_row_halo_fuzz_against_torch():
+    """Seeded random 3x3 problems through the row-halo kernel: every chunk width (Cin multiples of 32 / 48 / 64), ragged Cout
+    (multiples of 4 and of 8), image sizes from 1x1 up, widths that are not multiples of anything, with and without residual /
+    ReLU -- tiles of 126 flat pixels cross image rows and images in almost every case."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(20260929)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    for case in range(24):
+        ci = (32, 48, 64, 96, 128, 160, 192)[ri(0, 6)]
+        co = 4 * ri(1, 50) if case % 3 else 8 * ri(1, 30)
+        H, W, B = ri(1, 37), ri(1, 41), ri(1, 5)
+        act, res = ri(0, 1), bool(ri(0, 1))
+        x = torch.randn(B, ci, H, W, generator=rng).bfloat16()
+        w = torch.randn(co, ci, 3, 3, generator=rng) / (ci * 9) ** 0.5
+        bnp = (torch.rand(co, generator=rng) + 0.5, torch.randn(co, generator=rng) * 0.1, torch.randn(co, generator=rng) * 0.1,
+               torch.rand(co, generator=rng) * 0.4 + 0.8)
+        wp, bias, cw = capf.pack_conv_bf16_rh(w.cuda(), tuple(t.cuda() for t in bnp))
+        w_fold = wp.float().cpu().view(co, 3, ci // cw, 3, cw).permute(0, 2, 4, 1, 3).reshape(co, ci, 3, 3)
+        want = F.conv2d(x.float(), w_fold, bias.cpu(), 1, 1)
+        r = torch.randn_like(want).bfloat16() if res else None
+        if res:
+            want = want + r.float()
+        if act:
+            want = F.relu(want)
+        got = capf.conv_nhwc_bf16_rh(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
+                                     r.permute(0, 2, 3, 1).contiguous().cuda() if res else None)
+        got = got.float().cpu().permute(0, 3, 1, 2)
+        tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
+        err = (got - want).abs().max().item()
+        assert err <= tol, f"case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}: {err:.3e} > {tol:.3e}"
