@@ -39,6 +39,16 @@ sys.path.insert(0, os.path.join(ROOT, "contextaware-poseformer_amd"))
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (fp32-input matrix = vector rate)
 HBM_PEAK_GBS = 8000.0
 
+# the reference's own forward timed in the survey container (not on this box; orientation only)
+REFERENCE_CPU = {
+    ("hrnet_32", 256, 256): {"cores": 8, "kind": "reference", "where": "survey container, 8 x Xeon 2.10 GHz",
+                             "frames_per_s": {"batch 1": 9.0, "batch 16": 18.8, "batch 64": 13.9}},
+    ("hrnet_48", 256, 256): {"cores": 8, "kind": "reference", "where": "survey container, 8 x Xeon 2.10 GHz",
+                             "frames_per_s": {"batch 16": 13.3}},
+    ("cpn", 384, 288): {"cores": 8, "kind": "reference", "where": "survey container, 8 x Xeon 2.10 GHz",
+                        "frames_per_s": {"batch 16": 9.3}},
+}
+
 # BASELINE.json configs[i] -> arguments (batch is per GPU)
 CONFIGS = {
     0: dict(backbone="hrnet_32", batch=1, height=256, width=256, dtype="f32", train=False),
@@ -155,6 +165,9 @@ def cpu_baseline(backbone, H, W, sd_cpu, budget_s=24.0):
     points.append({"batch": 1, "threads": best_threads, "frames_per_s": round(1 / t1[len(t1) // 2], 2)})
     return {"value": round(16 / med16, 2), "unit": "frames/s", "cores": best_threads, "host_cores": host, "kind": "port",
             "points": points,
+            # the REFERENCE itself (imported from /root/reference, PyTorch-CPU/oneDNN) cannot travel to this box; its timing in the
+            # survey container is the second comparator SURVEY.md §8(d) asks for (8 x Xeon 2.1 GHz, 8 threads)
+            "reference_in_survey_container": REFERENCE_CPU.get((backbone, H, W)),
             "sample": f"{len(times)} x batch-16 and {len(t1)} x batch-1 {backbone} {H}x{W} fp32 forwards of oracle/capf_oracle.py "
                       f"(functional PyTorch-CPU/oneDNN; value = median batch-16 rate at {best_threads} threads, the best of the sweep in `points`)"}
 
@@ -179,13 +192,24 @@ def main():
         for _ in range(a.steps):
             time.sleep(0.002 * (1 + rank))
         cdist.barrier()
-        elapsed = cdist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+        mine_s = time.perf_counter() - t0
+        dry_dist = None
+        if world > 1:
+            ones = torch.ones(1)
+            dist.all_reduce(ones)
+            mine = torch.tensor([B * a.steps / mine_s], dtype=torch.float64)
+            rates = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(rates, mine)
+            dry_dist = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()), "devices_visible": torch.cuda.device_count(),
+                        "per_rank_frames_per_s": [round(r.item(), 2) for r in rates]}
+        elapsed = cdist.max_over_ranks(mine_s, torch.device("cpu"))
         if rank == 0:
             print(json.dumps({"metric": "frames/sec", "value": round(B * world * a.steps / elapsed, 2), "unit": "frames/s",
                               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "none",
                               "dry_run": True, "config": {"workload": workload_string(a, tag), "frames_per_step": B * world,
-                                                          "shard_of_rank0": [lo, hi]}}))
+                                                          "shard_of_rank0": [lo, hi]},
+                              "distributed": dry_dist}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -196,6 +220,9 @@ def main():
     from mvn.utils.cfg import backbone_preset, config
     if os.environ.get("CAPF_BENCH_SINGLE_DEVICE"):         # smoke-testing the N>1 flow on a 1-GPU box (gloo only)
         local = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s): one rank per GPU is the contract "
+                         f"(RCCL refuses two ranks on one device); nothing was measured")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -232,8 +259,8 @@ def main():
             model.zero_grad(set_to_none=True)
             loss.backward()
             flat_g = model.last_flat_grad
-            cdist.allreduce_mean_(flat_g)                                    # ONE RCCL all-reduce of 56.4 MB (C3)
-            opt.step(flat_g)
+            flat_g, gscale = cdist.allreduce_sum_(flat_g)                    # ONE RCCL all-reduce of 56.4 MB (C3) ...
+            opt.step(flat_g, grad_scale=gscale)                              # ... its 1 / world folded into the AdamW kernel
             model.lifter_params_changed()
             return pred.detach()
     else:
@@ -257,6 +284,19 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    dist_info = None
+    if world > 1:
+        # evidence that the job really ran on `world` ranks of the named backend: a SUM all-reduce of ones on the device
+        # (through RCCL when the backend is nccl) and every rank's own rate
+        on_host = dist.get_backend() == "gloo"
+        ones = torch.ones(1, dtype=torch.float32, device="cpu" if on_host else dev)
+        dist.all_reduce(ones)
+        mine = torch.tensor([B * a.steps / elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
+        rates = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rates, mine)
+        dist_info = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()),
+                     "devices_visible": torch.cuda.device_count(),
+                     "per_rank_frames_per_s": [round(r.item(), 2) for r in rates]}
     elapsed = cdist.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / a.steps * 1e3
     fps = B * world * a.steps / elapsed
@@ -268,6 +308,7 @@ def main():
         # the training configuration the frozen-backbone forward is 90 % of the step and owns the dominant kernel)
         table = eng.op_table(B)
         obytes = eng.op_bytes(B)
+        oexec = eng.op_executed_flops(B)
         acc = {}
         out_buf = torch.empty_like(out)
         with torch.no_grad():
@@ -288,22 +329,25 @@ def main():
                                 else ("igemm_wino_group" if kern.startswith("igemm_wino") else "igemm_f32_group"))
                     if not kern or table[l][0].startswith("copy."):
                         continue
-                    e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0])
+                    e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0, 0.0])
                     e[0] += ms[l]; e[1] += sum(table[i][2] for i in ops_); e[2] += 1; e[3] += sum(obytes[i] for i in ops_)
+                    e[4] += sum(oexec[i] for i in ops_)
                 n_launches = len(members)
         nprof = max(1, a.profile_steps)
         total_ms = sum(e[0] for e in acc.values())
-        dname, (dms, dflops, dn, dbytes) = max(acc.items(), key=lambda kv: kv[1][0])
+        dname, (dms, dflops, dn, dbytes, dexec) = max(acc.items(), key=lambda kv: kv[1][0])
         tflops = dflops / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
         gbs = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
         gemm_ms = sum(e[0] for k, e in acc.items() if k.startswith("igemm"))
         gemm_fl = sum(e[1] for k, e in acc.items() if k.startswith("igemm"))
         gemm_by = sum(e[3] for k, e in acc.items() if k.startswith("igemm"))
+        gemm_ex = sum(e[4] for k, e in acc.items() if k.startswith("igemm"))
         peak = PEAK_TFLOPS[a.dtype]
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
         # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
         traffic, tsrc = None, None
-        for tfile, key in ((os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"), f"cfg{tag}"),
+        for tfile, key in ((os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"), f"cfg{tag}"),
+                           (os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"), f"cfg{tag}"),
                            (os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"), None)):
             if traffic is None and tag is not None and os.path.exists(tfile):
                 data = json.load(open(tfile))
@@ -316,12 +360,21 @@ def main():
         roofline = dict(first)
         roofline.update({
             "kernel": dname, "traffic": traffic, "traffic_source": tsrc, "other_roof": second,
+            # `achieved` / `frac` above credit the kernel with the ALGORITHMIC (direct-convolution-equivalent) FLOPs, as SURVEY.md
+            # 8(d) prescribes; a Winograd kernel EXECUTES 1/2 (F(4,3)) or 2/3 (F(2,3)) of those multiplies, so the matrix pipe's
+            # own utilisation is the second pair: executed FLOPs / duration / peak (an upper bound on SQ_VALU_MFMA_BUSY, which the
+            # PMC pass in profiles/ measures directly)
+            "flops_convention": "algorithmic = 2*M*N*K of the direct convolution (SURVEY 8d); executed = MFMA MACs actually issued",
+            "executed_flops_per_launch": round(dexec / dn, 1),
+            "executed_tflops": round(dexec / (dms * 1e-3) / 1e12, 2) if dms > 0 else 0.0,
+            "mfma_busy_frac": round(dexec / (dms * 1e-3) / 1e12 / peak, 4) if dms > 0 else 0.0,
             "algorithmic_flops_per_launch": round(dflops / dn, 1), "algorithmic_bytes_per_launch": round(dbytes / dn, 1),
             "launches_per_step": dn // nprof, "avg_launch_us": round(dms / dn * 1e3, 2),
             "share_of_forward": round(dms / total_ms, 4),
             "measured_hbm_gbs": round(traffic / (dms / dn * 1e-3) / 1e9, 1) if traffic else None,
             "all_mfma_kernels": {"tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
                                  "mfma_frac": round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                                 "mfma_busy_frac": round(gemm_ex / (gemm_ms * 1e-3) / 1e12 / peak, 4),
                                  "algorithmic_gbs": round(gemm_by / (gemm_ms * 1e-3) / 1e9, 1),
                                  "share_of_forward": round(gemm_ms / total_ms, 4)},
             "forward_ms_by_events": round(total_ms / nprof, 3)})
@@ -329,8 +382,9 @@ def main():
             for k, e in sorted(acc.items(), key=lambda kv: -kv[1][0]):
                 tf = e[1] / (e[0] * 1e-3) / 1e12 if e[0] > 0 else 0
                 gb = e[3] / (e[0] * 1e-3) / 1e9 if e[0] > 0 else 0
-                print(f"  {k:34s} {e[2] // nprof:4d} launches/step {e[0] / nprof:9.3f} ms/step {tf:8.2f} TFLOP/s {gb:8.1f} GB/s(alg)",
-                      file=sys.stderr)
+                ex = e[4] / (e[0] * 1e-3) / 1e12 if e[0] > 0 else 0
+                print(f"  {k:34s} {e[2] // nprof:4d} launches/step {e[0] / nprof:9.3f} ms/step {tf:8.2f} TFLOP/s(alg) {ex:8.2f} TFLOP/s(exec) "
+                      f"{gb:8.1f} GB/s(alg)", file=sys.stderr)
         launches, flops = eng.stats(B)
         par = f"dp{world} (independent frames, " + ("one flat-gradient all-reduce per step)" if a.train else "no collective)")
         result = {
@@ -342,6 +396,8 @@ def main():
             "end_to_end_forward_tflops": round(fps * flops / B / 1e12, 2),
             "roofline": roofline,
         }
+        if dist_info is not None:
+            result["distributed"] = dist_info
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(a.backbone, H, W, sd_cpu)
             result["gpu_over_cpu"] = round(fps / result["cpu_baseline"]["value"], 1)

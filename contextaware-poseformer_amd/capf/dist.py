@@ -52,17 +52,26 @@ def gather_predictions(local, total, world=None):
     return torch.cat(parts, 0)
 
 
-def allreduce_mean_(flat):
-    """In-place average of one flat fp32 gradient buffer over ranks (one collective for all 14 M lifter
-    gradients instead of DDP's three 25 MB buckets)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def allreduce_sum_(flat):
+    """In-place SUM of one flat fp32 gradient buffer over ranks — one collective for all 14 M lifter gradients instead of
+    DDP's three 25 MB buckets.  Returns (flat, scale) with scale = 1 / world_size: the division that turns the sum into DDP's
+    average is folded into the consumer (capf_adamw_step's grad_scale), not run as a separate pass over 56 MB."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1:
         if flat.is_cuda and dist.get_backend() == "gloo":        # CPU-staged (smoke tests of the N>1 flow on one GPU)
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             flat.copy_(host)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+    return flat, 1.0 / world
+
+
+def allreduce_mean_(flat):
+    """allreduce_sum_ followed by the division (for consumers that want the averaged gradient itself, e.g. torch optimizers)."""
+    flat, scale = allreduce_sum_(flat)
+    if scale != 1.0:
+        flat.mul_(scale)
     return flat
 
 

@@ -8,6 +8,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY = 1, 2, 4, 8     # capf_plan_flag
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
@@ -16,6 +17,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_op_conv_bf16_group", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
+    "capf_op_bilinear_corners", "capf_mpjpe_nd", "capf_op_executed_flops",
 ]
 
 
@@ -29,7 +31,7 @@ class CapfConfig(ctypes.Structure):
         ("base_dim", c_int32), ("embed_dim_ratio", c_int32), ("levels", c_int32), ("num_joints", c_int32),
         ("num_heads", c_int32), ("deform_heads", c_int32), ("deform_samples", c_int32), ("context_blocks", c_int32),
         ("compute_dtype", c_int32), ("max_batch", c_int32), ("height", c_int32), ("width", c_int32),
-        ("training", c_int32),
+        ("training", c_int32), ("plan_flags", c_int32),
     ]
 
 
@@ -75,6 +77,7 @@ def load_library():
     lib.capf_num_ops.argtypes = [H]
     lib.capf_op_info.argtypes = [H, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double)]
     lib.capf_op_bytes.argtypes = [H, c_int, c_int, POINTER(c_double)]
+    lib.capf_op_executed_flops.argtypes = [H, c_int, c_int, POINTER(c_double)]
     lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          POINTER(c_float), c_int]
     lib.capf_forward_profile_launches.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -89,7 +92,9 @@ def load_library():
     lib.capf_grad_elems.restype = c_int64
     lib.capf_grad_info.argtypes = [H, c_int, POINTER(c_int64)]
     lib.capf_mpjpe.argtypes = [P, P, P, c_int, P, P, c_float]
-    lib.capf_adamw_step.argtypes = [P, P, P, P, P, c_int64] + [c_float] * 5 + [c_int]
+    lib.capf_mpjpe_nd.argtypes = [P, P, P, c_int, c_int, P, P, c_float]
+    lib.capf_adamw_step.argtypes = [P, P, P, P, P, c_int64] + [c_float] * 5 + [c_int, c_float]
+    lib.capf_op_bilinear_corners.argtypes = [P, P, c_int, c_int, c_int, c_int, P, P]
     lib.capf_op_pack_conv.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     lib.capf_op_linear.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -285,6 +290,14 @@ class Engine:
         for i in range(self.lib.capf_num_ops(self.h)):
             self._check(self.lib.capf_op_bytes(self.h, i, batch, byref(b)), "op_bytes")
             out.append(b.value)
+        return out
+
+    def op_executed_flops(self, batch):
+        """FLOPs the matrix pipe executes per op at `batch` (capf_op_executed_flops: Winograd ops count 1/2 or 2/3), launch order"""
+        f, out = c_double(), []
+        for i in range(self.lib.capf_num_ops(self.h)):
+            self._check(self.lib.capf_op_executed_flops(self.h, i, batch, byref(f)), "op_executed_flops")
+            out.append(f.value)
         return out
 
     def forward_profile(self, images, k2d, kcrop, out, stream):
@@ -559,6 +572,21 @@ def linear(x, w, bias=None, act=0, residual=None):
     if rc:
         raise CapfError(f"capf_op_linear failed ({rc})")
     return y
+
+
+def bilinear_corners(grid, H, W, border):
+    """grid: CUDA fp32 [..., 2] normalised (x, y) -> (idx int32 [..., 2] = NW corner (x0, y0), frac fp32 [..., 2]) by the
+    device function both sampling sites of capf_forward use."""
+    import torch
+    lib = load_library()
+    g = grid.contiguous()
+    n = g.numel() // 2
+    idx = torch.empty(g.shape, dtype=torch.int32, device=g.device)
+    frac = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+    rc = lib.capf_op_bilinear_corners(_stream(g), _p(g), n, int(H), int(W), 1 if border else 0, _p(idx), _p(frac))
+    if rc:
+        raise CapfError(f"capf_op_bilinear_corners failed ({rc})")
+    return idx, frac
 
 
 def linear_bf16(x, w, bias=None, residual=None, gelu=False):

@@ -36,11 +36,12 @@ class FusedAdamW:
         self.v = torch.zeros_like(flat_params)
         self.t = 0
 
-    def step(self, flat_grad):
+    def step(self, flat_grad, grad_scale=1.0):
+        """grad_scale: multiplied into every gradient element inside the kernel (1 / world_size after a SUM all-reduce)."""
         self.t += 1
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
         rc = self.lib.capf_adamw_step(stream, P(self.p), P(flat_grad), P(self.m), P(self.v), self.p.numel(), self.lr,
-                                      self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+                                      self.betas[0], self.betas[1], self.eps, self.wd, self.t, float(grad_scale))
         if rc:
             raise RuntimeError(f"capf_adamw_step failed ({rc})")

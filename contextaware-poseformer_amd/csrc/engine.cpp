@@ -107,7 +107,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
     a.act = op.act;
     a.out_bf16 = op.out_bf16;
-    static const bool splitk_on = [] { const char* e = getenv("CAPF_SPLITK"); return !e || atoi(e) != 0; }();   // A/B runs only
+    static const bool splitk_on = [] { const char* e = diag_env("CAPF_SPLITK"); return !e || atoi(e) != 0; }();   // A/B runs only
     if (op.conv && !op.bf16 && split_ws && lanes != 1 && splitk_on) {      // one stream: launches use the scratch one after the other
         a.split_ws = split_ws; a.split_cnt = split_cnt;
         a.split_ws_elems = SPLIT_WS_ELEMS; a.split_cnt_elems = SPLIT_CNT_ELEMS;
@@ -180,6 +180,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             a.ref = kcrop;
             a.B = batch; a.J = op.i0; a.L = op.i1; a.NH = op.i2; a.NS = op.i3;
             a.feat_bf16 = op.bf16;
+            if (debug && op.idxs[0] >= 0) { a.cpos = ptr(op.idxs[0]); a.cidx = reinterpret_cast<int*>(ptr(op.idxs[1])); }
             HIP_TRY(launch_deform_sample(a, s));
             break;
         }
@@ -214,6 +215,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             a.X = ptr(op.out);
             a.BJ = batch * op.i0; a.J = op.i0; a.L = op.i1; a.L1 = op.i1 + 1; a.C = op.C; a.NH = op.i2; a.NS = op.i3;
             a.feat_bf16 = op.bf16;
+            if (debug && op.idxs[0] >= 0) { a.cpos = ptr(op.idxs[0]); a.cidx = reinterpret_cast<int*>(ptr(op.idxs[1])); }
             HIP_TRY(launch_ctx_attn(a, s));
             break;
         }
@@ -356,6 +358,11 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         g_create_error = "compute_dtype must be CAPF_F32 or CAPF_BF16";
         delete h;
         return CAPF_ERR_UNSUPPORTED;
+    }
+    if (cfg->plan_flags & ~15) {
+        g_create_error = "unknown capf_plan_flag bits";
+        delete h;
+        return CAPF_ERR_INVALID;
     }
     if (cfg->max_batch <= 0) {
         g_create_error = "max_batch must be positive";
@@ -573,11 +580,17 @@ int capf_mpjpe(void* stream, const float* pred, const float* gt, int rows, float
                ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_mpjpe_nd(void* stream, const float* pred, const float* gt, int rows, int dim, float* loss, float* dpred, float grad_scale) {
+    if (!pred || !gt || !loss || rows <= 0 || dim <= 0) return CAPF_ERR_INVALID;
+    return capf::launch_mpjpe_nd(pred, gt, rows, dim, loss, dpred, grad_scale, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_adamw_step(void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int step) {
+                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return CAPF_ERR_INVALID;
     return capf::launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
-                              static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+                              static_cast<hipStream_t>(stream), grad_scale) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
 int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* kcrop_inout, int batch, float* out) {
@@ -689,6 +702,12 @@ int capf_op_linear(void* stream, const float* x, const float* w, const float* bi
     a.amap = capf::row_ld(K); a.omap = capf::row_ld(N); a.rmap = capf::row_ld(N);
     a.act = act;
     return capf::launch_gemm_f32(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_bilinear_corners(void* stream, const float* grid, int n, int H, int W, int border, int32_t* idx, float* frac) {
+    if (!grid || !idx || !frac || n <= 0 || H <= 0 || W <= 0) return CAPF_ERR_INVALID;
+    return capf::launch_bilinear_corners(grid, n, H, W, border, idx, frac, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
 }
 
 int capf_op_pack_conv_bf16(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
@@ -837,6 +856,24 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
                                                                       : h->e.wino_now(op, batch) ? capf::gemm_wino_kernel_name()
                                                                               : capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)));
     if (flops) *flops = op.flops_per_frame * batch;
+    return CAPF_OK;
+}
+
+// FLOPs the MFMA pipe is asked to execute for one op at `batch` (2 x MACs issued, K padding included, tile-edge padding
+// not): the Winograd kernels issue 18 (F(4,3), per four outputs) or 12 (F(2,3), per two) MACs per (cin, cout) where the
+// direct conv issues 36 / 18, i.e. 1/2 or 2/3 of the algorithmic count capf_op_info reports.
+int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* flops) {
+    if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0 || !flops) return CAPF_ERR_INVALID;
+    const capf::Engine& e = h->e;
+    const capf::Op& op = e.ops[index];
+    *flops = op.flops_per_frame * batch;
+    if (op.kind != capf::OP_GEMM) return CAPF_OK;
+    const capf::Pack& pk = e.packs[op.pack];
+    const double MN = 2.0 * (double)op.rows_per_frame * batch * op.N;
+    if (op.conv && e.wino_now(op, batch)) *flops = MN * op.Cin * (pk.Kpad == 18 * pk.Cin ? 4.5 : 6.0);
+    else if (op.wino) *flops = MN * pk.Kpad2;                      // small batch: the direct kernel on the direct layout
+    else if (pk.rh && op.conv) *flops = MN * op.K;                 // row-halo layout has no K padding (decided per launch; lower bound)
+    else *flops = MN * (pk.direct ? op.K : pk.Kpad);
     return CAPF_OK;
 }
 

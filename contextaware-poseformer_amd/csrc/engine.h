@@ -207,6 +207,7 @@ struct Engine {
     // ---- training step (train.cpp)
     int feat_buf[4] = {-1, -1, -1, -1}, feat_H[4] = {0, 0, 0, 0}, feat_W[4] = {0, 0, 0, 0}, feat_C[4] = {0, 0, 0, 0};
     std::vector<int> ctx_ao_pack;        // pack index of [attention_weights | sampling_offsets] per context block
+    std::vector<int> ctx_tap_pos, ctx_tap_idx;   // per context block: debug tap buffers (sampling positions, NW corner indices)
     std::vector<long> grad_off;          // per parameter: offset in the flat lifter gradient, -1 for the backbone
     long grad_elems = 0;
     int train_batch = 0;                 // batch of the forward_train whose activations are still in the workspace (0: none)

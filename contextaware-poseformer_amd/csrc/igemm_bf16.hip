@@ -970,7 +970,7 @@ bool gemm_bf16_smallc_ok(const GemmArgs& a) {
 }
 
 static int stem_runs_ks(const GemmArgs& a) {     // 7 / 3: the run-based stem kernel applies; 0: the element-wise gather kernel
-    static const int v2 = [] { const char* e = getenv("CAPF_STEM_V2"); return e ? atoi(e) : 1; }();     // A/B runs only
+    static const int v2 = [] { const char* e = diag_env("CAPF_STEM_V2"); return e ? atoi(e) : 1; }();     // A/B runs only
     if (!v2 || a.Cin != 3 || a.pad != a.ks / 2 || a.K != a.ks * a.ks * 3) return 0;
     if (a.ks == 7 && a.Kpad >= 6 * 21 + 24) return 7;
     if (a.ks == 3 && a.Kpad >= 2 * 9 + 12) return 3;
@@ -1009,7 +1009,7 @@ static int rh_tn(int N, int cw) { return N <= 32 ? 1 : ((N % 96 == 0 && cw == 48
 
 // chunk width of the row-halo kernel for Cin input channels (a multiple of 64, 48 or 32), 0 = not supported
 int bf16_rh_width(int Cin) {
-    static const int force = [] { const char* e = getenv("CAPF_BF16_RH_CW"); return e ? atoi(e) : 0; }();   // tuning only
+    static const int force = [] { const char* e = diag_env("CAPF_BF16_RH_CW"); return e ? atoi(e) : 0; }();   // tuning only
     if (force && Cin % force == 0 && (force == 64 || force == 48 || force == 32)) return force;
     return Cin % 64 == 0 ? 64 : (Cin % 48 == 0 ? 48 : (Cin % 32 == 0 ? 32 : 0));
 }
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256, 4) void igemm_bf16_group_rh_kernel(GroupArgsB 
 // batch 1 / 8; thresholds 512 / 1024 / 2048 / 4096 / never give 9489 / 9599 / 10144 / 10137 / 10066 frames/s at batch 32 and
 // 13699 / 13716 / 13713 / 13195 / 13052 at batch 64.
 static int pp_min_tiles() {
-    static const int v = [] { const char* e = getenv("CAPF_BF16_PP_MIN_TILES"); return e ? atoi(e) : 2048; }();
+    static const int v = [] { const char* e = diag_env("CAPF_BF16_PP_MIN_TILES"); return e ? atoi(e) : 2048; }();
     return v;
 }
 

@@ -789,7 +789,7 @@ static const char* kTileNames[N_TILES] = {"w4,128x64", "w4,64x64", "w4,128x128",
 // that "biggest tile that still gives >= 256 blocks" does not: 270 tiles of 128x64 take TWO rounds on 256 CUs
 // (the lifter's M = 17 * 64 GEMMs), 510 tiles of 64x64 take one.  CAPF_TILE=<index> forces a tile (tuning only).
 static TileCfg pick_tile(const GemmArgs& a) {
-    static const int forced = [] { const char* e = getenv("CAPF_TILE"); return e ? atoi(e) : -1; }();
+    static const int forced = [] { const char* e = diag_env("CAPF_TILE"); return e ? atoi(e) : -1; }();
     if (forced >= 0 && forced < N_TILES) return (TileCfg)forced;
     struct Cand { TileCfg cfg; int bm, bn, unit, occ; };
     static const Cand cands[4] = {{W4_256x32, 256, 32, 2, 2}, {W4_128x128, 128, 128, 4, 2}, {W4_128x64, 128, 64, 2, 3},
@@ -814,7 +814,7 @@ static TileCfg pick_tile(const GemmArgs& a) {
 
 // compute_dtype = bf16 (the op writes bf16): the stem runs on the bf16 MFMA too (igemm_bf16.hip); CAPF_STEM_BF16=0 keeps it fp32
 static bool stem_on_bf16(const GemmArgs& a) {
-    static const int on = [] { const char* e = getenv("CAPF_STEM_BF16"); return e ? atoi(e) : 1; }();
+    static const int on = [] { const char* e = diag_env("CAPF_STEM_BF16"); return e ? atoi(e) : 1; }();
     return on && gemm_bf16_smallc_ok(a);
 }
 
@@ -840,7 +840,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     if (a.conv) {
         if (!plain) return hipErrorInvalidValue;
 #ifdef CAPF_DIAG      // ablation / timeline instantiations (make DIAG=1; tools/ablate.sh, tools/timeline.py)
-        static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
+        static const int abl = [] { const char* e = diag_env("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
         if (abl == 1)
             hipLaunchKernelGGL((igemm_f32_kernel<NW, BM, BN, WM, WN, S, AMODE_CONV, false, true, 1>), grid, block, 0, s, a);
         else if (abl == 3)
@@ -900,7 +900,8 @@ static long group_tiles_small(const GemmArgs& a) {
 }
 // does a lone conv gain from the split-K path of the grouped kernel? (few tiles, long K, scratch available)
 static bool worth_splitting(const GemmArgs& a) {
-    return a.conv && a.split_ws && a.split_cnt && gemm_f32_groupable(a) && a.Kpad / BK >= 32 && group_tiles_small(a) <= 16 &&
+    // (a.N & 3) == 0: the slab stores / reloads are 16-byte accesses at slab + m * N + n
+    return a.conv && a.split_ws && a.split_cnt && gemm_f32_groupable(a) && (a.N & 3) == 0 && a.Kpad / BK >= 32 && group_tiles_small(a) <= 16 &&
            (long)a.M * a.N * 2 <= a.split_ws_elems;
 }
 
@@ -983,7 +984,7 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     bool any_split = false;
     for (int i = 0; i < n; ++i) any_split |= ga.splits[i] > 1;
 #ifdef CAPF_DIAG
-    static const int abl = [] { const char* e = getenv("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int abl = [] { const char* e = diag_env("CAPF_ABLATE"); return e ? atoi(e) : 0; }();
     if (abl == 7 && !any_split) {
         hipLaunchKernelGGL((igemm_f32_group_kernel<7>), dim3(start), dim3(256), 0, s, ga);
         return hipGetLastError();

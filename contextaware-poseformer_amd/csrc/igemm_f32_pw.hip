@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 3) void igemm_f32_pw_kernel(GemmArgs p) {
 // 1x1 / stride 1 / no padding, K = Cin = Kpad a multiple of 32, N a multiple of 8, plain 16-byte aligned row maps, no
 // DropPath scale / LayerNorm fold / split-K / GELU, and enough tiles for the ping-pong schedule (8 per CU)
 bool gemm_f32_pw_ok(const GemmArgs& a) {
-    static const int on = [] { const char* e = getenv("CAPF_F32_PW"); return e ? atoi(e) : 1; }();     // A/B runs only
+    static const int on = [] { const char* e = diag_env("CAPF_F32_PW"); return e ? atoi(e) : 1; }();     // A/B runs only
     if (!on || !a.conv || a.ks != 1 || a.stride != 1 || a.pad != 0 || a.K != a.Cin || a.Kpad != a.K || a.K % 32 != 0 || a.N % 8 != 0)
         return false;
     if (a.omap.G != 1 || (a.omap.S1 & 3) || (a.omap.off & 3) || (a.res && (a.rmap.G != 1 || (a.rmap.S1 & 3) || (a.rmap.off & 3)))) return false;

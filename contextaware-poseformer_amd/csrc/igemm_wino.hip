@@ -1012,7 +1012,7 @@ static hipError_t wino_attr() {
 
 // CAPF_WINO_MODE (A/B runs only): 0 (default) ping-pong, 64 KiB, two blocks per CU; 1: double-buffered 64 x 64 tile, 128 KiB
 static int wino_mode() {
-    static const int m = [] { const char* e = getenv("CAPF_WINO_MODE"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char* e = diag_env("CAPF_WINO_MODE"); return e ? atoi(e) : 0; }();
     return m;
 }
 
@@ -1022,7 +1022,7 @@ static const int kWLDS[5] = {WLDS / 2, 4 * (64 + 32) * WBK, 4 * (64 + 32) * WBK,
 // tile configuration for a prepared problem (a.M = tiles).  F(2,3): narrow outputs -> 64 x 32; few tiles -> 32 x 64 (twice the
 // blocks).  F(4,3): 32 tiles x 64 channels, or 64 x 32 for outputs that are not a multiple of 64 wide.
 static int wino_cfg(const GemmArgs& a) {
-    static const int forced = [] { const char* e = getenv("CAPF_WINO_CFG"); return e ? atoi(e) : -1; }();   // tuning only
+    static const int forced = [] { const char* e = diag_env("CAPF_WINO_CFG"); return e ? atoi(e) : -1; }();   // tuning only
     if (is43(a)) return a.N % 64 != 0 ? 3 : 4;
     if (forced == 1 || (forced == 2 && a.N % 64 == 0)) return forced;
     if (a.N % 64 != 0) return 1;

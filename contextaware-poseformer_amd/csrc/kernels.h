@@ -3,7 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace capf {
+
+// A/B and tuning switches read the environment ONLY in the diagnostic build (make DIAG=1 -> tools/ab/libcapf_diag.so,
+// -DCAPF_DIAG, loaded through CAPF_LIB by the tools); the product library ignores them, so an exported variable can never
+// change a production plan or its numerics.  What tests need to steer is an explicit field: capf_config::plan_flags.
+inline const char* diag_env(const char* name) {
+#ifdef CAPF_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction);
 // the software form (5 integer ops per value) made the bf16 epilogues VALU-bound.  Host passes never call these.
@@ -18,6 +32,34 @@ __host__ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {  
 #endif
 }
 __host__ __device__ __forceinline__ unsigned short to_bf16(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
+
+// Bilinear corner of F.grid_sample(mode='bilinear', align_corners=True) at normalised coordinates (gx, gy): the integer NW
+// corner and the fractional weights of the +1 corners, exactly as ATen computes them (GridSampler.h:27-36, 58-60, 143-171:
+// ((g + 1) / 2) * (size - 1); padding 'border' clips the COORDINATE to [0, size - 1] before floor, 'zeros' keeps it).  The
+// result feeds an index gather that must be bit-exact, so every translation unit that instantiates this is built with
+// -ffp-contract=off (csrc/Makefile: lifter.hip, lifter_fused.hip) -- no FMA contraction, IEEE division.
+struct BilinearCorner {
+    int x0, y0;
+    float wx1, wy1;
+};
+#if defined(__HIPCC__)
+template <bool BORDER>
+__device__ __forceinline__ BilinearCorner bilinear_corner(float gx, float gy, int H, int W) {
+    float x = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float y = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    if (BORDER) {   // clip_coordinates: min(size - 1, max(x, 0)) before floor
+        x = fminf((float)(W - 1), fmaxf(x, 0.0f));
+        y = fminf((float)(H - 1), fmaxf(y, 0.0f));
+    }
+    const float xf = floorf(x), yf = floorf(y);
+    BilinearCorner c;
+    c.x0 = (int)xf;
+    c.y0 = (int)yf;
+    c.wx1 = x - xf;
+    c.wy1 = y - yf;
+    return c;
+}
+#endif
 
 // addr(m) = (m / G) * S1 + (m % G) * S2 + off   (elements).  G == 1 -> plain leading dimension S1.
 struct RowMap {
@@ -168,8 +210,13 @@ struct DeformArgs {
     int feat_bf16;           // the context maps are bf16
     int ld_ao;               // row pitch of AO (0 = 3*NH*NS, the inference layout; 64 in training)
     const float* dU[4];      // backward only: gradient w.r.t. U[l]
+    float* cpos;             // optional taps (capf_set_debug): sampling positions pos = tanh(off) + ref, [B*J, L, NH*NS, 2] ...
+    int* cidx;               // ... and the NW corner (x0, y0) of each, border mode (bit-exact check against the oracle)
 };
 hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s);
+// the corner arithmetic of both sampling sites on caller-supplied coordinates (op-level parity test): grid [n, 2] normalised
+// (x, y) -> idx [n, 2] = (x0, y0), frac [n, 2] = (wx1, wy1); border = 1: padding_mode='border' (pose_dformer.py:128), 0: zeros (:217)
+hipError_t launch_bilinear_corners(const float* grid, int n, int H, int W, int border, int* idx, float* frac, hipStream_t s);
 // ---- fused front half of the lifter (lifter_fused.hip) -----------------------------------------------------------
 // crop-keypoint normalisation (in place) + coord_embed + reference-point sampling (padding zeros) + feat_embed + pos
 struct EmbedArgs {
@@ -198,6 +245,8 @@ struct CtxAttnArgs {
     int BJ, J, L, L1, C, NH, NS;
     int feat_bf16;
     int woff[4];                 // per-wave LDS section offsets (floats), filled by the launcher
+    float* cpos;                 // optional taps (capf_set_debug): sampling positions [BJ, L, NH*NS, 2] and their NW corners
+    int* cidx;
 };
 hipError_t launch_ctx_attn(const CtxAttnArgs& a, hipStream_t s);
 // tiny multi-head attention: QKV [G*N, 3*heads*d] -> O [G*N, heads*d]; N tokens per group
@@ -225,8 +274,10 @@ hipError_t launch_attention_bwd(const float* qkv, const float* dO, float* dqkv, 
 hipError_t launch_deform_bwd(const DeformArgs& a, float* dAO, int ldd, hipStream_t s);
 hipError_t launch_mpjpe(const float* pred, const float* gt, int rows, float* loss, float* dpred, float gscale,
                         hipStream_t s);
+hipError_t launch_mpjpe_nd(const float* pred, const float* gt, int rows, int D, float* loss, float* dpred, float gscale,
+                           hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                        float wd, int step, hipStream_t s);
+                        float wd, int step, hipStream_t s, float gscale = 1.0f);
 // dst[r, :] = src[smap(r), :] * scale[r / div]   (DropPath mask on a gradient), width C
 hipError_t launch_scale_rows(const float* src, RowMap smap, const float* scale, int div, float* dst, int rows, int C,
                              hipStream_t s);

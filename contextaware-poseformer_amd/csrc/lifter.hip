@@ -48,25 +48,23 @@ hipError_t launch_prep_embed(float* kcrop, const float* k2d, const float* w, con
 }
 
 // ---- bilinear corner computation shared by both sampling sites ------------------------------------
-struct Corner {
-    int x0, y0;
-    float wx1, wy1;
-};
+typedef BilinearCorner Corner;      // kernels.h: shared with lifter_fused.hip and the op-level entry point below
 template <bool BORDER>
-__device__ __forceinline__ Corner corner_of(float gx, float gy, int H, int W) {
-    float x = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-    float y = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-    if (BORDER) {   // clip_coordinates: min(size-1, max(x, 0)) before floor
-        x = fminf((float)(W - 1), fmaxf(x, 0.0f));
-        y = fminf((float)(H - 1), fmaxf(y, 0.0f));
-    }
-    const float xf = floorf(x), yf = floorf(y);
-    Corner c;
-    c.x0 = (int)xf;
-    c.y0 = (int)yf;
-    c.wx1 = x - xf;
-    c.wy1 = y - yf;
-    return c;
+__device__ __forceinline__ Corner corner_of(float gx, float gy, int H, int W) { return bilinear_corner<BORDER>(gx, gy, H, W); }
+
+__global__ void bilinear_corners_kernel(const float* __restrict__ grid, int n, int H, int W, int border, int* __restrict__ idx,
+                                        float* __restrict__ frac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gx = grid[i * 2 + 0], gy = grid[i * 2 + 1];
+    const Corner c = border ? corner_of<true>(gx, gy, H, W) : corner_of<false>(gx, gy, H, W);
+    idx[i * 2 + 0] = c.x0; idx[i * 2 + 1] = c.y0;
+    frac[i * 2 + 0] = c.wx1; frac[i * 2 + 1] = c.wy1;
+}
+
+hipError_t launch_bilinear_corners(const float* grid, int n, int H, int W, int border, int* idx, float* frac, hipStream_t s) {
+    hipLaunchKernelGGL(bilinear_corners_kernel, dim3((n + 255) / 256), dim3(256), 0, s, grid, n, H, W, border, idx, frac);
+    return hipGetLastError();
 }
 
 // element c of an NHWC pixel stored as fp32 or bf16
@@ -229,6 +227,11 @@ __global__ void deform_sample_kernel(DeformArgs a) {
             const float px = tanhf(ao[nk + 2 * k + 0]) + rx;
             const float py = tanhf(ao[nk + 2 * k + 1]) + ry;
             const Corner q = corner_of<true>(px, py, H, W);
+            if (a.cidx && lane == 0) {                      // debug taps (capf_set_debug): positions and NW corners
+                const long t = ((((long)bp * a.L + l) * nk) + k) * 2;
+                a.cpos[t] = px; a.cpos[t + 1] = py;
+                a.cidx[t] = q.x0; a.cidx[t + 1] = q.y0;
+            }
             // border mode: coordinates are already clipped; the +1 corner can only fall outside when its
             // weight is exactly 0, so clamping its index is equivalent to ATen's masked load.
             const int xb = min(q.x0 + 1, W - 1), yb = min(q.y0 + 1, H - 1);

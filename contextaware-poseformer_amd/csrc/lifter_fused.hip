@@ -24,23 +24,9 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-struct CornerF {
-    int x0, y0;
-    float wx1, wy1;
-};
+typedef BilinearCorner CornerF;     // kernels.h: the one corner rule of both sampling sites
 template <bool BORDER>
-__device__ __forceinline__ CornerF corner_f(float gx, float gy, int H, int W) {
-    float x = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-    float y = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-    if (BORDER) {
-        x = fminf((float)(W - 1), fmaxf(x, 0.0f));
-        y = fminf((float)(H - 1), fmaxf(y, 0.0f));
-    }
-    const float xf = floorf(x), yf = floorf(y);
-    CornerF c;
-    c.x0 = (int)xf; c.y0 = (int)yf; c.wx1 = x - xf; c.wy1 = y - yf;
-    return c;
-}
+__device__ __forceinline__ CornerF corner_f(float gx, float gy, int H, int W) { return bilinear_corner<BORDER>(gx, gy, H, W); }
 template <bool BF>
 __device__ __forceinline__ float ld1(const float* pix, int c) {
     if (!BF) return pix[c];
@@ -257,6 +243,11 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
         const float px = ao[CTX_NK + 2 * lane + 0] + a.ref[bp * 2 + 0];
         const float py = ao[CTX_NK + 2 * lane + 1] + a.ref[bp * 2 + 1];
         const CornerF cq = corner_f<true>(px, py, H, W);
+        if (a.cidx) {                                       // debug taps (capf_set_debug): positions and NW corners
+            const long t = ((((long)bp * a.L + l) * CTX_NK) + lane) * 2;
+            a.cpos[t] = px; a.cpos[t + 1] = py;
+            a.cidx[t] = cq.x0; a.cidx[t + 1] = cq.y0;
+        }
         // border mode: coordinates are already clipped; the +1 corner can only fall outside when its weight is
         // exactly 0, so clamping its index is equivalent to ATen's masked load.
         const int xb = min(cq.x0 + 1, W - 1), yb = min(cq.y0 + 1, H - 1);

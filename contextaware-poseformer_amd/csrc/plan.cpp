@@ -641,6 +641,13 @@ void Engine::build_lifter(const Tensor feats[4]) {
             const std::string n = "ctx" + std::to_string(i);
             const int pk_ao = make_linear_pack(*this, {p + ".attention_weights", p + ".sampling_offsets"});
             ctx_ao_pack.push_back(pk_ao);                   // (row layout: the training step's GEMMs, train.cpp)
+            // debug taps of the border-mode sampling site (pose_dformer.py:126-128): positions and NW corner indices
+            const int tap_pos = new_buffer((size_t)J * L * NH * NS * 2, "cpos" + std::to_string(i));
+            const int tap_idx = new_buffer((size_t)J * L * NH * NS * 2, "cidx" + std::to_string(i));
+            name_tensor(*this, "cpos" + std::to_string(i), tap_pos, {-1, J, L * NH * NS, 2});
+            name_tensor(*this, "cidx" + std::to_string(i), tap_idx, {-1, J, L * NH * NS, 2}, 1);
+            ctx_tap_pos.push_back(tap_pos);
+            ctx_tap_idx.push_back(tap_idx);
             if (fused_lifter) {
                 Op op;
                 op.kind = OP_CTX_ATTN;
@@ -663,6 +670,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 op.flops_per_frame += 2.0 * J * L * (double)C * 3 * NH * NS;
                 op.i0 = J; op.i1 = L; op.i2 = NH; op.i3 = NS; op.C = C;
                 op.bf16 = bf16() ? 1 : 0;
+                op.idxs[0] = tap_pos; op.idxs[1] = tap_idx;
                 push(op);
             } else {
             layernorm(*this, n + ".norm1", p + ".norm1", 1e-5f, X, tok, X, tok0, Q, (long)J * L, C);
@@ -683,6 +691,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
                 }
                 op.i0 = J; op.i1 = L; op.i2 = NH; op.i3 = NS;
                 op.bf16 = bf16() ? 1 : 0;
+                op.idxs[0] = tap_pos; op.idxs[1] = tap_idx;
                 push(op);
             }
             for (int l = 0; l < L; ++l) {
@@ -858,14 +867,23 @@ bool Engine::build() {
         err = "unsupported lifter configuration (levels must be 4, 4x4 deformable sampling, embed_dim_ratio % 32 == 0)";
         return false;
     }
-    if (const char* fz = getenv("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;      // A/B runs only
-    if (const char* wz = getenv("CAPF_WINO")) use_wino = atoi(wz) != 0;                  // A/B runs only
-    if (const char* rz = getenv("CAPF_BF16_RH")) use_rh = atoi(rz) != 0;                 // A/B runs only
-    if (const char* wb = getenv("CAPF_WINO_MIN_BATCH")) wino_min_batch = atoi(wb);
-    if (const char* wf = getenv("CAPF_WINO_F43")) wino_f43 = atoi(wf) != 0;               // A/B runs only
-    if (const char* wf = getenv("CAPF_WINO_F43_MINHW")) wino_f43_min_hw = atoi(wf);
-    if (const char* wf = getenv("CAPF_WINO_F43_CPN")) wino_f43_cpn = atoi(wf) != 0;
-    if (const char* wf = getenv("CAPF_WINO_F43_MAXHW")) wino_f43_max_hw = atoi(wf);
+    if (cfg.plan_flags & CAPF_PLAN_NO_FUSED_LIFTER) fused_lifter = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_WINOGRAD) use_wino = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_ROW_HALO) use_rh = false;
+    if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
+    // tuning knobs of the diagnostic build only (diag_env is a constant nullptr in the product library)
+    if (const char* fz = diag_env("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;
+    if (const char* wz = diag_env("CAPF_WINO")) use_wino = atoi(wz) != 0;
+    if (const char* rz = diag_env("CAPF_BF16_RH")) use_rh = atoi(rz) != 0;
+    if (const char* wb = diag_env("CAPF_WINO_MIN_BATCH")) wino_min_batch = atoi(wb);
+    if (const char* wf = diag_env("CAPF_WINO_F43")) wino_f43 = atoi(wf) != 0;
+    if (const char* wf = diag_env("CAPF_WINO_F43_MINHW")) wino_f43_min_hw = atoi(wf);
+    if (const char* wf = diag_env("CAPF_WINO_F43_CPN")) wino_f43_cpn = atoi(wf) != 0;
+    if (const char* wf = diag_env("CAPF_WINO_F43_MAXHW")) wino_f43_max_hw = atoi(wf);
+    // the fused front half (lifter_fused.hip) holds a token row in 4 values per lane and a sampled row in 2 KiB of LDS: wider
+    // configurations (embed_dim_ratio 272 / 288 / ..., > 512-channel context maps) take the one-kernel-per-op plan instead
+    if (cfg.embed_dim_ratio > 256) fused_lifter = false;
+    if (cfg.backbone == CAPF_HRNET && cfg.hr_channels[3] > 512) fused_lifter = false;
     Tensor img{EXT_IMAGES, cfg.height, cfg.width, 3};
     Tensor feats[4];
     if (cfg.backbone == CAPF_HRNET) {

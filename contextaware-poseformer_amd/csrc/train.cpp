@@ -189,6 +189,7 @@ int Engine::forward_train(hipStream_t s, int B, const float* masks) {
         }
         da.AO = tw + c.ao; da.ref = kcrop; da.B = B; da.J = J; da.L = Lv; da.NH = NH; da.NS = NS; da.ld_ao = 64;
         da.feat_bf16 = bf16() ? 1 : 0;
+        if (debug) { da.cpos = bptr(ctx_tap_pos[i], B); da.cidx = reinterpret_cast<int*>(bptr(ctx_tap_idx[i], B)); }
         HIP_TRY(launch_deform_sample(da, s));
         for (int l = 0; l < Lv; ++l) {
             const std::string ep = p + ".embed_proj." + std::to_string(l);

@@ -592,12 +592,45 @@ hipError_t launch_mpjpe(const float* pred, const float* gt, int rows, float* los
     return hipGetLastError();
 }
 
+// the same loss for any width D of the last axis (the reference's MPJPE takes [..., D]: 2-D keypoints, loss.py:16-22)
+__global__ void mpjpe_nd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int rows, int D,
+                                float* __restrict__ loss, float* __restrict__ dpred, float gscale) {
+    __shared__ float red[1024];
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        float q = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float d = pred[(long)r * D + c] - gt[(long)r * D + c];
+            q += d * d;
+        }
+        const float n = sqrtf(q);
+        acc += n;
+        if (dpred) {
+            const float inv = n > 0.f ? gscale / (n * (float)rows) : 0.f;
+            for (int c = 0; c < D; ++c) dpred[(long)r * D + c] = (pred[(long)r * D + c] - gt[(long)r * D + c]) * inv;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)rows;
+}
+
+hipError_t launch_mpjpe_nd(const float* pred, const float* gt, int rows, int D, float* loss, float* dpred, float gscale,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(mpjpe_nd_kernel, dim3(1), dim3(1024), 0, s, pred, gt, rows, D, loss, dpred, gscale);
+    return hipGetLastError();
+}
+
 // ---- fused AdamW over one flat parameter buffer (torch.optim.AdamW semantics, train.py:345) -----------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt) {
+                             float bc1, float bc2_sqrt, float gscale) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i];
+        const float gi = g[i] * gscale;        // 1 / world_size after a SUM all-reduce (exact for 1.0f)
         float pi = p[i] * (1.0f - lr * wd);
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
@@ -609,11 +642,11 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                        float wd, int step, hipStream_t s) {
+                        float wd, int step, hipStream_t s, float gscale) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
     const long want = (n + 255) / 256;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2,
-                       eps, wd, bc1, bc2s);
+                       eps, wd, bc1, bc2s, gscale);
     return hipGetLastError();
 }
 

@@ -38,22 +38,26 @@ def evaluate_using_pred(keypoints_gt, keypoints_3d_predicted, labels_action_idx,
     sums, counts = _capf.segment_sums(err, seg, prev, n_segments=len(action_names))
     sums, counts = sums.cpu().numpy(), counts.cpu().numpy()
 
+    # An action with no frames in the evaluated subset: the reference's e1 / e2 / ev on empty arrays are NaN (mean of nothing) and
+    # the NaN propagates into the merged action; values stay numpy scalars so n == 0 divides to NaN instead of raising.
+    nan = np.float64('nan')
     action_scores = {}
     for a, name in enumerate(action_names):
         n, pairs = int(counts[a, 0]), int(counts[a, 1])
         # the reference stores frame_count * mean(...) per action (:373-376); MPJVE's mean runs over n-1 pairs
-        action_scores[name] = {'MPJPE': sums[a, 0], 'P_MPJPE': sums[a, 1],
-                               'MPJVE': n * (sums[a, 3] / pairs) if pairs > 0 else float('nan'), 'frame_count': n}
+        action_scores[name] = {'MPJPE': np.float64(sums[a, 0]) if n > 0 else nan, 'P_MPJPE': np.float64(sums[a, 1]) if n > 0 else nan,
+                               'MPJVE': np.float64(n * (sums[a, 3] / pairs)) if pairs > 0 else nan, 'frame_count': n}
     for base in [name[:-2] for name in action_names if name.endswith('-1')]:                   # :386-406
-        combined = {'MPJPE': 0.0, 'P_MPJPE': 0.0, 'MPJVE': 0.0, 'frame_count': 0}
+        combined = {'MPJPE': np.float64(0.0), 'P_MPJPE': np.float64(0.0), 'MPJVE': np.float64(0.0), 'frame_count': 0}
         for trial in 1, 2:
             key = '%s-%d' % (base, trial)
             for k in combined:
-                combined[k] += action_scores[key][k]
+                combined[k] = combined[k] + action_scores[key][k]
             del action_scores[key]
         action_scores[base] = combined
-    for k in action_scores:                                                                   # :408-415
-        n = action_scores[k]['frame_count']
-        action_scores[k] = {'MPJPE': action_scores[k]['MPJPE'] / n, 'P_MPJPE': action_scores[k]['P_MPJPE'] / n,
-                            'MPJVE': action_scores[k]['MPJVE'] / n}
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for k in action_scores:                                                               # :408-415
+            n = np.float64(action_scores[k]['frame_count'])
+            action_scores[k] = {'MPJPE': action_scores[k]['MPJPE'] / n, 'P_MPJPE': action_scores[k]['P_MPJPE'] / n,
+                                'MPJVE': action_scores[k]['MPJVE'] / n}
     return action_scores

@@ -17,7 +17,7 @@ from capf.lib import CPN50, HRNET, CapfConfig, CapfError, Engine
 MAX_BATCH = 8192
 
 
-def make_capf_config(config, height=256, width=192, context_blocks=True, compute_dtype="fp32"):
+def make_capf_config(config, height=256, width=192, context_blocks=True, compute_dtype="fp32", plan_flags=0):
     bb = config.model.backbone
     pf = config.model.poseformer
     c = CapfConfig()
@@ -61,6 +61,7 @@ def make_capf_config(config, height=256, width=192, context_blocks=True, compute
     c.max_batch = MAX_BATCH
     c.height, c.width = height, width
     c.training = 1                  # workspace also holds what capf_backward needs (6.4 MB/frame)
+    c.plan_flags = int(plan_flags)  # 0 = the product plan (capf.lib.PLAN_*: take a kernel family out, parity tests only)
     return c
 
 

@@ -52,12 +52,13 @@ class _LifterStep(torch.autograd.Function):
 
 
 class CA_PF(nn.Module):
-    def __init__(self, config, device="cuda:0", compute_dtype="fp32", context_blocks=True):
+    def __init__(self, config, device="cuda:0", compute_dtype="fp32", context_blocks=True, plan_flags=0):
         """compute_dtype: 'fp32' (exact fp32 MFMA, the reference's precision) or 'bf16' (backbone convolutions on
         bf16 MFMA with bf16 activations and fp32 accumulation; the lifter stays fp32) — an extension of the
         reference signature for BASELINE.json's bf16 configurations."""
         super().__init__()
         self.compute_dtype = compute_dtype
+        self.plan_flags = plan_flags               # capf.lib.PLAN_* bits: parity tests compare kernel families; 0 = product plan
         self.context_blocks = context_blocks       # False: the MPI-INF-3DHP variant (model/conpose.py)
         self.num_joints = config.model.backbone.num_joints
         self._config = config
@@ -129,7 +130,7 @@ class CA_PF(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(_native.make_capf_config(self._config, H, W, context_blocks=self.context_blocks,
-                                                  compute_dtype=self.compute_dtype), device=dev.index)
+                                                  compute_dtype=self.compute_dtype, plan_flags=self.plan_flags), device=dev.index)
             eng._bound_generation = None
             eng._lifter_print = None
             self._engines[key] = eng

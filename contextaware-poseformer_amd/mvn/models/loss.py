@@ -32,32 +32,38 @@ class _MPJPEFn(torch.autograd.Function):
         from capf.lib import load_library
         lib = load_library()
         pred_c, gt_c = pred.contiguous(), gt.contiguous()
-        rows = pred_c.numel() // 3
+        dim = pred_c.shape[-1]
+        rows = pred_c.numel() // dim
         loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        dpred = torch.empty_like(pred_c)
+        dpred = torch.empty_like(pred_c) if ctx.needs_input_grad[0] else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)
-        rc = lib.capf_mpjpe(stream, ctypes.c_void_p(pred_c.data_ptr()), ctypes.c_void_p(gt_c.data_ptr()), rows,
-                            ctypes.c_void_p(loss.data_ptr()), ctypes.c_void_p(dpred.data_ptr()), 1.0)
+        P = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+        if dim == 3:
+            rc = lib.capf_mpjpe(stream, P(pred_c), P(gt_c), rows, P(loss), P(dpred), 1.0)
+        else:
+            rc = lib.capf_mpjpe_nd(stream, P(pred_c), P(gt_c), rows, dim, P(loss), P(dpred), 1.0)
         if rc:
             raise RuntimeError(f"capf_mpjpe failed ({rc})")
-        ctx.save_for_backward(dpred)
+        ctx.dpred = dpred
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        (dpred,) = ctx.saved_tensors
-        return dpred * g, None
+        return (ctx.dpred * g if ctx.dpred is not None else None), None
 
 
 class MPJPE(nn.Module):
-    """loss.py:16-22: mean over every leading axis of ||pred - gt||_2 along the last one."""
+    """loss.py:16-22: mean over every leading axis of ||pred - gt||_2 along the last one (any width: 3-D joints, 2-D keypoints).
+    CUDA tensors only — there is no CPU fallback; other float dtypes are computed in fp32."""
 
     def forward(self, keypoints_pred, keypoints_gt):
         assert keypoints_pred.shape == keypoints_gt.shape
-        if keypoints_pred.is_cuda and keypoints_pred.dtype == torch.float32 and keypoints_pred.shape[-1] == 3:
-            return _MPJPEFn.apply(keypoints_pred, keypoints_gt)
-        from capf.lib import CapfError
-        raise CapfError("MPJPE runs on the MI355X only: need fp32 CUDA tensors [..., 3] (no CPU fallback)")
+        if not (keypoints_pred.is_cuda and keypoints_gt.is_cuda):
+            from capf.lib import CapfError
+            raise CapfError("MPJPE runs on the MI355X only: got a CPU tensor (no CPU fallback)")
+        if keypoints_pred.dtype != torch.float32 or keypoints_gt.dtype != torch.float32:
+            keypoints_pred, keypoints_gt = keypoints_pred.float(), keypoints_gt.float()
+        return _MPJPEFn.apply(keypoints_pred, keypoints_gt)
 
 
 def _set_mean(pred, gt, column, per_pair=False):
@@ -101,7 +107,7 @@ class _KeypointsLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, validity, mode, threshold):
         from capf.lib import keypoints_loss
-        loss, dpred = keypoints_loss(mode, pred, gt, validity, threshold, want_grad=pred.requires_grad)
+        loss, dpred = keypoints_loss(mode, pred, gt, validity, threshold, want_grad=ctx.needs_input_grad[0])
         ctx.dpred = dpred
         return loss[0]
 

@@ -70,7 +70,16 @@ typedef struct capf_config {
     int32_t max_batch;         /* workspace is sized for this many frames */
     int32_t height, width;     /* input image size (256x256, 256x192, 384x288, ...) */
     int32_t training;          /* 1: size the workspace for capf_forward_train / capf_backward as well */
+    int32_t plan_flags;        /* 0 = the product plan.  capf_plan_flag bits take one kernel family out of the plan (parity
+                                  tests compare the two routes; nothing else -- no environment variable -- changes a plan) */
 } capf_config;
+
+enum capf_plan_flag {
+    CAPF_PLAN_NO_FUSED_LIFTER = 1,  /* one kernel per lifter op instead of embed_kernel / ctx_attn_kernel / LayerNorm-in-GEMM */
+    CAPF_PLAN_NO_WINOGRAD = 2,      /* fp32 3x3 stride-1 convs on the direct MFMA kernel */
+    CAPF_PLAN_NO_ROW_HALO = 4,      /* bf16 3x3 stride-1 convs on the direct bf16 kernel */
+    CAPF_PLAN_WINOGRAD_F23_ONLY = 8 /* F(2,3) where F(4,3) would be chosen */
+};
 
 /* ---- lifetime -------------------------------------------------------------------------------
  * Replaces CA_PF.__init__ (conpose.py:10-27): builds the layer plan (pose_hrnet.py:312-462 /
@@ -145,8 +154,14 @@ int64_t capf_grad_elems(const capf_handle* h);
 int capf_grad_info(const capf_handle* h, int param_index, int64_t* offset);   /* -1: not a lifter parameter */
 int capf_mpjpe(void* stream, const float* pred, const float* gt, int rows, float* loss, float* dpred,
                float grad_scale);
+/* the same loss for rows of any width `dim` (MPJPE.forward accepts [..., D]: 2-D keypoints as well, loss.py:16-22) */
+int capf_mpjpe_nd(void* stream, const float* pred, const float* gt, int rows, int dim, float* loss, float* dpred,
+                  float grad_scale);
+/* grad_scale multiplies every gradient element on the way in: 1 / world_size turns the SUM all-reduce of the flat
+ * gradient into DDP's average (train.py:361-362) without a separate pass over the 56 MB buffer; 1.0f is exact. */
 int capf_adamw_step(void* stream, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale);
 
 /* Lifter only, on the context maps left in the workspace by the last capf_backbone_forward /
  * capf_forward of the same batch.  Replaces self.volume_net(...) conpose.py:40
@@ -170,6 +185,8 @@ int capf_set_debug(capf_handle* h, int on);
  *   feat0..feat3   context maps, NHWC [B,h,w,C_l]
  *   sampled0..3    reference-point samples [B,17,C_l]          (pose_dformer.py:216-218)
  *   idx0..idx3     int32 [B,17,2] (ix0, iy0) bilinear NW corner of those samples (bit-exact check)
+ *   cpos0..3       with capf_set_debug: sampling positions of DeformableBlock i, fp32 [B,17,L*16,2] (level, head*4+sample)
+ *   cidx0..3       ... and the int32 NW corner (ix0, iy0) of each, padding_mode='border' (pose_dformer.py:126-128)
  *   tok_ctx / tok_res / tok_joint   token buffer [B,17,L+1,c] after each block group (layout b p l c)
  * Pointers are into the workspace and valid until the next forward on this handle.
  * Returns 0 for an fp32 tensor, 1 for an int32 tensor, 2 for a bf16 tensor (context maps of a
@@ -224,6 +241,12 @@ int capf_op_conv_wino(void* stream, const float* x, const float* wp, const float
 int capf_op_conv_wino_group(void* stream, int n, const capf_conv_desc* d, int variant);
 int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual,
                    float* y, int M, int N, int K, int act);
+/* capf_op_bilinear_corners: the corner rule of both sampling sites (F.grid_sample, bilinear, align_corners=True) on
+ * caller-supplied normalised coordinates grid [n,2] = (x, y): idx [n,2] = NW corner (x0, y0), frac [n,2] = weights of the
+ * +1 corners.  border = 1: padding_mode='border' (DeformableBlock, pose_dformer.py:128), 0: 'zeros' (:217).  The same
+ * device function serves capf_forward; inside a forward the corners actually used are exposed through capf_tensor
+ * ("idx{l}" / "cidx{i}" under capf_set_debug).  Must equal ATen's index arithmetic bit for bit.                     */
+int capf_op_bilinear_corners(void* stream, const float* grid, int n, int H, int W, int border, int32_t* idx, float* frac);
 /* bf16 twins (igemm_bf16.hip, v_mfma_f32_32x32x16_bf16): x / residual / y are bf16 NHWC, w_packed is bf16
  * [Cout][Kpad] with Kpad = ks*ks*Cin rounded up to 64, bias stays fp32.  Cin % 8 == 0, Cout % 4 == 0. */
 int capf_op_pack_conv_bf16(void* stream, const float* w_oihw, const float* gamma, const float* beta,
@@ -313,6 +336,11 @@ int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* 
 int capf_num_ops(const capf_handle* h);
 int capf_op_info(const capf_handle* h, int index, int batch, const char** name, const char** kernel,
                  double* flops);
+/* FLOPs the matrix pipe is asked to EXECUTE for op `index` at `batch` (2 x issued MACs; K padding included, tile-edge padding
+ * not).  Differs from capf_op_info's ALGORITHMIC count for the Winograd kernels (F(4,3): 1/2, F(2,3): 2/3 of the direct
+ * convolution's multiplies): bench.py reports both, so that `roofline.frac` (algorithmic / peak) is never read
+ * as matrix-pipe utilisation. */
+int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* flops);
 /* Algorithmic (compulsory) HBM bytes of op `index` at `batch`: each operand read once, the result written once
  * (bf16 tensors 2 B/element).  bench.py's HBM-side roofline divides these by the measured launch durations. */
 int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes);

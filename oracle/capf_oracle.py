@@ -24,6 +24,15 @@ oracle/make_goldens.py, which writes tests/golden/*.npz; tests/test_oracle_golde
 (runs on CPU, no reference needed).  Third-party arithmetic (ATen conv / grid_sampler / layer_norm,
 timm DropPath, einops.rearrange) is restated from its documented semantics; the bilinear rule follows
 ATen/native/GridSampler.h:27-36,58-60,143-171 of the installed torch (the reference pins 1.11.0).
+
+`emulate_bf16=True` (ca_pf_forward / hrnet_forward / cpn_forward / lifter_forward): the SAME algorithm with the storage
+roundings of the engine's compute_dtype = bf16 mode applied at the points where the engine stores bf16:
+conv weights after the BatchNorm fold, the image on its way into the stem, every conv / fuse-sum / max-pool / resize
+output, the LayerNorm rows / attention outputs / GELU hidden rows that feed the lifter's qkv / proj / fc1 / fc2
+projections and those projections' weights; accumulation, bias, residual adds, LayerNorm statistics, softmax, both
+samplers and the token stream stay fp32, as in the engine.  It is the checker for BASELINE configs[2] / [4]: against IT
+the HIP path may differ only by fp32 summation order (and the rare bf16 rounding flip that causes), so the bound is tight,
+while the distance of either from the fp32 reference is the (reported) rounding budget of the bf16 mode.
 """
 import math
 
@@ -47,8 +56,66 @@ def _bn(P, name, x):
                         P[name + ".weight"], P[name + ".bias"], False, 0.0, BN_EPS)
 
 
+def bf16_round(x):
+    """fp32 -> bf16 (round to nearest even, what v_cvt_pk_bf16_f32 does) -> fp32."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class Numerics:
+    """Where values are rounded to bf16 storage.  FP32: nowhere (the reference's arithmetic).  BF16: the engine's
+    compute_dtype = bf16 mode (see the module docstring)."""
+
+    def __init__(self, bf16=False):
+        self.bf16 = bf16
+
+    def r(self, x):
+        return bf16_round(x) if self.bf16 else x
+
+
+FP32, BF16 = Numerics(False), Numerics(True)
+
+
+class _NoRound(Numerics):
+    """bf16 operands (folded weights), result left in fp32: a conv whose output meets another term before it is stored."""
+
+    def __init__(self):
+        super().__init__(True)
+
+    def r(self, x):
+        return x
+
+
+_NOROUND = _NoRound()
+
+
+def _cbr(P, conv, bn, x, stride=1, pad=0, relu=True, res=None, nm=FP32):
+    """conv (bias=False) + eval BatchNorm (+ residual) (+ ReLU): ONE launch of the engine (csrc/plan.cpp conv_bn), so in
+    bf16 mode ONE rounding at the end.  fp32 mode is literally relu(bn(conv(x)) + res)."""
+    if not nm.bf16:
+        y = _bn(P, bn, _conv(P, conv, x, stride, pad))
+    else:
+        # the engine folds BatchNorm into the weights in fp32 and THEN rounds them (elementwise.hip pack_conv_kernel):
+        #   sc = gamma / sqrt(var + eps);  w' = bf16(w * sc);  bias = beta - mean * sc  (fp32)
+        sc = P[bn + ".weight"] / torch.sqrt(P[bn + ".running_var"] + BN_EPS)
+        w = bf16_round(P[conv + ".weight"] * sc.view(-1, 1, 1, 1))
+        y = F.conv2d(x, w, P[bn + ".bias"] - P[bn + ".running_mean"] * sc, stride, pad)
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    return nm.r(y)
+
+
 def _linear(P, name, x):
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _linear_mm(P, name, x, nm):
+    """nn.Linear on the MFMA path: in bf16 mode the weight is a bf16 copy and x must already hold bf16 values; fp32 bias,
+    fp32 accumulation, fp32 result."""
+    if not nm.bf16:
+        return _linear(P, name, x)
+    return F.linear(x, bf16_round(P[name + ".weight"]), P.get(name + ".bias"))
 
 
 def _ln(P, name, x, eps):
@@ -59,24 +126,22 @@ def _ln(P, name, x, eps):
 # ----------------------------------------------------------------------------------------------
 # HRNet (pose_hrnet.py)
 # ----------------------------------------------------------------------------------------------
-def _basic_block(P, pre, x):
+def _basic_block(P, pre, x, nm=FP32):
     """pose_hrnet.py:66-95 (never has a downsample inside HRNet stages: in==out, stride 1)."""
-    y = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x, 1, 1)))
-    y = _bn(P, pre + ".bn2", _conv(P, pre + ".conv2", y, 1, 1))
-    return F.relu(y + x)
+    y = _cbr(P, pre + ".conv1", pre + ".bn1", x, 1, 1, nm=nm)
+    return _cbr(P, pre + ".conv2", pre + ".bn2", y, 1, 1, res=x, nm=nm)
 
 
-def _bottleneck(P, pre, x):
+def _bottleneck(P, pre, x, nm=FP32):
     """pose_hrnet.py:98-136; downsample (1x1 conv + BN) exists iff its keys are present."""
-    y = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x)))
-    y = F.relu(_bn(P, pre + ".bn2", _conv(P, pre + ".conv2", y, 1, 1)))
-    y = _bn(P, pre + ".bn3", _conv(P, pre + ".conv3", y))
+    y = _cbr(P, pre + ".conv1", pre + ".bn1", x, nm=nm)
+    y = _cbr(P, pre + ".conv2", pre + ".bn2", y, 1, 1, nm=nm)
     if (pre + ".downsample.0.weight") in P:
-        x = _bn(P, pre + ".downsample.1", _conv(P, pre + ".downsample.0", x))
-    return F.relu(y + x)
+        x = _cbr(P, pre + ".downsample.0", pre + ".downsample.1", x, relu=False, nm=nm)
+    return _cbr(P, pre + ".conv3", pre + ".bn3", y, res=x, nm=nm)
 
 
-def _hr_module(P, pre, xs, n_out):
+def _hr_module(P, pre, xs, n_out, nm=FP32):
     """HighResolutionModule.forward, pose_hrnet.py:285-303.
 
     Returns (fused outputs, branch outputs).  The reference mutates its input list in place
@@ -87,7 +152,7 @@ def _hr_module(P, pre, xs, n_out):
     for i in range(nb):
         y = xs[i]
         for k in range(4):                                   # NUM_BLOCKS = 4 everywhere (cfg.py:44,53,62)
-            y = _basic_block(P, f"{pre}.branches.{i}.{k}", y)
+            y = _basic_block(P, f"{pre}.branches.{i}.{k}", y, nm)
         br.append(y)
     outs = []
     for i in range(n_out):
@@ -97,45 +162,44 @@ def _hr_module(P, pre, xs, n_out):
                 t = br[j]
             elif j > i:                                      # 1x1 conv + BN + nearest upsample (:238-245)
                 fp = f"{pre}.fuse_layers.{i}.{j}"
-                t = _bn(P, fp + ".1", _conv(P, fp + ".0", br[j]))
+                t = _cbr(P, fp + ".0", fp + ".1", br[j], relu=False, nm=nm)
                 t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
             else:                                            # chain of 3x3 s2 convs (:249-275)
                 t = br[j]
                 for k in range(i - j):
                     fp = f"{pre}.fuse_layers.{i}.{j}.{k}"
-                    t = _bn(P, fp + ".1", _conv(P, fp + ".0", t, 2, 1))
-                    if k != i - j - 1:
-                        t = F.relu(t)
+                    t = _cbr(P, fp + ".0", fp + ".1", t, 2, 1, relu=(k != i - j - 1), nm=nm)
             acc = t if acc is None else acc + t              # summation order j = 0,1,2,.. (:294-300)
-        outs.append(F.relu(acc))
+        outs.append(nm.r(F.relu(acc)))                       # (bf16 mode: fuse_sum_kernel adds in fp32, stores bf16)
     return outs, br
 
 
-def hrnet_forward(P, x, pre="backbone"):
+def hrnet_forward(P, x, pre="backbone", nm=FP32):
     """PoseHighResolutionNet.forward, pose_hrnet.py:464-501.  x: [B,3,H,W] -> 4 maps (NCHW)."""
-    x = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x, 2, 1)))
-    x = F.relu(_bn(P, pre + ".bn2", _conv(P, pre + ".conv2", x, 2, 1)))
+    x = nm.r(x)                                              # (bf16 mode: the stem kernel rounds the image into LDS)
+    x = _cbr(P, pre + ".conv1", pre + ".bn1", x, 2, 1, nm=nm)
+    x = _cbr(P, pre + ".conv2", pre + ".bn2", x, 2, 1, nm=nm)
     for k in range(4):
-        x = _bottleneck(P, f"{pre}.layer1.{k}", x)
+        x = _bottleneck(P, f"{pre}.layer1.{k}", x, nm)
 
     def trans(name, src):
         # _make_transition_layer pose_hrnet.py:377-411: either one 3x3 s1 conv (same branch,
         # channel change) or a 3x3 s2 conv from the last branch (new branch); +BN+ReLU.
         if (name + ".0.weight") in P:
-            return F.relu(_bn(P, name + ".1", _conv(P, name + ".0", src, 1, 1)))
-        return F.relu(_bn(P, name + ".0.1", _conv(P, name + ".0.0", src, 2, 1)))
+            return _cbr(P, name + ".0", name + ".1", src, 1, 1, nm=nm)
+        return _cbr(P, name + ".0.0", name + ".0.1", src, 2, 1, nm=nm)
 
     xs = [trans(pre + ".transition1.0", x), trans(pre + ".transition1.1", x)]
-    ys, _ = _hr_module(P, pre + ".stage2.0", xs, 2)
+    ys, _ = _hr_module(P, pre + ".stage2.0", xs, 2, nm)
 
     xs = [ys[0], ys[1], trans(pre + ".transition2.2", ys[-1])]
     for m in range(4):
-        ys, _ = _hr_module(P, f"{pre}.stage3.{m}", xs if m == 0 else ys, 3)
+        ys, _ = _hr_module(P, f"{pre}.stage3.{m}", xs if m == 0 else ys, 3, nm)
 
     xs = [ys[0], ys[1], ys[2], trans(pre + ".transition3.3", ys[-1])]
-    ys, br0 = _hr_module(P, pre + ".stage4.0", xs, 4)
-    ys, _ = _hr_module(P, pre + ".stage4.1", ys, 4)
-    ys, _ = _hr_module(P, pre + ".stage4.2", ys, 1)
+    ys, br0 = _hr_module(P, pre + ".stage4.0", xs, 4, nm)
+    ys, _ = _hr_module(P, pre + ".stage4.1", ys, 4, nm)
+    ys, _ = _hr_module(P, pre + ".stage4.2", ys, 1, nm)
     # :501 returns [y_list[0], x_list[1], x_list[2], x_list[3]]; x_list was mutated in place by
     # stage4[0] (:289-290), so entries 1..3 are stage4[0]'s *branch* outputs (SURVEY.md fact 2).
     return [ys[0], br0[1], br0[2], br0[3]]
@@ -144,42 +208,44 @@ def hrnet_forward(P, x, pre="backbone"):
 # ----------------------------------------------------------------------------------------------
 # CPN-50 (networks/resnet.py, globalNet.py, refineNet.py)
 # ----------------------------------------------------------------------------------------------
-def _res_bottleneck(P, pre, x, stride):
+def _res_bottleneck(P, pre, x, stride, nm=FP32):
     """networks/resnet.py:58-93 (expansion 4, stride on the 3x3)."""
-    y = F.relu(_bn(P, pre + ".bn1", _conv(P, pre + ".conv1", x)))
-    y = F.relu(_bn(P, pre + ".bn2", _conv(P, pre + ".conv2", y, stride, 1)))
-    y = _bn(P, pre + ".bn3", _conv(P, pre + ".conv3", y))
+    y = _cbr(P, pre + ".conv1", pre + ".bn1", x, nm=nm)
+    y = _cbr(P, pre + ".conv2", pre + ".bn2", y, stride, 1, nm=nm)
     if (pre + ".downsample.0.weight") in P:
-        x = _bn(P, pre + ".downsample.1", _conv(P, pre + ".downsample.0", x, stride))
-    return F.relu(y + x)
+        x = _cbr(P, pre + ".downsample.0", pre + ".downsample.1", x, stride, relu=False, nm=nm)
+    return _cbr(P, pre + ".conv3", pre + ".bn3", y, res=x, nm=nm)
 
 
-def cpn_forward(P, x, pre="backbone", out_hw=(64, 48)):
+def cpn_forward(P, x, pre="backbone", out_hw=(64, 48), nm=FP32):
     """CPN.forward networks/network.py:16-22 -> 4 maps [B,256,64,48].
 
     The `predict` heads of globalNet (globalNet.py:71) and refineNet.final_predict are computed and
     discarded / never called by the reference; they have no effect on the outputs and are skipped.
     """
     r = pre + ".resnet"
-    x = F.relu(_bn(P, r + ".bn1", _conv(P, r + ".conv1", x, 2, 3)))          # resnet.py:137-139
-    x = F.max_pool2d(x, 3, 2, 1)                                             # :140
+    x = nm.r(x)
+    x = _cbr(P, r + ".conv1", r + ".bn1", x, 2, 3, nm=nm)                    # resnet.py:137-139
+    x = F.max_pool2d(x, 3, 2, 1)                                             # :140 (exact on bf16 values)
     feats = []
     for li, (n, s) in enumerate(zip([3, 4, 6, 3], [1, 2, 2, 2])):            # :141-144, resnet50
         for k in range(n):
-            x = _res_bottleneck(P, f"{r}.layer{li + 1}.{k}", x, s if k == 0 else 1)
+            x = _res_bottleneck(P, f"{r}.layer{li + 1}.{k}", x, s if k == 0 else 1, nm)
         feats.append(x)
     res_out = feats[::-1]                                                    # [x4,x3,x2,x1] :147
 
     g = pre + ".global_net"
-    fms, up = [], None
+    fms, u = [], None
     for i in range(4):                                                       # globalNet.py:61-83
-        f = F.relu(_bn(P, f"{g}.laterals.{i}.1", _conv(P, f"{g}.laterals.{i}.0", res_out[i])))
+        f = _cbr(P, f"{g}.laterals.{i}.0", f"{g}.laterals.{i}.1", res_out[i], nm=nm)
         if i > 0:
-            f = f + up
+            # feature_i = lateral_i + BN(conv1x1(bilinear x2(feature_{i-1})))   (:66-70; the engine adds the lateral in the
+            # upsample conv's epilogue: one rounding in bf16 mode)
+            up = _cbr(P, f"{g}.upsamples.{i - 1}.1", f"{g}.upsamples.{i - 1}.2", u, relu=False, nm=_NOROUND if nm.bf16 else FP32)
+            f = nm.r(f + up)
         fms.append(f)
         if i != 3:
-            u = F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True)
-            up = _bn(P, f"{g}.upsamples.{i}.2", _conv(P, f"{g}.upsamples.{i}.1", u))
+            u = nm.r(F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True))
 
     rn = pre + ".refine_net"
     outs = []
@@ -187,11 +253,11 @@ def cpn_forward(P, x, pre="backbone", out_hw=(64, 48)):
         y = fms[i]
         for k in range(3 - i):
             bp = f"{rn}.cascade.{i}.{k}"
-            t = F.relu(_bn(P, bp + ".bn1", _conv(P, bp + ".conv1", y)))
-            t = F.relu(_bn(P, bp + ".bn2", _conv(P, bp + ".conv2", t, 1, 1)))
-            t = _bn(P, bp + ".bn3", _conv(P, bp + ".conv3", t))
-            y = F.relu(t + _bn(P, bp + ".downsample.1", _conv(P, bp + ".downsample.0", y)))
-        outs.append(F.interpolate(y, size=out_hw, mode="bilinear", align_corners=True))
+            t = _cbr(P, bp + ".conv1", bp + ".bn1", y, nm=nm)
+            t = _cbr(P, bp + ".conv2", bp + ".bn2", t, 1, 1, nm=nm)
+            d = _cbr(P, bp + ".downsample.0", bp + ".downsample.1", y, relu=False, nm=nm)
+            y = _cbr(P, bp + ".conv3", bp + ".bn3", t, res=d, nm=nm)
+        outs.append(nm.r(F.interpolate(y, size=out_hw, mode="bilinear", align_corners=True)))
     return outs
 
 
@@ -249,28 +315,33 @@ def grid_sample_explicit(feat, grid, padding):
 # ----------------------------------------------------------------------------------------------
 # lifting transformer (pose_dformer.py)
 # ----------------------------------------------------------------------------------------------
-def _mlp(P, pre, x):
-    """Mlp.forward pose_dformer.py:24-31 (exact erf GELU, dropout p=0)."""
-    return _linear(P, pre + ".fc2", F.gelu(_linear(P, pre + ".fc1", x)))
+def _mlp(P, pre, x, nm=FP32):
+    """Mlp.forward pose_dformer.py:24-31 (exact erf GELU, dropout p=0).  bf16 mode: x holds bf16 rows (the LayerNorm kernel
+    wrote them), fc1's epilogue stores GELU(.) as bf16, fc2 accumulates in fp32."""
+    return _linear_mm(P, pre + ".fc2", nm.r(F.gelu(_linear_mm(P, pre + ".fc1", x, nm))), nm)
 
 
-def _attn_block(P, pre, x, heads, keep=None):
+def _attn_block(P, pre, x, heads, keep=None, nm=FP32):
     """Block.forward pose_dformer.py:76-79 with Attention.forward :46-59 inlined; LN eps 1e-6 (:166).
-    keep: optional (mask1, mask2) per-sample DropPath multipliers (training parity only)."""
+    keep: optional (mask1, mask2) per-sample DropPath multipliers (training parity only).
+    bf16 mode: LayerNorm rows and the attention output are stored bf16 (operands of qkv / proj / fc1), qkv itself, the
+    softmax and the residual stream are fp32."""
     B, N, C = x.shape
     d = C // heads
-    h = _ln(P, pre + ".norm1", x, 1e-6)
-    qkv = _linear(P, pre + ".attn.qkv", h).reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    h = nm.r(_ln(P, pre + ".norm1", x, 1e-6))
+    qkv = _linear_mm(P, pre + ".attn.qkv", h, nm).reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     a = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(dim=-1)
-    h = _linear(P, pre + ".attn.proj", (a @ v).transpose(1, 2).reshape(B, N, C))
+    h = _linear_mm(P, pre + ".attn.proj", nm.r((a @ v).transpose(1, 2).reshape(B, N, C)), nm)
     x = x + (h if keep is None else h * keep[0])
-    h = _mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", x, 1e-6))
+    h = _mlp(P, pre + ".mlp", nm.r(_ln(P, pre + ".norm2", x, 1e-6)), nm)
     return x + (h if keep is None else h * keep[1])
 
 
-def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False, keep=None):
-    """DeformableBlock.forward pose_dformer.py:115-141; LN eps 1e-5 (default nn.LayerNorm, :84)."""
+def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False, keep=None, nm=FP32):
+    """DeformableBlock.forward pose_dformer.py:115-141; LN eps 1e-5 (default nn.LayerNorm, :84).
+    bf16 mode: the attention half (query LayerNorm, logits / offsets, sampling of the bf16-valued maps, embed_proj) is fp32
+    in the engine (ctx_attn_kernel); only the MLP half runs bf16 operands."""
     x0, xr = x[:, :1], x[:, 1:]
     b, l, p, c = xr.shape
     q = _ln(P, pre + ".norm1", xr + x0, 1e-5)
@@ -289,7 +360,7 @@ def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False,
     s = torch.stack(sampled, dim=1)                                         # b, l, p, hs, c/heads
     s = (w * s.view(b, l, p, heads, samples, -1)).sum(dim=-2).view(b, l, p, -1)
     xr = xr + (s if keep is None else s * keep[0])
-    h = _mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", xr, 1e-5))
+    h = _mlp(P, pre + ".mlp", nm.r(_ln(P, pre + ".norm2", xr, 1e-5)), nm)
     xr = xr + (h if keep is None else h * keep[1])
     return torch.cat([x0, xr], dim=1), pos
 
@@ -311,13 +382,14 @@ def split_drop_masks(masks, B, J=17, levels=4):
 
 
 def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=False, taps=None,
-                   context_blocks=True, drop_masks=None):
+                   context_blocks=True, drop_masks=None, emulate_bf16=False):
     """PoseTransformer.forward pose_dformer.py:210-241.
 
     k2d [B,17,2], ref [B,17,2] (already normalised), feats: 4 NCHW maps -> [B,1,17,3].
     taps: optional dict that receives intermediates for stage-level parity tests.
     """
     b, p, _ = k2d.shape
+    nm = BF16 if emulate_bf16 else FP32
     keep = split_drop_masks(drop_masks, b, p, levels) if drop_masks is not None else None
     x = _linear(P, pre + ".coord_embed", k2d)                               # :214
     toks = []
@@ -335,7 +407,7 @@ def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=Fals
     if context_blocks:
         for i in range(levels):                                             # :228-229 (depth = levels, :169)
             x, pos = _deformable_block(P, f"{pre}.context_blocks.{i}", x, ref, feats, explicit=explicit,
-                                       keep=keep["ctx"][i] if keep else None)
+                                       keep=keep["ctx"][i] if keep else None, nm=nm)
             if taps is not None:
                 taps.setdefault("ctx_pos", []).append(pos)
         if taps is not None:
@@ -343,12 +415,12 @@ def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=Fals
     L = x.shape[1]
     x = x.permute(0, 2, 1, 3).reshape(b * p, L, -1)                          # 'b l p c -> (b p) l c' :231
     for i in range(levels):
-        x = _attn_block(P, f"{pre}.res_blocks.{i}", x, 8, keep=keep["res"][i] if keep else None)   # :233-234
+        x = _attn_block(P, f"{pre}.res_blocks.{i}", x, 8, keep=keep["res"][i] if keep else None, nm=nm)   # :233-234
     x = x.reshape(b, p, -1)                                                 # '(b p) l c -> b p (l c)' :235
     if taps is not None:
         taps["tokens_res"] = x
     for i in range(levels):
-        x = _attn_block(P, f"{pre}.joint_blocks.{i}", x, 8, keep=keep["joint"][i] if keep else None)   # :237-238
+        x = _attn_block(P, f"{pre}.joint_blocks.{i}", x, 8, keep=keep["joint"][i] if keep else None, nm=nm)   # :237-238
     if taps is not None:
         taps["tokens_joint"] = x
     x = _linear(P, pre + ".head.1", _ln(P, pre + ".head.0", x, 1e-5))       # :240
@@ -365,16 +437,20 @@ def normalise_crop_keypoints_(kcrop):
     return kcrop
 
 
-def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit=False, taps=None, drop_masks=None):
+def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit=False, taps=None, drop_masks=None,
+                  emulate_bf16=False):
     """CA_PF.forward conpose.py:30-42.  images [B,H,W,3] NHWC fp32; mutates kcrop in place.
-    drop_masks: training-mode DropPath multipliers (see split_drop_masks), None = eval / no drop."""
+    drop_masks: training-mode DropPath multipliers (see split_drop_masks), None = eval / no drop.
+    emulate_bf16: the engine's compute_dtype = bf16 storage roundings (module docstring); False = the reference's fp32."""
+    nm = BF16 if emulate_bf16 else FP32
     x = images.permute(0, 3, 1, 2).contiguous()
     ref = normalise_crop_keypoints_(kcrop)
-    feats = cpn_forward(P, x) if backbone == "cpn" else hrnet_forward(P, x)
+    feats = cpn_forward(P, x, nm=nm) if backbone == "cpn" else hrnet_forward(P, x, nm=nm)
     if taps is not None:
         taps["ref"] = ref.clone()
         taps["features"] = feats
-    return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps, drop_masks=drop_masks)
+    return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps, drop_masks=drop_masks,
+                          emulate_bf16=emulate_bf16)
 
 
 def mpjpe(pred, gt):

@@ -201,7 +201,7 @@ def test_integration_stub_struct_matches_the_header_and_the_binding():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     stub = doc[doc.index("class capf_config(ctypes.Structure)"):doc.index("class CA_PF(nn.Module):")]
     assert re.findall(r'\("(\w+)", ctypes\.c_int32', stub) == bound
-    assert ctypes.sizeof(CapfConfig) == 4 * 22
+    assert ctypes.sizeof(CapfConfig) == 4 * 23
     ctor = re.search(r"c = capf_config\(([^\n]*)\)\s+#", doc).group(1)
     assert len(re.sub(r"\([^)]*\)", "T", ctor).split(",")) == len(bound)
 
@@ -231,3 +231,64 @@ def test_hot_kernels_do_not_spill_registers():
     with concurrent.futures.ThreadPoolExecutor(4) as ex:
         bad = sum(ex.map(spills, ["igemm_bf16", "igemm_f32", "igemm_f32_pw", "igemm_wino"]), [])
     assert not bad, f"kernels with register spills: {bad}"
+
+
+def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
+    """capf_config::plan_flags is the ONLY way to take a kernel family out of the plan: the A/B environment switches of
+    earlier rounds are compiled out of the product library (kernels.h diag_env), unknown flag bits are rejected."""
+    from capf import Engine
+    from capf.lib import PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
+    from mvn.models import _native
+
+    def kernels(flags, embed=128):
+        cfg = _cfg("hrnet_32")
+        cfg.model.poseformer.embed_dim_ratio = embed
+        eng = Engine(_native.make_capf_config(cfg, 256, 256, plan_flags=flags), device=None)
+        return [(n, k) for n, k, _ in eng.op_table(64)]
+
+    base = kernels(0)
+    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_wino") for _, k in base)
+    for var in ("CAPF_LIFTER_FUSED", "CAPF_WINO", "CAPF_BF16_RH", "CAPF_WINO_F43"):
+        monkeypatch.setenv(var, "0")
+    assert kernels(0) == base                                               # the environment does not reach the product plan
+    unfused = kernels(PLAN_NO_FUSED_LIFTER)
+    assert not any(k in ("ctx_attn", "embed") for _, k in unfused) and any(k == "deform_sample" for _, k in unfused)
+    assert not any(k.startswith("igemm_wino") for _, k in kernels(PLAN_NO_WINOGRAD))
+    with pytest.raises(CapfError):
+        kernels(1 << 10)
+    # embed_dim_ratio beyond the fused kernels' register / LDS budget: the plan falls back to one kernel per op
+    wide = kernels(0, embed=288)
+    assert not any(k in ("ctx_attn", "embed") for _, k in wide) and any(k == "deform_sample" for _, k in wide)
+
+
+def test_executed_flops_of_winograd_ops_are_half_or_two_thirds_of_the_algorithmic_count():
+    from capf import Engine
+    from mvn.models import _native
+    eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
+    table, ex = eng.op_table(64), eng.op_executed_flops(64)
+    seen = set()
+    for (name, kern, alg), e in zip(table, ex):
+        if kern.startswith("igemm_wino"):
+            r = e / alg
+            assert abs(r - 0.5) < 1e-9 or abs(r - 2.0 / 3.0) < 1e-9, (name, r)
+            seen.add(round(r, 3))
+        elif kern.startswith("igemm") and alg > 0:
+            assert 1.0 - 1e-9 <= e / alg <= 1.2, (name, kern, e / alg)       # K padded to the chunk width only
+    assert 0.5 in seen
+    # below the Winograd batch threshold the same ops run the direct kernel: executed == algorithmic
+    t1, e1 = eng.op_table(1), eng.op_executed_flops(1)
+    assert all(abs(e / a - 1.0) < 0.2 for (n, k, a), e in zip(t1, e1) if k.startswith("igemm") and a > 0)
+
+
+def test_sync_batchnorm_conversion_keeps_the_reference_state_dict():
+    """train.py:317-318 on the host mirror (CPU part; the GPU box checks that the engine binds the converted tree)."""
+    import contextlib, io
+    import torch
+    from mvn.models.conpose import CA_PF
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "schema_hrnet_32.json")))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CA_PF(_cfg("hrnet_32"))
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == want
+    assert sum(isinstance(x, torch.nn.SyncBatchNorm) for x in m.modules()) == 292
+    assert not any(p.requires_grad for p in m.backbone.parameters())

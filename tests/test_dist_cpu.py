@@ -138,6 +138,11 @@ def test_bench_self_spawns_two_ranks_dry_run():
     assert j["n_gpus"] == 2 and j["dry_run"] and j["config"]["frames_per_step"] == 1024 and j["scaling"] == "weak"
     assert j["ms_per_step"] >= 4.0            # max over ranks: rank 1 sleeps 4 ms per step
     assert j["config"]["workload"].startswith("configs[3]: TRAINING")
+    # evidence a driver-side SCALE record can be checked against: the backend that ran, how many ranks a collective on it
+    # saw, and every rank's own rate (the GPU path emits the same keys, measured through the data-parallel backend)
+    d = j["distributed"]
+    assert d["backend"] == "gloo" and d["ranks_seen"] == 2 and len(d["per_rank_frames_per_s"]) == 2
+    assert d["per_rank_frames_per_s"][0] > d["per_rank_frames_per_s"][1] > 0     # rank 1 sleeps twice as long
 
 
 def test_bench_labels_follow_the_arguments():

@@ -344,10 +344,10 @@ def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
         assert torch.equal(a, b)
 
 
-def test_row_halo_engine_path_agrees_with_the_direct_bf16_kernels(monkeypatch):
+def test_row_halo_engine_path_agrees_with_the_direct_bf16_kernels():
     """Batch 48 HRNet-32 bf16: the grouped branch launches have >= 2048 tiles, so the engine runs the row-halo kernel
     (capf_forward_profile_variants reports igemm_bf16_group_rh_kernel for them); a second engine planned with
-    CAPF_BF16_RH=0 runs the direct kernels.  Different K order and bias placement, same bf16 operands: the four context
+    plan_flags = CAPF_PLAN_NO_ROW_HALO runs the direct kernels.  Different K order and bias placement, same bf16 operands: the four context
     maps agree to the noise two bf16 evaluations with different summation orders accumulate over ~50 layers (measured 5-8e-3,
     the same size as either run's distance from the fp32 oracle)."""
     import copy, contextlib, io
@@ -359,10 +359,10 @@ def test_row_halo_engine_path_agrees_with_the_direct_bf16_kernels(monkeypatch):
     img, k2d, kc = synth.synth_inputs(48, 256, 256, seed=16)
     img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
     maps, variants = [], []
-    for rh in ("1", "0"):
-        monkeypatch.setenv("CAPF_BF16_RH", rh)
+    from capf.lib import PLAN_NO_ROW_HALO
+    for flags in (0, PLAN_NO_ROW_HALO):
         with contextlib.redirect_stdout(io.StringIO()):
-            model = CA_PF(cfg, compute_dtype="bf16").eval()
+            model = CA_PF(cfg, compute_dtype="bf16", plan_flags=flags).eval()
         synth.load_synthetic(model, seed=4, bn_mode="random")
         model = model.cuda()
         with torch.no_grad():

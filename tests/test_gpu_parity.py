@@ -93,49 +93,6 @@ def test_batch_independence_and_determinism():
     assert (a[2:3] - one).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("backbone,B,H,W", [("hrnet_32", 2, 256, 256), ("hrnet_48", 2, 256, 256), ("cpn", 1, 384, 288)])
-def test_bf16_backbone_path_tracks_the_fp32_oracle(backbone, B, H, W):
-    """compute_dtype='bf16' (BASELINE configs[2]/[4]): bf16 MFMA convolutions with bf16 activations, and the lifter's
-    qkv / proj / fc1 / fc2 projections on bf16 operands (fp32 accumulation; LayerNorm, softmax, samplers and the
-    residual stream stay fp32).  bf16 carries 8 bits of mantissa: the context maps agree with the fp32 oracle to
-    < 1e-2 relative and the 17x3 joints to < 1e-2 absolute (metres) — reported, and bounded at 2x the measurement."""
-    import copy, contextlib, io
-    from capf import synth
-    from mvn.models.conpose import CA_PF
-    from mvn.utils.cfg import backbone_preset, config
-    cfg = backbone_preset(copy.deepcopy(config), backbone)
-    cfg.model.backbone.fix_weights = True
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg, compute_dtype="bf16").eval()
-    sd = synth.load_synthetic(model, seed=31, bn_mode="random")
-    model = model.cuda()
-    img, k2d, kc = synth.synth_inputs(B, H, W, seed=32)
-    taps = {}
-    with torch.no_grad():
-        want = oracle.ca_pf_forward(sd, img, k2d, kc.clone(), backbone=backbone, taps=taps)
-        got = model(img.cuda(), k2d.cuda(), kc.cuda()).cpu()
-    eng = model.engine_for(img.cuda())
-    for l in range(4):
-        f = eng.tensor(f"feat{l}").float().cpu().permute(0, 3, 1, 2)
-        ref = taps["features"][l]
-        rel = (f - ref).norm().item() / ref.norm().item()
-        print(f"{backbone} feat{l}: relative L2 error {rel:.3e}")
-        assert rel < BF16_MAP_REL[backbone]
-    err = (got - want).abs().max().item()
-    mpj = (got - want).norm(dim=-1).mean().item()
-    print(f"{backbone} bf16: max|joint delta| {err:.3e}, mean joint distance {mpj:.3e}")
-    assert err < BF16_JOINT_MAX[backbone] and mpj < BF16_JOINT_MEAN[backbone]
-
-
-# bounds = 2x what this build measures on the MI355X for these seeds (printed by the test); bf16 operands with fp32
-# accumulation through ~300 conv layers against the fp32 oracle
-# measured (maps rel L2 / joints max / joints mean): hrnet_32 7.8e-3 / 7.4e-3 / 4.2e-3, hrnet_48 7.7e-3 / 8.3e-3 / 4.1e-3,
-# cpn 2.9e-3 / 9.3e-3 / 7.4e-3 (with the lifter's projections on bf16 operands as well)
-BF16_MAP_REL = {"hrnet_32": 1.6e-2, "hrnet_48": 1.6e-2, "cpn": 0.6e-2}
-BF16_JOINT_MAX = {"hrnet_32": 1.5e-2, "hrnet_48": 1.7e-2, "cpn": 1.9e-2}
-BF16_JOINT_MEAN = {"hrnet_32": 8.5e-3, "hrnet_48": 8.5e-3, "cpn": 1.5e-2}
-
-
 def test_mpi_variant_matches_reference_golden():
     """N4: model.conpose.VolumetricTriangulationNet (context_blocks = 0) vs the sibling reference app."""
     from test_oracle_golden import _mpi_model

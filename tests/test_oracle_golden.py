@@ -157,3 +157,28 @@ def test_oracle_droppath_training_step_matches_reference():
     for k in keys:
         want = g["dp_grad:" + k]
         assert np.abs(P[k].grad.numpy() - want).max() <= 1e-5 * max(1e-6, np.abs(want).max()) + 1e-9, k
+
+
+def test_bf16_emulation_rounds_where_the_engine_stores_bf16_and_nowhere_else():
+    """oracle.ca_pf_forward(..., emulate_bf16=True): (a) every context map holds bf16-representable values; (b) the result
+    moves away from the fp32 path by a bf16-sized amount (1e-4 .. 3e-2 m), not by fp32 roundoff and not by a blunder;
+    (c) the fp32 path is untouched by the refactor (the golden tests above pin it to the reference at 0.0)."""
+    import torch
+    import capf_oracle as oracle
+    from conftest import make_model
+    from capf import synth
+    for backbone, H, W in (("hrnet_32", 128, 96), ("cpn", 128, 96)):
+        model, sd = make_model(backbone, wseed=61)
+        img, k2d, kc = synth.synth_inputs(2, H, W, seed=62, crop_range=(W, H))
+        te, tf = {}, {}
+        with torch.no_grad():
+            e = oracle.ca_pf_forward(sd, img, k2d, kc.clone(), backbone=backbone, taps=te, emulate_bf16=True)
+            f = oracle.ca_pf_forward(sd, img, k2d, kc.clone(), backbone=backbone, taps=tf)
+        for l in range(4):
+            m = te["features"][l]
+            assert torch.equal(m, oracle.bf16_round(m))
+            assert not torch.equal(tf["features"][l], oracle.bf16_round(tf["features"][l]))
+            rel = ((m - tf["features"][l]).norm() / tf["features"][l].norm()).item()
+            assert 1e-4 < rel < 3e-2, (backbone, l, rel)
+        d = (e - f).abs().max().item()
+        assert 1e-5 < d < 3e-2, (backbone, d)
