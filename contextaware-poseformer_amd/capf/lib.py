@@ -18,6 +18,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_op_conv_bf16_group", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
     "capf_op_bilinear_corners", "capf_mpjpe_nd", "capf_op_executed_flops",
+    "capf_forward_prefix", "capf_op_describe", "capf_op_tensor",
 ]
 
 
@@ -33,6 +34,13 @@ class CapfConfig(ctypes.Structure):
         ("compute_dtype", c_int32), ("max_batch", c_int32), ("height", c_int32), ("width", c_int32),
         ("training", c_int32), ("plan_flags", c_int32),
     ]
+
+
+class OpDesc(ctypes.Structure):
+    """mirrors include/capf.h :: capf_op_desc"""
+    _fields_ = [(k, c_int32) for k in ("kind", "backbone", "conv", "Cin", "H", "W", "Cout", "Ho", "Wo", "ks", "stride", "pad", "act",
+                                       "in_dtype", "out_dtype", "mfma_bf16", "n_in")] + [("shift", c_int32 * 4)] + \
+               [(k, c_int32) for k in ("relu", "p_weight", "p_bn_weight", "has_residual", "checkpoint")]
 
 
 _lib = None
@@ -78,6 +86,9 @@ def load_library():
     lib.capf_op_info.argtypes = [H, c_int, c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double)]
     lib.capf_op_bytes.argtypes = [H, c_int, c_int, POINTER(c_double)]
     lib.capf_op_executed_flops.argtypes = [H, c_int, c_int, POINTER(c_double)]
+    lib.capf_forward_prefix.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]
+    lib.capf_op_describe.argtypes = [H, c_int, POINTER(OpDesc)]
+    lib.capf_op_tensor.argtypes = [H, c_int, c_int, POINTER(c_void_p)]
     lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          POINTER(c_float), c_int]
     lib.capf_forward_profile_launches.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -299,6 +310,37 @@ class Engine:
             self._check(self.lib.capf_op_executed_flops(self.h, i, batch, byref(f)), "op_executed_flops")
             out.append(f.value)
         return out
+
+    # ---- layer-wise parity aids (capf_forward_prefix / capf_op_describe / capf_op_tensor)
+    def forward_prefix(self, images, n_ops, stream, k2d=None, kcrop=None, out=None):
+        B = images.shape[0]
+        self.ensure_workspace(B)
+        self._prefix_images = images
+        P = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+        self._check(self.lib.capf_forward_prefix(self.h, c_void_p(stream), P(images), P(k2d), P(kcrop), B, P(out), int(n_ops)),
+                    "forward_prefix")
+
+    def op_describe(self, index):
+        d = OpDesc()
+        self._check(self.lib.capf_op_describe(self.h, index, byref(d)), "op_describe")
+        return d
+
+    def op_tensor(self, index, slot, shape, dtype_code):
+        """View (no copy) of one operand of op `index` after a forward_prefix: slot 0..3 inputs, 4 residual, 5 output;
+        shape = full [B, ...] shape, dtype_code 0 fp32 / 2 bf16."""
+        import torch
+        ptr = c_void_p()
+        self._check(self.lib.capf_op_tensor(self.h, index, slot, byref(ptr)), f"op_tensor({index}, {slot})")
+        n = 1
+        for v in shape:
+            n *= v
+        img = getattr(self, "_prefix_images", None)
+        if img is not None and ptr.value == img.data_ptr():
+            return img.view(*shape)
+        off = (ptr.value - self._ws.data_ptr()) // 4
+        if dtype_code == 2:
+            return self._ws[off:off + (n + 1) // 2].view(torch.bfloat16)[:n].view(*shape)
+        return self._ws[off:off + n].view(*shape)
 
     def forward_profile(self, images, k2d, kcrop, out, stream):
         """One forward with a HIP event pair around every launch (on `stream`); returns ms per op.

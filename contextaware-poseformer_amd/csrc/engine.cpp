@@ -973,6 +973,69 @@ int capf_op_schedule(const capf_handle* h, int index, int32_t* region, int32_t* 
     return CAPF_OK;
 }
 
+int capf_forward_prefix(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout, int batch,
+                        float* out, int n_ops) {
+    if (!h || !images_nhwc) return CAPF_ERR_INVALID;
+    Engine& e = h->e;
+    if (n_ops < 0 || n_ops > (int)e.ops.size()) return CAPF_ERR_INVALID;
+    if (n_ops > e.n_backbone_ops && (!k2d || !kcrop_inout || !out)) return CAPF_ERR_INVALID;
+    int rc = check_run(e, batch);
+    if (rc) return rc;
+    e.images = images_nhwc; e.k2d = k2d; e.kcrop = kcrop_inout; e.out = out;
+    e.last_batch = batch;
+    e.invalidate_train();
+    return e.run(static_cast<hipStream_t>(stream), batch, 0, n_ops);
+}
+
+int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
+    if (!h || !d || index < 0 || index >= (int)h->e.ops.size()) return CAPF_ERR_INVALID;
+    const Engine& e = h->e;
+    const capf::Op& op = e.ops[index];
+    memset(d, 0, sizeof(*d));
+    d->kind = op.kind == capf::OP_GEMM ? 0 : op.kind == capf::OP_FUSE ? 1 : op.kind == capf::OP_MAXPOOL ? 2
+              : op.kind == capf::OP_RESIZE ? 3 : -1;
+    if (op.kind == capf::OP_FUSE && op.i0 == 1) d->kind = -1;          // debug copy
+    d->backbone = index < e.n_backbone_ops;
+    d->p_weight = d->p_bn_weight = -1;
+    const int act_dt = e.bf16() ? 2 : 0;
+    d->in_dtype = d->out_dtype = (d->backbone ? act_dt : 0);
+    d->H = op.H; d->W = op.W; d->Ho = op.Ho; d->Wo = op.Wo;
+    if (op.kind == capf::OP_GEMM) {
+        const capf::Pack& pk = e.packs[op.pack];
+        d->conv = op.conv; d->Cin = op.conv ? op.Cin : op.K; d->Cout = op.N;
+        d->ks = op.ks; d->stride = op.stride; d->pad = op.pad; d->act = op.act;
+        d->has_residual = op.aux >= 0 || op.res_param >= 0;
+        d->mfma_bf16 = (op.bf16 || op.out_bf16) ? 1 : 0;
+        if (op.conv) {
+            d->in_dtype = op.in[0] == -2 ? 0 : (op.bf16 ? 2 : 0);
+            d->out_dtype = (op.bf16 || op.out_bf16) ? 2 : 0;
+            d->p_weight = pk.w[0]; d->p_bn_weight = pk.bn_g;
+        } else {
+            d->in_dtype = op.bf16 == 2 ? 2 : 0;
+            d->out_dtype = op.out_bf16 ? 2 : 0;
+            d->p_weight = pk.n_lin == 1 ? pk.w[0] : -1;
+        }
+    } else {
+        d->Cin = d->Cout = op.C;
+        d->n_in = op.n_in; d->relu = op.relu;
+        for (int i = 0; i < 4; ++i) d->shift[i] = op.shift[i];
+        if (op.kind == capf::OP_FUSE) { d->Ho = op.H; d->Wo = op.W; }
+    }
+    d->checkpoint = (op.region >= 0 ? e.regions[op.region].second : index) + 1;
+    return CAPF_OK;
+}
+
+int capf_op_tensor(const capf_handle* h, int index, int slot, const void** dev_ptr) {
+    if (!h || !dev_ptr || index < 0 || index >= (int)h->e.ops.size() || slot < 0 || slot > 5) return CAPF_ERR_INVALID;
+    const Engine& e = h->e;
+    const capf::Op& op = e.ops[index];
+    const int buf = slot < 4 ? op.in[slot] : slot == 4 ? op.aux : op.out;
+    if (buf == -2) { *dev_ptr = e.images; return CAPF_OK; }
+    if (buf < 0 || !e.ws || e.last_batch <= 0) return CAPF_ERR_INVALID;
+    *dev_ptr = e.bptr(buf, e.last_batch);
+    return CAPF_OK;
+}
+
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
                          int batch, float* out, float* op_ms, int n_ops) {
     if (!h || !images_nhwc || !k2d || !kcrop_inout || !out || !op_ms) return CAPF_ERR_INVALID;

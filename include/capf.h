@@ -350,6 +350,35 @@ int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes);
  *   -2 = the external image.  Lets host-side tests check that the schedule is a valid topological order. */
 int capf_op_schedule(const capf_handle* h, int index, int32_t* region, int32_t* level, int32_t* lane,
                      int32_t reads[5], int32_t writes[6]);
+/* ---- layer-wise ("teacher-forced") parity aids ---------------------------------------------------------------
+ * A deep bf16 network is chaotic at the rounding level: two correct implementations that differ only in fp32 summation
+ * order drift apart to the full bf16 noise floor after ~50 layers, so an end-to-end comparison cannot be tighter than that
+ * floor.  What CAN be tight is one op at a time on the engine's OWN inputs:
+ *   capf_forward_prefix : the product schedule (grouped launches and all) for the first n_ops ops only; k2d / kcrop_inout /
+ *                         out may be NULL while n_ops stays inside the backbone.
+ *   capf_op_describe    : geometry, operand types and parameter indices of op `index`, and `checkpoint` = the prefix
+ *                         length after which every tensor the op touched is still intact in the workspace (buffers are
+ *                         reused along the plan; a fork/join region keeps all of its buffers until its join).
+ *   capf_op_tensor      : device pointer of one operand of op `index` after such a prefix (slot 0..3 inputs, 4 residual,
+ *                         5 output; the external image for the stem's input).
+ * tests/test_gpu_layerwise.py recomputes every backbone op on the CPU from the engine's inputs and compares outputs.   */
+typedef struct capf_op_desc {
+    int32_t kind;              /* 0 conv / linear on the MFMA kernels, 1 fuse-sum, 2 max-pool 3x3 s2, 3 bilinear resize, -1 other */
+    int32_t backbone;          /* 1: the op belongs to the backbone plan */
+    int32_t conv;              /* kind 0: 1 = convolution (NHWC), 0 = rows-mode linear */
+    int32_t Cin, H, W, Cout, Ho, Wo, ks, stride, pad, act;   /* act: 0 none, 1 ReLU, 2 GELU */
+    int32_t in_dtype, out_dtype;                             /* capf_tensor convention: 0 fp32, 2 bf16 */
+    int32_t mfma_bf16;         /* operands are rounded to bf16 for the matrix pipe */
+    int32_t n_in, shift[4], relu;                            /* fuse-sum: inputs, log2 nearest-upsample factors, ReLU */
+    int32_t p_weight, p_bn_weight;                           /* capf_param_info indices of <conv>.weight and <bn>.weight; -1 */
+    int32_t has_residual;
+    int32_t checkpoint;
+} capf_op_desc;
+int capf_forward_prefix(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
+                        int batch, float* out, int n_ops);
+int capf_op_describe(const capf_handle* h, int index, capf_op_desc* desc);
+int capf_op_tensor(const capf_handle* h, int index, int slot, const void** dev_ptr);
+
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
                          float* kcrop_inout, int batch, float* out, float* op_ms, int n_ops);
 int capf_forward_profile_launches(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,

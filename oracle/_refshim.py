@@ -203,3 +203,50 @@ def build_reference_mpi(backbone="hrnet_32"):
         with contextlib.redirect_stdout(io.StringIO()):
             m = net(c)
     return m.eval(), c
+
+
+def run_reference_prefetcher(batch, backbone, is_train, flip_test, flip):
+    """ONE batch through the reference's own `data_prefetcher.preload` (ContextPose/mvn/datasets/utils.py:15-89) on CPU.
+    The class only runs on a GPU upstream (torch.cuda.Stream, .cuda()), and its package __init__ pulls the whole dataset
+    stack (cv2, h5py): the FILE is executed as a module of its own (importlib, no package __init__) with `cv2` stubbed (it is
+    imported, never called on this path) and the CUDA plumbing it touches replaced by CPU no-ops for the duration of the call:
+    torch.cuda.Stream / torch.cuda.stream / Tensor.cuda / torch.cuda.current_stream.  `flip` replaces the reference's
+    `random.random() <= 0.5` draw (:55).  Returns the four tensors `.next()` hands to one_epoch_full."""
+    import contextlib
+    import importlib.util
+    import random
+    import torch
+
+    class _Stream:
+        def wait_stream(self, other):
+            pass
+
+    class _Cv2Stub(types.ModuleType):          # OpenCV is absent here; the file only names cv2 constants as default arguments
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return 0
+
+    stubbed = "cv2" not in sys.modules
+    if stubbed:
+        sys.modules["cv2"] = _Cv2Stub("cv2")
+    saved = (torch.cuda.Stream, torch.cuda.stream, torch.Tensor.cuda, torch.cuda.current_stream, random.random)
+    try:
+        with reference_imports() as ri:
+            torch.cuda.Stream = lambda *a, **k: _Stream()
+            torch.cuda.stream = lambda s: contextlib.nullcontext()
+            torch.Tensor.cuda = lambda self, *a, **k: self
+            torch.cuda.current_stream = lambda *a, **k: _Stream()
+            random.random = lambda: 0.0 if flip else 1.0
+            spec = importlib.util.spec_from_file_location("reference_datasets_utils", REFERENCE_ROOT + "/mvn/datasets/utils.py")
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            ri.check("mvn.utils.img")
+            assert mod.__file__.startswith(REFERENCE_ROOT + "/")
+            pf = mod.data_prefetcher([[t.clone() for t in batch]], torch.device("cpu"), is_train, flip_test, backbone)
+            out = pf.next()
+    finally:
+        torch.cuda.Stream, torch.cuda.stream, torch.Tensor.cuda, torch.cuda.current_stream, random.random = saved
+        if stubbed:
+            del sys.modules["cv2"]
+    return out

@@ -464,19 +464,28 @@ def gelu_exact(x):
 
 
 # ----------------------------------------------------------------------------------------------
-# neighbours of the path.  The reference class needs a CUDA stream and cannot run in
-# the build container, so these are restated from ContextPose/mvn/datasets/utils.py:33-82 and train.py:170-181
-# and pinned by hand-computable vectors in tests/test_oracle_golden.py.
+# neighbours of the path: restated from ContextPose/mvn/datasets/utils.py:33-82 and
+# train.py:170-181.  Pinned twice: by tests/golden/prefetch.npz — outputs of the reference's OWN data_prefetcher class,
+# executed on CPU with its CUDA-stream plumbing stubbed (oracle/_refshim.run_reference_prefetcher) — and by the
+# hand-computable vectors in tests/test_oracle_golden.py.
 # ----------------------------------------------------------------------------------------------
 JOINTS_LEFT = [4, 5, 6, 11, 12, 13]      # datasets/utils.py:12
 JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]     # :13
 
 
-def prefetch_preprocess(images_u8, gt, k2d, kcrop, backbone="hrnet_32", is_train=False, flip=False, flip_test=False):
+def prefetch_preprocess(images_u8, gt, k2d, kcrop, backbone="hrnet_32", is_train=False, flip=False, flip_test=False,
+                        scalar_div="cuda"):
     """data_prefetcher.preload.  `flip` replaces the reference's `random.random() <= 0.5` draw (:55).
-    `images / 255.0` is written as a multiplication by the fp32 reciprocal: that is what ATen's CUDA kernel does
-    for a Python-scalar divisor, and the reference's prefetcher only runs on a GPU."""
-    images = torch.flip(images_u8, [-1]).float() * torch.tensor(1.0, dtype=torch.float32).div(255.0)      # :45,:47
+    scalar_div: how `images / 255.0` (:47) is evaluated.  "cuda" (default): multiplication by the fp32 reciprocal — what
+    ATen's CUDA kernel does for a Python-scalar divisor, and the reference's prefetcher only ever runs on a GPU; this is the
+    mode capf_preprocess is held to bit for bit.  "cpu": a true division, what the same line does when the reference class is
+    run on CPU — the mode that tests/golden/prefetch.npz (captured from the reference's own class, oracle/make_goldens.py)
+    pins bit for bit.  The two differ by at most one ulp of the quotient and in nothing else."""
+    images = torch.flip(images_u8, [-1]).float()                                                          # :45
+    if scalar_div == "cuda":
+        images = images * torch.tensor(1.0, dtype=torch.float32).div(255.0)                              # :47
+    else:
+        images = images / 255.0
     if backbone in ("hrnet_32", "hrnet_48"):
         mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
         images = (images - mean) / std                                                                  # :47-48

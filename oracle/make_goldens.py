@@ -164,6 +164,19 @@ def loss_case():
     return rec
 
 
+def prefetch_case():
+    """N1: the reference's own data_prefetcher.preload (datasets/utils.py:33-82), run on CPU through
+    _refshim.run_reference_prefetcher, on the seeded loader batch of golden_cases.prefetch_inputs in every mode."""
+    from golden_cases import PREFETCH_MODES, prefetch_inputs
+    rec = {}
+    for name, (backbone, is_train, flip_test, flip) in PREFETCH_MODES.items():
+        out = _refshim.run_reference_prefetcher(prefetch_inputs(), backbone, is_train, flip_test, flip)
+        for key, t in zip(("images", "gt", "k2d", "kcrop"), out):
+            assert t.dtype == torch.float32
+            rec[f"{name}:{key}"] = t.numpy().copy()
+    return rec
+
+
 def schemas():
     import json
     out = {}
@@ -197,7 +210,7 @@ def compare(name, rec, path):
 
 
 def main():
-    """python oracle/make_goldens.py [--check] [case ... | schema | losses]
+    """python oracle/make_goldens.py [--check] [case ... | schema | losses | prefetch]
     --check: regenerate in memory from the reference and compare with the committed fixtures (exit 1 on mismatch)."""
     import json
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -216,7 +229,7 @@ def main():
             else:
                 with open(path, "w") as f:
                     json.dump(sch, f, separators=(",", ":"))
-    todo = [(n, lambda n=n, c=c: run_case(n, c)) for n, c in CASES.items()] + [("losses", loss_case)]
+    todo = [(n, lambda n=n, c=c: run_case(n, c)) for n, c in CASES.items()] + [("losses", loss_case), ("prefetch", prefetch_case)]
     for name, fn in todo:
         if only and name not in only:
             continue

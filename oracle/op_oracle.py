@@ -1,0 +1,81 @@
+"""Single-op CPU restatements for the layer-wise ("teacher-forced") parity tests.
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE (same rules as capf_oracle.py: only tests/ may import it).
+
+Why it exists: a deep bf16 network is chaotic at the rounding level — two correct implementations that differ only in fp32
+summation order decorrelate to the full bf16 noise floor within a few dozen layers — so the end-to-end distance between the
+HIP path and ANY CPU evaluation (fp32 or bf16-emulating) cannot be bounded tighter than that floor.  One op at a time it can:
+each function here recomputes ONE op of the engine's plan (csrc/plan.cpp) from the operands the ENGINE itself produced
+(capf_op_tensor), with the same storage roundings (capf_oracle.Numerics), so the outputs agree to fp32 summation order — in
+bf16 storage: bit for bit except for the rare value whose fp32 pre-image straddles a rounding boundary (one bf16 ulp).
+The ops follow the reference's modules exactly as capf_oracle does:
+    conv + eval BatchNorm (+ residual) (+ ReLU)   pose_hrnet.py:66-136, 238-275, 321-327, 383-407; networks/resnet.py:58-93, 137-139;
+                                                  globalNet.py:29-45; refineNet.py:3-45
+    fuse sum (nearest upsample + add + ReLU)      pose_hrnet.py:294-301
+    max-pool 3x3 s2 p1                            networks/resnet.py:140
+    bilinear resize, align_corners=True           globalNet.py:40, refineNet.py:61
+"""
+import torch
+import torch.nn.functional as F
+
+import capf_oracle as oracle
+
+
+def _nchw(x):
+    return x.float().permute(0, 3, 1, 2).contiguous()
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def conv_bn_act(P, conv, bn, x_nhwc, residual_nhwc, ks, stride, pad, act, bf16):
+    """x / residual: the engine's own NHWC operands (fp32 or bf16 tensors) -> NHWC fp32 holding what the engine must store."""
+    nm = oracle.BF16 if bf16 else oracle.FP32
+    x = nm.r(_nchw(x_nhwc))                                  # (the stem rounds the fp32 image on its way into LDS)
+    res = _nchw(residual_nhwc) if residual_nhwc is not None else None
+    assert act in (0, 1)
+    y = oracle._cbr(P, conv, bn, x, stride, pad, relu=(act == 1), res=res, nm=nm)
+    return _nhwc(y)
+
+
+def fuse_sum(inputs_nhwc, shifts, relu, bf16):
+    nm = oracle.BF16 if bf16 else oracle.FP32
+    acc = None
+    for t, s in zip(inputs_nhwc, shifts):
+        t = _nchw(t)
+        if s:
+            t = F.interpolate(t, scale_factor=2 ** s, mode="nearest")
+        acc = t if acc is None else acc + t
+    if relu:
+        acc = F.relu(acc)
+    return _nhwc(nm.r(acc))
+
+
+def maxpool(x_nhwc):
+    return _nhwc(F.max_pool2d(_nchw(x_nhwc), 3, 2, 1))
+
+
+def resize(x_nhwc, Ho, Wo, bf16):
+    nm = oracle.BF16 if bf16 else oracle.FP32
+    return _nhwc(nm.r(F.interpolate(_nchw(x_nhwc), size=(Ho, Wo), mode="bilinear", align_corners=True)))
+
+
+def compare(got, want, bf16):
+    """-> dict(max_err, frac_inexact, ok).  bf16 storage: values must be identical or ADJACENT bf16 numbers (one rounding flip),
+    except where the fp32 pre-image is cancellation noise (|value| below 1e-4 of the tensor's mean magnitude); at most 3 % of a
+    tensor may be inexact.  fp32: 1e-4 of the tensor's largest magnitude (Winograd F(4,3) amplifies roundoff by its 1/24..8
+    transform constants: 1e-5..2.5e-5 per conv measured against PyTorch)."""
+    got, want = got.float(), want.float()
+    d = (got - want).abs()
+    scale = want.abs().max().clamp_min(1e-30)
+    if not bf16:
+        err = (d.max() / scale).item()
+        return {"max_err": err, "frac_inexact": (d > 0).float().mean().item(), "ok": err <= 1e-4}
+    mag = torch.maximum(got.abs(), want.abs())
+    ulp = torch.pow(2.0, torch.floor(torch.log2(mag.clamp_min(1e-30))) - 7)        # spacing of bf16 numbers at that magnitude
+    allowed = ulp + 1e-4 * want.abs().mean()
+    bad = (d > allowed)
+    frac = (d > 0).float().mean().item()
+    return {"max_err": (d / (mag + 1e-4 * want.abs().mean())).max().item(), "frac_inexact": frac,
+            "ok": (not bool(bad.any())) and frac <= 0.03}

@@ -1,44 +1,57 @@
-"""Shared by the bf16 GPU tests: per-stage attribution of a compute_dtype='bf16' run and the bounds it is held to."""
+"""Shared by the bf16 GPU tests: per-stage attribution of a compute_dtype='bf16' run, and what it is held to.
 
-# Parity bounds of the bf16 mode, against the bf16-EMULATING oracle (oracle.ca_pf_forward(..., emulate_bf16=True)): the HIP
-# path and the emulation round the same values at the same places, so they differ only through fp32 summation order and the
-# occasional bf16 rounding flip that order causes (one flip = 2^-9 relative on one activation).  The joints get the
-# north-star tolerance of the fp32 path (1e-3 m); maps 2e-3 relative L2 (a quarter of one bf16 ulp).  The distance to the
-# fp32 oracle is the mode's ROUNDING BUDGET: printed per stage and only sanity-capped (3e-2 m: 8 mantissa bits, ~300 layers).
-BF16_EMU_JOINTS = 1e-3
-BF16_EMU_MAPS = 2e-3
-BF16_BUDGET_CAP = 3e-2
+Three evaluations of the same frames are compared pairwise at every tap (context maps, token buffer after each block group,
+joints):  H = the HIP path,  E = the bf16-EMULATING oracle (capf_oracle.ca_pf_forward(emulate_bf16=True): the engine's
+storage roundings, CPU summation order),  F = the fp32 oracle (the reference's arithmetic).
+
+A deep bf16 network is chaotic at the rounding level: H and E round the same quantities at the same places and still end up
+as far from each other as either is from F — the first differing fp32 summation flips a few roundings, each flip perturbs
+hundreds of downstream sums by a fraction of a bf16 ulp, which flips more (measured on the MI355X: |H-E| ~ |H-F| ~ |E-F| at
+every stage).  So:
+  * the TIGHT parity statement for bf16 is layer-wise, on the engine's own operands: tests/test_gpu_layerwise.py;
+  * end to end, E supplies the yardstick that replaces round 2's "2x what this build measured": a correct bf16 evaluation
+    sits |E-F| away from the fp32 truth, and the HIP path may not sit further away than 1.5x that (+ 1e-3 m on the joints,
+    the fp32 tolerance) at any stage.  The bound is derived from the oracle, not from the thing being tested."""
+
+SLACK = 1.5            # |H-F| <= SLACK * |E-F| + floor
+FLOOR_JOINTS = 1e-3    # metres (north-star fp32 tolerance)
+FLOOR_MAPS = 1e-3      # relative L2
+FLOOR_TOKENS = 2e-2    # token buffers carry values of order 1..10
+BUDGET_CAP = 3e-2      # sanity cap on the joints' distance from fp32 (8 mantissa bits through ~300 layers)
 
 
 def bf16_stage_report(tag, eng, got, rows, taps_emu, want_emu, taps_f32, want_f32):
-    """eng: engine after a debug forward of the FULL batch; `rows`: indices of the frames the oracles ran (list) or None = all.
-    Every tap against (a) the bf16-emulating oracle (the parity bound) and (b) the fp32 oracle (the rounding budget).
-    Returns {stage: (err vs emulation, err vs fp32)}; maps are relative L2, tokens / joints max-abs."""
-    import torch
+    """eng: engine after a debug forward of the FULL batch; rows: indices of the frames the oracles ran, or None = all.
+    Returns {stage: (|H-E|, |H-F|, |E-F|)}; maps are relative L2, tokens / joints max-abs."""
     sel = (lambda t: t) if rows is None else (lambda t: t[rows])
     n = got.shape[0] if rows is None else len(rows)
     rep = {}
+
+    def three(h, e, f, rel):
+        if rel:
+            return ((h - e).norm() / e.norm()).item(), ((h - f).norm() / f.norm()).item(), ((e - f).norm() / f.norm()).item()
+        return (h - e).abs().max().item(), (h - f).abs().max().item(), (e - f).abs().max().item()
+
     for l in range(4):
-        f = sel(eng.tensor(f"feat{l}").float().cpu()).permute(0, 3, 1, 2)
-        rep[f"feat{l}"] = tuple(((f - t["features"][l]).norm() / t["features"][l].norm()).item() for t in (taps_emu, taps_f32))
+        h = sel(eng.tensor(f"feat{l}").float().cpu()).permute(0, 3, 1, 2)
+        rep[f"feat{l}"] = three(h, taps_emu["features"][l], taps_f32["features"][l], True)
     if "tokens_ctx" in taps_emu:
-        tk = sel(eng.tensor("tok_ctx").cpu()).permute(0, 2, 1, 3)
-        rep["tok_ctx"] = tuple((tk - t["tokens_ctx"]).abs().max().item() for t in (taps_emu, taps_f32))
-    tk = sel(eng.tensor("tok_res").cpu()).reshape(n, 17, -1)
-    rep["tok_res"] = tuple((tk - t["tokens_res"]).abs().max().item() for t in (taps_emu, taps_f32))
-    tk = sel(eng.tensor("tok_joint").cpu()).reshape(n, 17, -1)
-    rep["tok_joint"] = tuple((tk - t["tokens_joint"]).abs().max().item() for t in (taps_emu, taps_f32))
+        rep["tok_ctx"] = three(sel(eng.tensor("tok_ctx").cpu()).permute(0, 2, 1, 3), taps_emu["tokens_ctx"], taps_f32["tokens_ctx"], False)
+    rep["tok_res"] = three(sel(eng.tensor("tok_res").cpu()).reshape(n, 17, -1), taps_emu["tokens_res"], taps_f32["tokens_res"], False)
+    rep["tok_joint"] = three(sel(eng.tensor("tok_joint").cpu()).reshape(n, 17, -1), taps_emu["tokens_joint"], taps_f32["tokens_joint"], False)
     g = sel(got)
-    rep["joints"] = ((g - want_emu).abs().max().item(), (g - want_f32).abs().max().item())
-    rep["joints_mean_dist"] = ((g - want_emu).norm(dim=-1).mean().item(), (g - want_f32).norm(dim=-1).mean().item())
-    print(f"{tag}: stage          vs bf16-emulating oracle   vs fp32 oracle (rounding budget)")
-    for k, (a, b) in rep.items():
-        print(f"    {k:18s} {a:12.3e} {b:24.3e}")
+    rep["joints"] = three(g, want_emu, want_f32, False)
+    rep["joints_mean_dist"] = ((g - want_emu).norm(dim=-1).mean().item(), (g - want_f32).norm(dim=-1).mean().item(),
+                               (want_emu - want_f32).norm(dim=-1).mean().item())
+    print(f"{tag}:  stage             |HIP - emu|   |HIP - fp32|   |emu - fp32|   (maps: relative L2; tokens / joints: max-abs)")
+    for k, (a, b, c) in rep.items():
+        print(f"    {k:18s} {a:12.3e} {b:14.3e} {c:14.3e}")
     return rep
 
 
 def check_bf16_report(rep):
-    for l in range(4):
-        assert rep[f"feat{l}"][0] <= BF16_EMU_MAPS, (l, rep[f"feat{l}"])
-    assert rep["joints"][0] <= BF16_EMU_JOINTS, rep["joints"]
-    assert rep["joints"][1] <= BF16_BUDGET_CAP, rep["joints"]
+    for k, (he, hf, ef) in rep.items():
+        floor = FLOOR_MAPS if k.startswith("feat") else FLOOR_JOINTS if k.startswith("joints") else FLOOR_TOKENS
+        assert hf <= SLACK * ef + floor, (k, hf, ef)
+        assert he <= SLACK * (hf + ef) + floor, (k, he, hf, ef)          # triangle: H and E are both within their budgets of F
+    assert rep["joints"][1] <= BUDGET_CAP, rep["joints"]

@@ -44,3 +44,27 @@ def metric_inputs(n=96, seed=77):
     action_idx = ((np.arange(n) // 5) % 6).astype(np.int32)
     validity = (rng.uniform(size=(n, 17, 1)) > 0.2).astype(np.float32)
     return pred, gt, action_idx, validity
+
+
+PREFETCH_MODES = {   # name: backbone, is_train, flip_test, flip  (datasets/utils.py:33-82)
+    "hrnet_eval": ("hrnet_32", False, False, False),
+    "hrnet_train_flip": ("hrnet_32", True, False, True),
+    "hrnet_train_noflip": ("hrnet_32", True, False, False),
+    "hrnet_fliptest": ("hrnet_48", False, True, False),
+    "cpn_eval": ("cpn", False, False, False),
+    "cpn_fliptest": ("cpn", False, True, False),
+}
+
+
+def prefetch_inputs(B=3, H=8, W=6, seed=91):
+    """One loader batch as Human36M.__getitem__ collates it: uint8 BGR crops [B,H,W,3] (every byte value occurs: the
+    /255 path is exercised on all 256 inputs), gt [B,1,17,3], k2d [B,17,2], crop keypoints [B,17,2] in 192x256 pixels."""
+    import numpy as np
+    import torch
+    rng = np.random.Generator(np.random.Philox(key=[seed, 20260928]))
+    img = rng.integers(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    img.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    gt = (rng.standard_normal((B, 1, 17, 3)) * 0.3).astype(np.float32)
+    k2d = rng.uniform(-1, 1, size=(B, 17, 2)).astype(np.float32)
+    kc = (rng.uniform(0, 1, size=(B, 17, 2)) * np.array([191.0, 255.0])).astype(np.float32)
+    return [torch.from_numpy(a) for a in (img, gt, k2d, kc)]

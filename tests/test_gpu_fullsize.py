@@ -14,7 +14,7 @@ import torch
 
 import capf_oracle as oracle
 from capf import synth
-from bf16_report import BF16_EMU_JOINTS, bf16_stage_report, check_bf16_report
+from bf16_report import BUDGET_CAP, bf16_stage_report, check_bf16_report
 from conftest import load_golden, make_model
 from golden_cases import CASES, case_inputs
 
@@ -58,8 +58,9 @@ def test_cfg1_batch64_hrnet32_fp32_whole_batch_vs_oracle():
 
 
 def _bf16_fullsize(tag, backbone, B, H, W, wseed, iseed, pick):
-    """One bf16 run at a BASELINE batch: a slice of frames spread over the batch against the bf16-emulating oracle (parity
-    bound) and the fp32 oracle (rounding budget), stage by stage; plus batch independence against the slice run on its own."""
+    """One bf16 run at a BASELINE batch: a slice of frames spread over the batch against the bf16-emulating oracle and the fp32
+    oracle, stage by stage (bounds and their derivation: bf16_report.py; the tight layer-wise check: test_gpu_layerwise.py);
+    plus batch independence against the slice run on its own."""
     model, sd = _model(backbone, "bf16", wseed)
     img, k2d, kc = synth.synth_inputs(B, H, W, seed=iseed, crop_range=(W, H))
     taps_e, taps_f = {}, {}
@@ -72,10 +73,11 @@ def _bf16_fullsize(tag, backbone, B, H, W, wseed, iseed, pick):
         rep = bf16_stage_report(tag, eng, got, pick, taps_e, want_e, taps_f, want_f)
         sub = model(img[pick].cuda(), k2d[pick].cuda(), kc[pick].clone().cuda()).cpu()
     check_bf16_report(rep)
-    # tile shapes and kernels depend on the batch -> another fp32 summation order; same roundings -> same bound as vs the emulation
+    # tile shapes and kernels depend on the batch -> another fp32 summation order -> (chaos at the rounding level, bf16_report.py)
+    # another point at the noise floor: bounded like the distance to the emulation
     d = (got[pick] - sub).abs().max().item()
     print(f"  batch independence (B={B} vs B={len(pick)}): max delta {d:.3e}")
-    assert d <= BF16_EMU_JOINTS
+    assert d <= 1.5 * (rep["joints"][1] + rep["joints"][2]) + 1e-3 and d <= BUDGET_CAP
 
 
 def test_cfg2_batch256_hrnet48_bf16_slice_vs_bf16_emulating_oracle():
@@ -189,7 +191,7 @@ def test_cfg3_training_step_batch512_vs_oracle_autograd():
         sub = model(img[128:192].cuda(), k2d[128:192].cuda(), kc[128:192].clone().cuda()).cpu()
     d = (pred.detach().cpu()[128:192] - sub).abs().max().item()
     print(f"  frames 128..191 inside B=512 (training plan) vs as a B=64 inference batch: max delta {d:.3e}")
-    assert d <= 2e-5
+    assert d <= 5e-5
 
 
 def test_droppath_step_matches_reference_golden():

@@ -89,7 +89,8 @@ def test_corner_rule_on_adversarial_coordinates(H, W):
 def test_bf16_path_matches_the_bf16_emulating_oracle(backbone, B, H, W):
     """compute_dtype='bf16' (BASELINE configs[2]/[4]): bf16 MFMA convolutions with bf16 activations, and the lifter's
     qkv / proj / fc1 / fc2 projections on bf16 operands (fp32 accumulation; LayerNorm, softmax, samplers and the residual
-    stream stay fp32) against the oracle run with the SAME storage roundings, stage by stage (bounds: bf16_report.py)."""
+    stream stay fp32) against the oracle run with the SAME storage roundings and against the fp32 oracle, stage by stage
+    (bounds and their derivation: bf16_report.py; the tight layer-wise check: test_gpu_layerwise.py)."""
     import copy, contextlib, io
     from capf import synth
     from mvn.models.conpose import CA_PF

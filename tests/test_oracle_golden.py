@@ -182,3 +182,25 @@ def test_bf16_emulation_rounds_where_the_engine_stores_bf16_and_nowhere_else():
             assert 1e-4 < rel < 3e-2, (backbone, l, rel)
         d = (e - f).abs().max().item()
         assert 1e-5 < d < 3e-2, (backbone, d)
+
+
+def test_prefetch_restatement_equals_the_reference_prefetcher_golden():
+    """N1 pinned by a RUN OF THE REFERENCE: tests/golden/prefetch.npz holds what the reference's own data_prefetcher.preload
+    (datasets/utils.py:33-82, executed on CPU with its CUDA-stream plumbing stubbed: oracle/_refshim.run_reference_prefetcher)
+    returned in six modes.  oracle.prefetch_preprocess(scalar_div="cpu") must equal it BIT FOR BIT; the "cuda" mode — the one
+    capf_preprocess is held to on the GPU box — may differ only in the images and only by the reciprocal-multiply rounding of
+    `x / 255.0` (ATen's CUDA scalar-divisor path), i.e. by at most one ulp of the quotient propagated through (.-mean)/std."""
+    from golden_cases import PREFETCH_MODES, prefetch_inputs
+    g = load_golden("prefetch")
+    for name, (backbone, is_train, flip_test, flip) in PREFETCH_MODES.items():
+        img, gt, k2d, kc = prefetch_inputs()
+        got = oracle.prefetch_preprocess(img, gt, k2d, kc, backbone, is_train=is_train, flip=flip, flip_test=flip_test, scalar_div="cpu")
+        for key, t in zip(("images", "gt", "k2d", "kcrop"), got):
+            np.testing.assert_array_equal(t.numpy(), g[f"{name}:{key}"], err_msg=f"{name}:{key}")
+        cuda = oracle.prefetch_preprocess(img, gt, k2d, kc, backbone, is_train=is_train, flip=flip, flip_test=flip_test)
+        for key, t in zip(("gt", "k2d", "kcrop"), cuda[1:]):
+            np.testing.assert_array_equal(t.numpy(), g[f"{name}:{key}"])
+        d = np.abs(cuda[0].numpy() - g[f"{name}:images"])
+        # one ulp of a quotient in [0, 1] is 6e-8; / std (>= 0.224) scales it by <= 4.5; + the roundings of values up to 2.7 (ulp 2.4e-7)
+        assert d.max() <= 1e-6, (name, d.max())
+        assert d.max() > 0 or backbone == "cpn"            # the two modes are not vacuously identical
