@@ -30,13 +30,20 @@ def _nhwc(x):
 
 
 def conv_bn_act(P, conv, bn, x_nhwc, residual_nhwc, ks, stride, pad, act, bf16):
-    """x / residual: the engine's own NHWC operands (fp32 or bf16 tensors) -> NHWC fp32 holding what the engine must store."""
+    """x / residual: the engine's own NHWC operands (fp32 or bf16 tensors) -> (NHWC fp32 holding what the engine must store,
+    NHWC fp32 `mass` = sum_k |x_k| |w_k| + |bias| + |residual| per output: the scale fp32 summation-order noise is relative to —
+    an output that is the small remainder of large cancelling terms cannot be reproduced to a fraction of ITS magnitude)."""
     nm = oracle.BF16 if bf16 else oracle.FP32
     x = nm.r(_nchw(x_nhwc))                                  # (the stem rounds the fp32 image on its way into LDS)
     res = _nchw(residual_nhwc) if residual_nhwc is not None else None
     assert act in (0, 1)
     y = oracle._cbr(P, conv, bn, x, stride, pad, relu=(act == 1), res=res, nm=nm)
-    return _nhwc(y)
+    sc = P[bn + ".weight"] / torch.sqrt(P[bn + ".running_var"] + oracle.BN_EPS)
+    w = (P[conv + ".weight"] * sc.view(-1, 1, 1, 1)).abs()
+    mass = F.conv2d(x.abs(), w, (P[bn + ".bias"] - P[bn + ".running_mean"] * sc).abs(), stride, pad)
+    if res is not None:
+        mass = mass + res.abs()
+    return _nhwc(y), _nhwc(mass)
 
 
 def fuse_sum(inputs_nhwc, shifts, relu, bf16):
@@ -61,21 +68,22 @@ def resize(x_nhwc, Ho, Wo, bf16):
     return _nhwc(nm.r(F.interpolate(_nchw(x_nhwc), size=(Ho, Wo), mode="bilinear", align_corners=True)))
 
 
-def compare(got, want, bf16):
-    """-> dict(max_err, frac_inexact, ok).  bf16 storage: values must be identical or ADJACENT bf16 numbers (one rounding flip),
-    except where the fp32 pre-image is cancellation noise (|value| below 1e-4 of the tensor's mean magnitude); at most 3 % of a
-    tensor may be inexact.  fp32: 1e-4 of the tensor's largest magnitude (Winograd F(4,3) amplifies roundoff by its 1/24..8
-    transform constants: 1e-5..2.5e-5 per conv measured against PyTorch)."""
+def compare(got, want, bf16, mass=None):
+    """-> dict(max_err, frac_inexact, ok).  `mass` (conv ops): per-output sum of |terms|; fp32 summation in another order moves
+    an output by ~1e-6 of it (K <= 3456 terms, eps 6e-8, random-walk growth), bounded here by 2e-5 * mass (Winograd F(4,3)
+    amplifies roundoff by its 1/24 .. 8 transform constants: measured 1e-5 of the range per conv).
+    fp32 storage: |got - want| <= 2e-5 * mass (no mass: 1e-5 of the tensor's range).
+    bf16 storage: got and want must be the SAME or ADJACENT bf16 numbers (one rounding flip), after allowing the fp32 pre-images
+    the same 2e-5 * mass; at most 3 % of a tensor may be inexact at all."""
     got, want = got.float(), want.float()
     d = (got - want).abs()
-    scale = want.abs().max().clamp_min(1e-30)
+    slack = 2e-5 * mass if mass is not None else 1e-5 * want.abs().max()
     if not bf16:
-        err = (d.max() / scale).item()
-        return {"max_err": err, "frac_inexact": (d > 0).float().mean().item(), "ok": err <= 1e-4}
+        worst = (d / (slack + 1e-30)).max().item()
+        return {"max_err": (d.max() / want.abs().max().clamp_min(1e-30)).item(), "frac_inexact": (d > 0).float().mean().item(),
+                "ok": worst <= 1.0}
     mag = torch.maximum(got.abs(), want.abs())
     ulp = torch.pow(2.0, torch.floor(torch.log2(mag.clamp_min(1e-30))) - 7)        # spacing of bf16 numbers at that magnitude
-    allowed = ulp + 1e-4 * want.abs().mean()
-    bad = (d > allowed)
+    allowed = ulp + slack
     frac = (d > 0).float().mean().item()
-    return {"max_err": (d / (mag + 1e-4 * want.abs().mean())).max().item(), "frac_inexact": frac,
-            "ok": (not bool(bad.any())) and frac <= 0.03}
+    return {"max_err": (d / allowed).max().item(), "frac_inexact": frac, "ok": bool((d <= allowed).all()) and frac <= 0.03}

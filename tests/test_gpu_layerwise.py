@@ -1,7 +1,8 @@
 """GPU: layer-wise ("teacher-forced") parity of the backbone plan AT THE BASELINE BATCH SIZES.  Every conv / fuse / pool /
 resize launch of the product schedule (grouped launches, Winograd, row-halo, ping-pong: whatever the engine picks at that
 batch) is recomputed on the CPU from the operands the ENGINE itself produced (oracle/op_oracle.py) and compared output for
-output: fp32 to 1e-4 of the tensor's range, bf16 to "identical or adjacent bf16 value, at most 3 % of a tensor inexact".
+output: fp32 to 2e-5 of each output's sum of |terms| (fp32 summation order), bf16 to "the same or the adjacent bf16 number
+once the fp32 pre-images are allowed that much; at most 3 % of a tensor inexact at all" (op_oracle.compare).
 
 This is the tight check the end-to-end comparisons cannot be: a deep bf16 network is chaotic at the rounding level (two
 correct evaluations that differ in fp32 summation order drift to the full bf16 noise floor; test_gpu_sampling.py prints the
@@ -39,6 +40,7 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
             take = lambda slot, h, w, c, dt: eng.op_tensor(i, slot, (B, h, w, c), dt)[rows].cpu()
             got = take(5, d.Ho, d.Wo, d.Cout, d.out_dtype)
             out_bf = d.out_dtype == 2
+            mass = None
             with torch.no_grad():
                 if d.kind == 0:
                     assert d.conv
@@ -46,7 +48,7 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
                     res = take(4, d.Ho, d.Wo, d.Cout, d.out_dtype) if d.has_residual else None
                     conv = names[d.p_weight][:-len(".weight")]
                     bn = names[d.p_bn_weight][:-len(".weight")]
-                    want = op_oracle.conv_bn_act(sd, conv, bn, x, res, d.ks, d.stride, d.pad, d.act, bool(d.mfma_bf16))
+                    want, mass = op_oracle.conv_bn_act(sd, conv, bn, x, res, d.ks, d.stride, d.pad, d.act, bool(d.mfma_bf16))
                 elif d.kind == 1:
                     ins = [take(k, d.H >> d.shift[k], d.W >> d.shift[k], d.Cin, d.in_dtype) for k in range(d.n_in)]
                     want = op_oracle.fuse_sum(ins, [d.shift[k] for k in range(d.n_in)], d.relu, out_bf)
@@ -54,7 +56,7 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
                     want = op_oracle.maxpool(take(0, d.H, d.W, d.Cin, d.in_dtype))
                 else:
                     want = op_oracle.resize(take(0, d.H, d.W, d.Cin, d.in_dtype), d.Ho, d.Wo, out_bf)
-            r = op_oracle.compare(got, want, out_bf)
+            r = op_oracle.compare(got, want, out_bf, mass)
             kern = table[i][1] or ("fuse_sum", "maxpool", "resize")[d.kind - 1]
             kernels.add(kern)
             w = worst.setdefault(kern, (0.0, 0.0, ""))
@@ -66,7 +68,7 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
             n_checked += 1
     print(f"{backbone} {dtype} B={B}: {n_checked} backbone ops recomputed from the engine's own operands on {len(rows)} frames")
     for k, (e, f, name) in sorted(worst.items()):
-        print(f"    {k:38s} worst error {e:9.2e}   largest inexact fraction {f:8.2e}   ({name})")
+        print(f"    {k:38s} worst error {e:9.2e} ({'of the allowance' if bf else 'of the range'})   largest inexact fraction {f:8.2e}   ({name})")
     assert n_checked == len(todo) and n_checked > 90
     return kernels
 
