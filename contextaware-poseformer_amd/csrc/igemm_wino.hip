@@ -878,6 +878,252 @@ __device__ __forceinline__ void wino43_tile(const GemmArgs& p, const int bid, fl
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// F(4,3) with 16-channel sub-chunks ("short" superchunks): the same maths, tile shapes, wave roles and epilogue as wino43_tile,
+// but a superchunk is (kh, 16 channels, 6 raw pixels): 6 x 96 rows x 64 B = 36 KiB of LDS instead of 72, and the kernel that
+// hosts it is built for THREE resident blocks per CU (<= 168 registers).  Why: a ping-pong block alternates a compute phase
+// and a load phase of about the same length and cannot overlap them itself, so a launch lasts (sum of the blocks' serial
+// times) / (resident blocks) unless the matrix pipe saturates first.  With two residents at ~48 % duty each the pipe idles
+// whenever both load and stalls whenever both compute (measured: 0.45 of the nominal MFMA rate, 1.8 blocks resident on
+// average); a third resident fills those holes.  Per superchunk a wave issues 24 MFMAs (2 k-steps of 12) and 9 LDS-DMA
+// instructions (3 per sub-chunk pair).
+//   LDS image of a superchunk: raw-pixel sub-chunks A_0..A_5 (HBT rows x 64 B each), then weight positions W_0..W_5 (HBN rows):
+//   576 rows = 9 DMA rounds of 64 rows (4 lanes per row); 16-byte quad q of row r lives at position q ^ ((r >> 2) & 3):
+//   conflict-free ds_read_b128.
+// The packed weights are wino43_tile's ([N][(kh, 32-channel chunk, p, c)], K'' = 18 Cin): both kernels share one copy.
+template <int HBT, int HBN>
+__device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, float* __restrict__ lds) {
+    constexpr int BK = 16;
+    constexpr int PSUB_A = HBT * BK, PSUB_W = HBN * BK;          // floats per sub-chunk of each operand
+    constexpr int NRA = 6 * HBT / 64, NRW = 6 * HBN / 64;        // DMA rounds (64 rows x 64 B) per superchunk: (6, 3) or (3, 6)
+    static_assert((HBT == 64 && HBN == 32) || (HBT == 32 && HBN == 64), "F(4,3) tiles");
+    static_assert(NRA + NRW == 9, "nine DMA instructions per thread and superchunk");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nbn = (p.N + HBN - 1) / HBN;
+    const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
+    const int m0 = tile_m * HBT, n0 = tile_n * HBN;
+
+    const int srow = tid >> 2;                                   // row of this thread inside a 64-row DMA round
+    const int kq = ((tid & 3) ^ ((srow >> 2) & 3)) * 4;          // source-side XOR swizzle of the 16-byte quad
+    const int arow = HBT == 64 ? srow : (srow & 31);             // tile row / weight row this thread stages (fixed for the tile)
+    const int asub = HBT == 64 ? 0 : (srow >> 5);                // ... and, where one round spans two sub-chunks, which of them
+    const int wrow = HBN == 64 ? srow : (srow & 31);
+    const int wsub = HBN == 64 ? 0 : (srow >> 5);
+    const int CC = p.Cin / BK;                                   // 16-channel chunks
+    const int nsc = 3 * CC;
+
+    constexpr unsigned OOB_A = 0x80000000u;
+    long a_base;
+    {
+        const int b = fast_div_w(m0, p.fd_hw), rem = m0 - b * p.Ho * p.Wo;
+        const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+        a_base = ((long)b * p.H * p.W + (long)(h - 1) * p.W + (4 * wt - 1)) * p.Cin;
+    }
+    const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a_base), 0, 0x7FFFFF00u, 0x00020000);
+    const rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wp + (long)n0 * p.Kpad), 0,
+                                                            (unsigned)(p.N - n0) * (unsigned)p.Kpad * 4u, 0x00020000);
+    unsigned a_rel = 0, a_mask = 0u;                             // mask bit kh * 8 + j (already shifted by this thread's asub)
+    {
+        const int t = m0 + arow;
+        if (t < p.M) {
+            const int b = fast_div_w(t, p.fd_hw), rem = t - b * p.Ho * p.Wo;
+            const int h = fast_div_w(rem, p.fd_wo), wt = rem - h * p.Wo;
+            const int h0 = h - 1, w0 = 4 * wt - 1;
+            const long off = ((long)b * p.H * p.W + (long)h0 * p.W + w0) * p.Cin;
+            a_rel = (unsigned)(off - a_base + kq + asub * p.Cin) * 4u;
+            const int j_lo = max(0, -w0), j_hi = min(6, p.W - w0);
+            const int kh_lo = max(0, -h0), kh_hi = min(3, p.H - h0);
+            if (j_hi > j_lo && kh_hi > kh_lo) {
+                const unsigned wbits = ((1u << j_hi) - 1) & ~((1u << j_lo) - 1);
+                const unsigned below_hi = (1u << (kh_hi * 8)) - 1, below_lo = (1u << (kh_lo * 8)) - 1;
+                a_mask = ((wbits * 0x10101u) & below_hi & ~below_lo) >> asub;
+            }
+        }
+    }
+    // weights: row wrow of the block's N range; position p = round's first position + wsub; 16-channel half (cc & 1) of chunk cc >> 1
+    const unsigned w_rel = (unsigned)(wrow * p.Kpad + kq + wsub * 32) * 4u;
+
+    // LDS image of a superchunk: A_j (HBT rows x 64 B) at j * PSUB_A, j = 0..5, then W_p (HBN rows) at 6 PSUB_A + p * PSUB_W
+    int u_kh = 0, u_cc = 0;                                      // walk of the superchunk being staged: chunk fastest, then kh
+    auto load_superchunk = [&]() {
+        const unsigned soff_a = __builtin_amdgcn_readfirstlane((unsigned)(u_kh * p.W * p.Cin + u_cc * BK) * 4u);
+        const unsigned soff_w = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * (CC >> 1) + (u_cc >> 1)) * 6 * 32 + (u_cc & 1) * BK) * 4u);
+        const unsigned row_mask = (a_mask >> (u_kh * 8)) & 0xffu;          // bit j: raw pixel j (+ asub) of this input row is inside the image
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {                          // round i: HBT == 64: raw pixel j = i; HBT == 32: j = 2 i + asub
+            const int j = HBT == 64 ? i : 2 * i;
+            const unsigned vo = (row_mask & (1u << j)) ? a_rel : OOB_A;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(lds + (i * 64 + wave * 16) * BK), 16, vo,
+                                                     soff_a + (unsigned)(j * p.Cin * 4), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) {                          // round i: HBN == 64: position i; HBN == 32: 2 i + wsub
+            const int pos = HBN == 64 ? i : 2 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(lds + 6 * PSUB_A + (i * 64 + wave * 16) * BK), 16, w_rel,
+                                                     soff_w + (unsigned)(pos * 32 * 4), 0, 0);
+        }
+        if (++u_cc == CC) { u_cc = 0; ++u_kh; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int pp = wave >> 1;                  // position triple
+    const int sub = wave & 1;                  // sub-tile
+    const int wm0 = HBT == 64 ? sub * 32 : 0;
+    const int wn0 = HBT == 64 ? 0 : sub * 32;
+    const int frow = lane & 31;
+    const int fsw = (frow >> 2) & 3;
+    const int fhalf = lane >> 5;
+
+    load_superchunk();
+
+    f32x4 dn[5];                               // raw pixels d_pp .. d_pp+4 of the next k-step
+    f32x4 v[2][3], uf[2][3];
+    const float* const a_ptr = lds + (wm0 + frow) * BK + pp * PSUB_A;              // raw pixel j = pp + jj
+    const float* const b_ptr = lds + 6 * PSUB_A + (wn0 + frow) * BK + 3 * pp * PSUB_W; // weight position 3 pp + k
+    auto rd_a = [&](int q, int jj) { dn[jj] = *reinterpret_cast<const f32x4*>(a_ptr + jj * PSUB_A + q * 4); };
+    auto rd_b = [&](int q, int k, int buf) { uf[buf][k] = *reinterpret_cast<const f32x4*>(b_ptr + k * PSUB_W + q * 4); };
+    float cf[3][5];
+    {
+        const float t0[3][5] = {{4.f, 0.f, -5.f, 0.f, 1.f}, {0.f, -4.f, -4.f, 1.f, 1.f}, {0.f, 4.f, -4.f, -1.f, 1.f}};     // p0 p1 p2 on d0..d4
+        const float t1[3][5] = {{-2.f, -1.f, 2.f, 1.f, 0.f}, {2.f, -1.f, -2.f, 1.f, 0.f}, {4.f, 0.f, -5.f, 0.f, 1.f}};     // p3 p4 p5 on d1..d5
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) cf[a][b] = pp == 0 ? t0[a][b] : t1[a][b];
+    }
+    auto xform1 = [&](int which, int e, int buf) {
+        const float x0 = dn[0][e], x1 = dn[1][e], x2 = dn[2][e], x3 = dn[3][e], x4 = dn[4][e];
+        v[buf][which][e] = ((cf[which][0] * x0 + cf[which][1] * x1) + (cf[which][2] * x2 + cf[which][3] * x3)) + cf[which][4] * x4;
+    };
+    auto first_frags = [&]() {
+        const int q0 = fhalf ^ fsw;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) rd_a(q0, j);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rd_b(q0, j, 0);
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xform1(w, e, 0);
+    };
+    first_frags();
+
+    const int t = m0 + wm0 + (lane & 31);
+    const bool t_ok = t < p.M;
+    const long o_row = (long)(4 * t) * p.omap.S1 + p.omap.off;
+    const long r_row = (long)(4 * t) * p.rmap.S1 + p.rmap.off;
+
+    for (int sc = 0; sc < nsc; ++sc) {
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            const int fb = step & 1, nb = fb ^ 1;
+            const int q_next = (2 + fhalf) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int pq = i % 3, e = i / 3;
+                acc[pq] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[fb][pq][e], v[fb][pq][e], acc[pq], 0, 0, 0);
+                if (step == 0) {
+                    if (i == 0) { rd_a(q_next, 0); rd_a(q_next, 1); }
+                    else if (i == 1) { rd_a(q_next, 2); rd_a(q_next, 3); }
+                    else if (i == 2) { rd_a(q_next, 4); rd_b(q_next, 0, nb); }
+                    else if (i == 3) { rd_b(q_next, 1, nb); rd_b(q_next, 2, nb); }
+                    else if (i >= 6) {                 // 12 transform units over slots 6..11, two per slot
+                        const int u0 = (i - 6) * 2, u1 = u0 + 1;
+                        xform1(u0 / 4, u0 % 4, nb);
+                        xform1(u1 / 4, u1 % 4, nb);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (sc + 1 < nsc) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_superchunk();
+            first_frags();
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
+
+    // epilogue (as wino43_tile; the residual rows are requested here, behind the K loop: the two other resident blocks cover
+    // their latency, and 40 registers stay out of the loop's live set)
+    f32x4 bv[2], rr[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * (2 * pp + k);
+        bv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) rr[k][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < p.N) {
+            if (p.bias) bv[k] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.res && t_ok) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) rr[k][o] = *reinterpret_cast<const f32x4*>(p.res + r_row + (long)o * p.rmap.S1 + n);
+            }
+        }
+    }
+    float qf[4][3];                            // A^T columns of this wave's triple, wave-uniform
+    {
+        const float t0[4][3] = {{1.f, 1.f, 1.f}, {0.f, 1.f, -1.f}, {0.f, 1.f, 1.f}, {0.f, 1.f, -1.f}};
+        const float t1[4][3] = {{1.f, 1.f, 0.f}, {2.f, -2.f, 0.f}, {4.f, 4.f, 0.f}, {8.f, -8.f, 1.f}};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) qf[a][b] = pp == 0 ? t0[a][b] : t1[a][b];
+    }
+    auto partial = [&](int g, int o, int e) -> float {
+        return (qf[o][0] * acc[0][4 * g + e] + qf[o][1] * acc[1][4 * g + e]) + qf[o][2] * acc[2][4 * g + e];
+    };
+    float* const xch = lds;                    // [sub][writer pp][8 slots][64 lanes] f32x4 = 32 KiB (<= the 36 KiB superstage)
+    {
+        float* dst = xch + (((sub * 2 + pp) * 8) * 64 + lane) * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if ((g >> 1) == pp) continue;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                f32x4 sv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[e] = partial(g, o, e);
+                *reinterpret_cast<f32x4*>(dst + (4 * (g & 1) + o) * 64 * 4) = sv;
+            }
+        }
+    }
+    __syncthreads();
+    const float* src = xch + (((sub * 2 + (pp ^ 1)) * 8) * 64 + lane) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if ((g >> 1) != pp) continue;
+        const int k = g & 1;
+        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4 other = *reinterpret_cast<const f32x4*>(src + (4 * k + o) * 64 * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mine = partial(g, o, e);
+                float sv = (pp == 0 ? mine + other[e] : other[e] + mine) + bv[k][e] + rr[k][o][e];
+                if (p.act == ACT_RELU) sv = fmaxf(sv, 0.f);
+                y[e] = sv;
+            }
+            if (t_ok && n < p.N) *reinterpret_cast<f32x4*>(p.out + o_row + (long)o * p.omap.S1 + n) = y;
+        }
+    }
+}
+#endif
+
 __device__ __forceinline__ int xcd_remap_w(int b, int nblk) {   // see igemm_f32.hip :: xcd_remap
     const int q = nblk >> 3, r = nblk & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -924,6 +1170,31 @@ __global__ __launch_bounds__(256, 2) void igemm_wino_group_kernel(WinoGroupArgs 
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
     wino_dispatch<PP>(ga.g[pi], ga.cfg[pi], bid, wlds);
+#endif
+}
+
+// F(4,3) problems only, 16-channel sub-chunks, THREE blocks per CU (<= 168 registers, 36 KiB of LDS): see wino43s_tile
+struct Wino43GroupArgs {
+    GemmArgs g[MAXG];
+    int start[MAXG + 1];
+    int tiles[MAXG];
+    int cfg[MAXG];                             // 3: 64 tiles x 32 channels, 4: 32 tiles x 64 channels
+    int n;
+};
+static constexpr int W43S_LDS = 6 * (64 + 32) * 16;              // floats per superstage (36 KiB)
+
+__global__ __launch_bounds__(256, 3) void igemm_wino43_group_kernel(Wino43GroupArgs ga) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float wlds[W43S_LDS];
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
+    const int l = b - ga.start[pi];
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int bid = (l & 7) * per_xcd + (l >> 3);
+    if (bid >= ga.tiles[pi]) return;
+    if (ga.cfg[pi] == 3) wino43s_tile<64, 32>(ga.g[pi], bid, wlds);
+    else wino43s_tile<32, 64>(ga.g[pi], bid, wlds);
 #endif
 }
 
@@ -1032,12 +1303,42 @@ static int wino_cfg(const GemmArgs& a) {
 
 static int wino_tiles(const GemmArgs& a, int cfg) { return ((a.M + kWT[cfg] - 1) / kWT[cfg]) * ((a.N + kWN[cfg] - 1) / kWN[cfg]); }
 
+// F(4,3) problems take the three-resident kernel (16-channel sub-chunks need Cin % 32 == 0 for the shared weight layout: always)
+static int wino43_short() {
+    static const int v = [] { const char* e = diag_env("CAPF_WINO43_SHORT"); return e ? atoi(e) : 1; }();     // A/B runs only
+    return v;
+}
+
+static hipError_t launch_wino43_group(const GemmArgs* prep, const int* cfgs, int n, hipStream_t s) {
+    struct Item { int idx, tiles; double cost; };
+    Item it[MAXG];
+    for (int i = 0; i < n; ++i)
+        it[i] = Item{i, wino_tiles(prep[i], cfgs[i]), (double)prep[i].Cin};          // both tile shapes do the same work per block
+    for (int i = 1; i < n; ++i)                  // longest tile first
+        for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    Wino43GroupArgs ga;
+    ga.n = n;
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+        ga.g[i] = prep[it[i].idx];
+        ga.cfg[i] = cfgs[it[i].idx];
+        ga.tiles[i] = it[i].tiles;
+        ga.start[i] = start;
+        start += (it[i].tiles + 7) & ~7;
+    }
+    ga.start[n] = start;
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 4; }
+    hipLaunchKernelGGL(igemm_wino43_group_kernel, dim3(start), dim3(256), 0, s, ga);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_wino(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
     if (!wino_prepare(a)) return hipErrorInvalidValue;
     hipError_t r = wino_attr();
     if (r != hipSuccess) return r;
     const int cfg = wino_cfg(a);
+    if (cfg >= 3 && wino43_short()) return launch_wino43_group(&a, &cfg, 1, s);
     const int nb = wino_tiles(a, cfg);
     if (wino_mode() == 1) hipLaunchKernelGGL(igemm_wino_kernel<false>, dim3(nb), dim3(256), WLDS * sizeof(float), s, a, cfg);
     else hipLaunchKernelGGL(igemm_wino_kernel<true>, dim3(nb), dim3(256), kWLDS[cfg] * sizeof(float), s, a, cfg);
@@ -1056,6 +1357,25 @@ hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
     Item it[MAXG];
     GemmArgs prep[MAXG];
     int lds_floats = 0;
+    if (wino43_short()) {                        // F(4,3) problems -> their own grid (three resident blocks per CU); the rest below
+        GemmArgs p43[MAXG], rest[MAXG];
+        int c43[MAXG], n43 = 0, nrest = 0;
+        for (int i = 0; i < n; ++i) {
+            GemmArgs a = list[i];
+            if (!wino_prepare(a)) return hipErrorInvalidValue;
+            const int cfg = wino_cfg(a);
+            if (cfg >= 3) { p43[n43] = a; c43[n43++] = cfg; }
+            else rest[nrest++] = list[i];
+        }
+        if (n43) {
+            r = launch_wino43_group(p43, c43, n43, s);
+            if (r != hipSuccess || nrest == 0) return r;
+            if (nrest == 1) return launch_gemm_wino(rest[0], s);
+            list = rest;                         // (local copies live until the launch below returns)
+            n = nrest;
+            return launch_gemm_wino_group(list, n, s);
+        }
+    }
     for (int i = 0; i < n; ++i) {
         prep[i] = list[i];
         if (!wino_prepare(prep[i])) return hipErrorInvalidValue;

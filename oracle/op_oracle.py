@@ -43,7 +43,11 @@ def conv_bn_act(P, conv, bn, x_nhwc, residual_nhwc, ks, stride, pad, act, bf16):
     mass = F.conv2d(x.abs(), w, (P[bn + ".bias"] - P[bn + ".running_mean"] * sc).abs(), stride, pad)
     if res is not None:
         mass = mass + res.abs()
-    return _nhwc(y), _nhwc(mass)
+    # largest single term |x_k w_k| an output can contain (bound: largest |x| in its window times the channel's largest |w|):
+    # the scale of ONE folded weight landing on the other side of a bf16 rounding boundary (see compare)
+    xmax = F.max_pool2d(x.abs().amax(dim=1, keepdim=True), ks, stride, pad)
+    term = xmax * w.amax(dim=(1, 2, 3)).view(1, -1, 1, 1)
+    return _nhwc(y), _nhwc(mass), _nhwc(term)
 
 
 def fuse_sum(inputs_nhwc, shifts, relu, bf16):
@@ -68,22 +72,34 @@ def resize(x_nhwc, Ho, Wo, bf16):
     return _nhwc(nm.r(F.interpolate(_nchw(x_nhwc), size=(Ho, Wo), mode="bilinear", align_corners=True)))
 
 
-def compare(got, want, bf16, mass=None):
-    """-> dict(max_err, frac_inexact, ok).  `mass` (conv ops): per-output sum of |terms|; fp32 summation in another order moves
-    an output by ~1e-6 of it (K <= 3456 terms, eps 6e-8, random-walk growth), bounded here by 2e-5 * mass (Winograd F(4,3)
-    amplifies roundoff by its 1/24 .. 8 transform constants: measured 1e-5 of the range per conv).
+def compare(got, want, bf16, mass=None, term=None):
+    """-> dict(max_err, frac_inexact, ok, weight_flips).  `mass` (conv ops): per-output sum of |terms|; fp32 summation in another
+    order moves an output by ~1e-6 of it (K <= 3456 terms, eps 6e-8, random-walk growth), bounded here by 2e-5 * mass (Winograd
+    F(4,3) amplifies roundoff by its 1/24 .. 8 transform constants: measured 1e-5 of the range per conv).
     fp32 storage: |got - want| <= 2e-5 * mass (no mass: 1e-5 of the tensor's range).
     bf16 storage: got and want must be the SAME or ADJACENT bf16 numbers (one rounding flip), after allowing the fp32 pre-images
-    the same 2e-5 * mass; at most 3 % of a tensor may be inexact at all."""
+    the same 2e-5 * mass; at most 3 % of a tensor may be inexact at all.  One more thing can legitimately differ: the BatchNorm
+    fold w * gamma / sqrt(var + eps) is evaluated once by the GPU and once by the CPU, and a folded weight whose fp32 value sits
+    on a bf16 rounding boundary may round the other way (probability ~2^-16 per weight).  Such a weight moves every output of ITS
+    channel by up to 2^-8 |x_k w_k|: outputs outside the allowance are accepted iff they are within that much (`term`) AND all lie
+    in at most two output channels (a kernel bug does not confine itself to one channel's worth of one tap)."""
     got, want = got.float(), want.float()
     d = (got - want).abs()
     slack = 2e-5 * mass if mass is not None else 1e-5 * want.abs().max()
     if not bf16:
         worst = (d / (slack + 1e-30)).max().item()
         return {"max_err": (d.max() / want.abs().max().clamp_min(1e-30)).item(), "frac_inexact": (d > 0).float().mean().item(),
-                "ok": worst <= 1.0}
+                "ok": worst <= 1.0, "weight_flips": 0}
     mag = torch.maximum(got.abs(), want.abs())
     ulp = torch.pow(2.0, torch.floor(torch.log2(mag.clamp_min(1e-30))) - 7)        # spacing of bf16 numbers at that magnitude
     allowed = ulp + slack
     frac = (d > 0).float().mean().item()
-    return {"max_err": (d / allowed).max().item(), "frac_inexact": frac, "ok": bool((d <= allowed).all()) and frac <= 0.03}
+    bad = d > allowed
+    flips = 0
+    if bool(bad.any()) and term is not None:
+        chans = torch.nonzero(bad.reshape(-1, bad.shape[-1]).any(dim=0)).flatten().tolist()
+        if len(chans) <= 2 and bool((d[bad] <= (allowed + term / 256.0)[bad]).all()):
+            flips = len(chans)
+            bad = torch.zeros_like(bad)
+    return {"max_err": (d / allowed).max().item(), "frac_inexact": frac, "ok": (not bool(bad.any())) and frac <= 0.03,
+            "weight_flips": flips}

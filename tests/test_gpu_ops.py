@@ -106,8 +106,10 @@ def test_winograd_conv_matches_torch(ci, co, H, W, B, act, res):
 @pytest.mark.parametrize("ci,co,H,W,B,act,res", [(64, 64, 32, 32, 2, 1, True), (32, 32, 16, 64, 3, 1, False), (128, 128, 8, 8, 5, 0, True),
                                                  (96, 96, 6, 12, 2, 1, True), (256, 64, 4, 4, 3, 1, False), (64, 160, 12, 8, 2, 1, True)])
 def test_winograd_f43_conv_matches_torch(ci, co, H, W, B, act, res):
-    """The selectable F(4,3)-along-W variant (four-pixel tiles, six positions; not in the default plan): same comparison,
-    tolerance 1e-4 relative (its transform constants reach 8 and 1/24; measured 1.3e-5 .. 2.9e-5)."""
+    """The F(4,3)-along-W kernel (four-pixel tiles, six positions) — the plan's default for every 3x3 stride-1 fp32 conv of
+    HRNet whose row length is a multiple of 4 (csrc/plan.cpp conv_bn), on the three-resident 16-channel-superchunk tile
+    (igemm_wino.hip wino43s_tile): same comparison, tolerance 1e-4 relative (its transform constants reach 8 and 1/24;
+    measured 1.3e-5 .. 2.9e-5).  Production tile counts: tests/test_gpu_layerwise.py (every conv of the plan at B = 64 / 512)."""
     from capf import lib as capf
     g = torch.Generator().manual_seed(ci + co * 5 + H + W)
     x = torch.randn(B, ci, H, W, generator=g)
@@ -136,6 +138,24 @@ def test_grouped_winograd_launch_is_bit_identical_to_single_launches():
         w = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).cuda()
         res = torch.randn(6, r_, r_, c, generator=g).cuda()
         wp, b = capf.pack_conv_wino(w)
+        probs.append((x, wp, b, 1, res))
+    grouped = capf.conv_nhwc_wino_group(probs)
+    for (x, wp, b, act, res), yg in zip(probs, grouped):
+        assert torch.equal(yg, capf.conv_nhwc_wino(x, wp, b, act, res))
+
+
+def test_grouped_winograd_f43_launch_is_bit_identical_to_single_launches():
+    """F(4,3) problems of a level share the three-resident grid (igemm_wino43_group_kernel); a mixed level (one row length
+    not a multiple of 4 -> that conv stays on F(2,3)) is split into the two grids.  Either way every conv sums exactly as on
+    its own."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(5)
+    probs = []
+    for c, r_ in ((32, 32), (64, 16), (128, 8), (256, 4)):
+        x = torch.randn(6, r_, r_, c, generator=g).cuda()
+        w = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).cuda()
+        res = torch.randn(6, r_, r_, c, generator=g).cuda()
+        wp, b = capf.pack_conv_wino(w, variant=43)
         probs.append((x, wp, b, 1, res))
     grouped = capf.conv_nhwc_wino_group(probs)
     for (x, wp, b, act, res), yg in zip(probs, grouped):
