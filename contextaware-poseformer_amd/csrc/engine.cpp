@@ -853,7 +853,7 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     if (name) *name = op.name.c_str();
     if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 == 2 ? capf::gemm_bf16_rows_kernel_name((int)(op.rows_per_frame * batch), op.N)
                                                                       : op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
-                                                                      : h->e.wino_now(op, batch) ? capf::gemm_wino_kernel_name()
+                                                                      : h->e.wino_now(op, batch) ? capf::gemm_wino_kernel_name(h->e.gemm_args(op, batch))
                                                                               : capf::gemm_f32_kernel_name(h->e.gemm_args(op, batch)));
     if (flops) *flops = op.flops_per_frame * batch;
     return CAPF_OK;

@@ -504,7 +504,13 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     const int tile_m = bid / nbn, tile_n = bid - tile_m * nbn;
     const int m0 = tile_m * BMO, n0 = tile_n * BN;
     const int HW = p.H * p.W, Kp = 9 * p.Cin, ncc = p.Cin / CW;
-    auto swz = [](int row) { return QPR == 8 ? (row >> 1) & 7 : (QPR == 4 ? (row >> 2) & 3 : 0); };
+    // XOR swizzle of the 16-byte quad inside an LDS row, chosen so that the 16 lanes of a ds_read_b128 group (rows covering every
+    // residue mod 16, all reading the same logical quad) hit 16 different bank quads.  128-B rows: (row >> 1) & 7; 64-B rows:
+    // (row >> 2) & 3; 96-B rows (CW = 48, HRNet-48's 48- and 96-channel branches): rows r and r + 8 start on the same bank
+    // (8 x 96 B = 3 x 256 B), so they swap adjacent quads: (row >> 3) & 1 (quad ^ 1 stays inside 0..5).  Without it every
+    // fragment read of those branches was a 2-way conflict: SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE on the grouped
+    // HRNet-48 level (profiles/r03_pmc_bf16_rh.txt).
+    auto swz = [](int row) { return QPR == 8 ? (row >> 1) & 7 : (QPR == 4 ? (row >> 2) & 3 : (row >> 3) & 1); };
 
     // ---- operand fetch: LDS-DMA with block-uniform descriptors (see igemm_bf16_tile); the descriptor of A starts one
     // pixel and one image row before the tile so that every (row, kh) offset is non-negative

@@ -42,9 +42,12 @@ static constexpr int WLDS = 2 * 4 * WSUB;      // 2 superstages x 4 sub-stages
 
 #ifdef CAPF_DIAG   // (diagnosis build) per-block stamps: {t_entry, t_prologue_done, t_loop_done, t_exit, realtime_entry, hw_id, xcc_id, realtime_exit}
 __device__ unsigned long long capf_wino_timeline[8192 * 8];
+__device__ unsigned long long capf_wino_phases[8192 * 8];     // wino43s_tile: cycles per phase of the K loop, summed over the tile
 #define WINO_STAMP(var) var = __builtin_amdgcn_s_memtime()
+#define WINO_PHASE(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); dbg_ph[k] += _t - dbg_last; dbg_last = _t; } while (0)
 #else
 #define WINO_STAMP(var)
+#define WINO_PHASE(k)
 #endif
 
 __device__ __forceinline__ int fast_div_w(int n, FastDiv d) {
@@ -891,8 +894,19 @@ __device__ __forceinline__ void wino43_tile(const GemmArgs& p, const int bid, fl
 //   576 rows = 9 DMA rounds of 64 rows (4 lanes per row); 16-byte quad q of row r lives at position q ^ ((r >> 2) & 3):
 //   conflict-free ds_read_b128.
 // The packed weights are wino43_tile's ([N][(kh, 32-channel chunk, p, c)], K'' = 18 Cin): both kernels share one copy.
-template <int HBT, int HBN>
+// DB = true: TWO superstages (72 KiB, two resident blocks): the 9 DMA instructions of superchunk s + 1 ride in MFMA slots of
+// superchunk s, so a block's own load latency hides behind its own MFMAs and only [wait, barrier, first fragments] stays
+// exposed between compute phases (the partner block covers that).  Measured motive (tools/wino_level_timeline.py, HRNet-32
+// level at batch 64, DB = false): 2.4 - 3.9 us per superchunk per block against 0.79 us of MFMA time -- the launch lasts as
+// long as the 48-superchunk tiles of the 8 x 8 branch take to crawl through their load phases (115 of 133 us).
+template <int HBT, int HBN, bool DB>
 __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, float* __restrict__ lds) {
+#ifdef CAPF_DIAG
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_last = 0;
+    unsigned long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 0 compute, 1 drain + barrier, 2 DMA issue, 3 data wait, 4 barrier, 5 first fragments
+    const unsigned long long dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    WINO_STAMP(dbg_t0);
     constexpr int BK = 16;
     constexpr int PSUB_A = HBT * BK, PSUB_W = HBN * BK;          // floats per sub-chunk of each operand
     constexpr int NRA = 6 * HBT / 64, NRW = 6 * HBN / 64;        // DMA rounds (64 rows x 64 B) per superchunk: (6, 3) or (3, 6)
@@ -947,27 +961,36 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
     const unsigned w_rel = (unsigned)(wrow * p.Kpad + kq + wsub * 32) * 4u;
 
     // LDS image of a superchunk: A_j (HBT rows x 64 B) at j * PSUB_A, j = 0..5, then W_p (HBN rows) at 6 PSUB_A + p * PSUB_W
+    constexpr int STAGE = 6 * (PSUB_A + PSUB_W);                 // floats per superstage (9216 = 36 KiB)
     int u_kh = 0, u_cc = 0;                                      // walk of the superchunk being staged: chunk fastest, then kh
-    auto load_superchunk = [&]() {
-        const unsigned soff_a = __builtin_amdgcn_readfirstlane((unsigned)(u_kh * p.W * p.Cin + u_cc * BK) * 4u);
-        const unsigned soff_w = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * (CC >> 1) + (u_cc >> 1)) * 6 * 32 + (u_cc & 1) * BK) * 4u);
-        const unsigned row_mask = (a_mask >> (u_kh * 8)) & 0xffu;          // bit j: raw pixel j (+ asub) of this input row is inside the image
-#pragma unroll
-        for (int i = 0; i < NRA; ++i) {                          // round i: HBT == 64: raw pixel j = i; HBT == 32: j = 2 i + asub
-            const int j = HBT == 64 ? i : 2 * i;
+    unsigned soff_a = 0, soff_w = 0, row_mask = 0;
+    auto prepare = [&]() {                                       // offsets of the next superchunk to stage
+        soff_a = __builtin_amdgcn_readfirstlane((unsigned)(u_kh * p.W * p.Cin + u_cc * BK) * 4u);
+        soff_w = __builtin_amdgcn_readfirstlane((unsigned)((u_kh * (CC >> 1) + (u_cc >> 1)) * 6 * 32 + (u_cc & 1) * BK) * 4u);
+        row_mask = (a_mask >> (u_kh * 8)) & 0xffu;               // bit j: raw pixel j (+ asub) of this input row is inside the image
+        if (++u_cc == CC) { u_cc = 0; ++u_kh; }
+    };
+    auto fire = [&](int k, float* stage) {                       // DMA instruction k = 0..8 of the prepared superchunk
+        if (k < NRA) {                                           // round k: HBT == 64: raw pixel j = k; HBT == 32: j = 2 k + asub
+            const int j = HBT == 64 ? k : 2 * k;
             const unsigned vo = (row_mask & (1u << j)) ? a_rel : OOB_A;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(lds + (i * 64 + wave * 16) * BK), 16, vo,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(stage + (k * 64 + wave * 16) * BK), 16, vo,
                                                      soff_a + (unsigned)(j * p.Cin * 4), 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NRW; ++i) {                          // round i: HBN == 64: position i; HBN == 32: 2 i + wsub
-            const int pos = HBN == 64 ? i : 2 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(lds + 6 * PSUB_A + (i * 64 + wave * 16) * BK), 16, w_rel,
+        } else {                                                 // round i: HBN == 64: position i; HBN == 32: 2 i + wsub
+            const int i = k - NRA, pos = HBN == 64 ? i : 2 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)(stage + 6 * PSUB_A + (i * 64 + wave * 16) * BK), 16, w_rel,
                                                      soff_w + (unsigned)(pos * 32 * 4), 0, 0);
         }
-        if (++u_cc == CC) { u_cc = 0; ++u_kh; }
+    };
+    auto load_superchunk = [&](float* stage) {
+        prepare();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fire(k, stage);
+        WINO_PHASE(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WINO_PHASE(3);
         __builtin_amdgcn_s_barrier();
+        WINO_PHASE(4);
     };
 
     f32x16 acc[3];
@@ -984,14 +1007,15 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
     const int fsw = (frow >> 2) & 3;
     const int fhalf = lane >> 5;
 
-    load_superchunk();
+    load_superchunk(lds);
 
     f32x4 dn[5];                               // raw pixels d_pp .. d_pp+4 of the next k-step
     f32x4 v[2][3], uf[2][3];
     const float* const a_ptr = lds + (wm0 + frow) * BK + pp * PSUB_A;              // raw pixel j = pp + jj
     const float* const b_ptr = lds + 6 * PSUB_A + (wn0 + frow) * BK + 3 * pp * PSUB_W; // weight position 3 pp + k
-    auto rd_a = [&](int q, int jj) { dn[jj] = *reinterpret_cast<const f32x4*>(a_ptr + jj * PSUB_A + q * 4); };
-    auto rd_b = [&](int q, int k, int buf) { uf[buf][k] = *reinterpret_cast<const f32x4*>(b_ptr + k * PSUB_W + q * 4); };
+    int so = 0;                                // float offset of the superstage being consumed (DB: 0 / STAGE)
+    auto rd_a = [&](int q, int jj) { dn[jj] = *reinterpret_cast<const f32x4*>(a_ptr + so + jj * PSUB_A + q * 4); };
+    auto rd_b = [&](int q, int k, int buf) { uf[buf][k] = *reinterpret_cast<const f32x4*>(b_ptr + so + k * PSUB_W + q * 4); };
     float cf[3][5];
     {
         const float t0[3][5] = {{4.f, 0.f, -5.f, 0.f, 1.f}, {0.f, -4.f, -4.f, 1.f, 1.f}, {0.f, 4.f, -4.f, -1.f, 1.f}};     // p0 p1 p2 on d0..d4
@@ -1017,6 +1041,11 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
             for (int e = 0; e < 4; ++e) xform1(w, e, 0);
     };
     first_frags();
+    WINO_STAMP(dbg_t1);
+#ifdef CAPF_DIAG
+    dbg_last = dbg_t1;
+    for (int k = 0; k < 8; ++k) dbg_ph[k] = 0;
+#endif
 
     const int t = m0 + wm0 + (lane & 31);
     const bool t_ok = t < p.M;
@@ -1024,6 +1053,9 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
     const long r_row = (long)(4 * t) * p.rmap.S1 + p.rmap.off;
 
     for (int sc = 0; sc < nsc; ++sc) {
+        const bool more = sc + 1 < nsc;
+        float* const next_stage = lds + (DB ? STAGE - so : 0);
+        if (DB && more) prepare();
 #pragma unroll
         for (int step = 0; step < 2; ++step) {
             const int fb = step & 1, nb = fb ^ 1;
@@ -1043,17 +1075,33 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
                         xform1(u1 / 4, u1 % 4, nb);
                     }
                 }
+                if (DB && more) {                      // the next superchunk's nine DMA instructions, one per MFMA slot
+                    const int k = step == 0 ? i - 4 : i + 8;        // step 0 slots 4..11 -> 0..7, step 1 slot 0 -> 8
+                    if (k >= 0 && k < 9) fire(k, next_stage);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (sc + 1 < nsc) {
+        WINO_PHASE(0);
+        if (more) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            load_superchunk();
+            if (DB) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WINO_PHASE(3);
+                __builtin_amdgcn_s_barrier();          // the next superchunk has landed; every wave is done reading this one
+                WINO_PHASE(4);
+                so = STAGE - so;
+            } else {
+                __builtin_amdgcn_s_barrier();
+                WINO_PHASE(1);
+                load_superchunk(lds);
+            }
             first_frags();
+            WINO_PHASE(5);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WINO_STAMP(dbg_t2);
     __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
 
     // epilogue (as wino43_tile; the residual rows are requested here, behind the K loop: the two other resident blocks cover
@@ -1121,6 +1169,15 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
             if (t_ok && n < p.N) *reinterpret_cast<f32x4*>(p.out + o_row + (long)o * p.omap.S1 + n) = y;
         }
     }
+#ifdef CAPF_DIAG
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = capf_wino_timeline + (size_t)blockIdx.x * 8;
+        d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = dbg_r0; d[5] = (unsigned long long)p.Cin; d[6] = (unsigned long long)nsc; d[7] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* ph = capf_wino_phases + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 8; ++k) ph[k] = dbg_ph[k];
+    }
+#endif
 }
 #endif
 
@@ -1179,13 +1236,14 @@ struct Wino43GroupArgs {
     int start[MAXG + 1];
     int tiles[MAXG];
     int cfg[MAXG];                             // 3: 64 tiles x 32 channels, 4: 32 tiles x 64 channels
+    int prio[MAXG];                            // s_setprio level of the problem's waves (see launch_wino43_group)
     int n;
 };
 static constexpr int W43S_LDS = 6 * (64 + 32) * 16;              // floats per superstage (36 KiB)
 
-__global__ __launch_bounds__(256, 3) void igemm_wino43_group_kernel(Wino43GroupArgs ga) {
+template <bool DB>
+__device__ __forceinline__ void wino43_group_body(const Wino43GroupArgs& ga, float* wlds) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float wlds[W43S_LDS];
     const int b = blockIdx.x;
     int pi = 0;
     while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
@@ -1193,8 +1251,27 @@ __global__ __launch_bounds__(256, 3) void igemm_wino43_group_kernel(Wino43GroupA
     const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
-    if (ga.cfg[pi] == 3) wino43s_tile<64, 32>(ga.g[pi], bid, wlds);
-    else wino43s_tile<32, 64>(ga.g[pi], bid, wlds);
+    // issue priority by K length (measured: no effect on the level either way; kept switchable in the diagnosis build)
+    const int prio = ga.prio[pi];
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (ga.cfg[pi] == 3) wino43s_tile<64, 32, DB>(ga.g[pi], bid, wlds);
+    else wino43s_tile<32, 64, DB>(ga.g[pi], bid, wlds);
+#endif
+}
+
+__global__ __launch_bounds__(256, 3) void igemm_wino43_group_kernel(Wino43GroupArgs ga) {          // ping-pong, three residents
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float wlds[W43S_LDS];
+    wino43_group_body<false>(ga, wlds);
+#endif
+}
+
+__global__ __launch_bounds__(256, 2) void igemm_wino43_group_db_kernel(Wino43GroupArgs ga) {       // double-buffered, two residents
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float wlds[2 * W43S_LDS];
+    wino43_group_body<true>(ga, wlds);
 #endif
 }
 
@@ -1305,7 +1382,14 @@ static int wino_tiles(const GemmArgs& a, int cfg) { return ((a.M + kWT[cfg] - 1)
 
 // F(4,3) problems take the three-resident kernel (16-channel sub-chunks need Cin % 32 == 0 for the shared weight layout: always)
 static int wino43_short() {
+    // 0: the 72 KiB ping-pong tiles of igemm_wino_group_kernel; 1: 16-channel superchunks, ping-pong, three residents;
+    // 2: 16-channel superchunks, double-buffered, two residents
     static const int v = [] { const char* e = diag_env("CAPF_WINO43_SHORT"); return e ? atoi(e) : 1; }();     // A/B runs only
+    return v;
+}
+
+static int wino43_prio() {
+    static const int v = [] { const char* e = diag_env("CAPF_WINO43_PRIO"); return e ? atoi(e) : 0; }();       // A/B runs only
     return v;
 }
 
@@ -1325,10 +1409,18 @@ static hipError_t launch_wino43_group(const GemmArgs* prep, const int* cfgs, int
         ga.tiles[i] = it[i].tiles;
         ga.start[i] = start;
         start += (it[i].tiles + 7) & ~7;
+        // longest K -> priority 3, next distinct K length 2, ...; problems of the shortest K (and lone problems) stay at 0
+        int longer = 0;
+        for (int j = 0; j < n; ++j)
+            if (it[j].cost > it[i].cost && (j == 0 || it[j].cost != it[j - 1].cost)) ++longer;
+        int shorter = 0;
+        for (int j = 0; j < n; ++j) shorter += it[j].cost < it[i].cost;
+        ga.prio[i] = (shorter && wino43_prio()) ? std::max(1, 3 - longer) : 0;
     }
     ga.start[n] = start;
-    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 4; }
-    hipLaunchKernelGGL(igemm_wino43_group_kernel, dim3(start), dim3(256), 0, s, ga);
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.cfg[i] = 4; ga.prio[i] = 0; }
+    if (wino43_short() == 2) hipLaunchKernelGGL(igemm_wino43_group_db_kernel, dim3(start), dim3(256), 0, s, ga);
+    else hipLaunchKernelGGL(igemm_wino43_group_kernel, dim3(start), dim3(256), 0, s, ga);
     return hipGetLastError();
 }
 
@@ -1345,7 +1437,10 @@ hipError_t launch_gemm_wino(const GemmArgs& a_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-const char* gemm_wino_kernel_name() { return "igemm_wino<w4,F(2,3)/F(4,3)>"; }
+// what rocprofv3 will call the launch: F(4,3) problems (alone or grouped) run igemm_wino43_group_kernel
+const char* gemm_wino_kernel_name(const GemmArgs& a) {
+    return (a.Kpad == 18 * a.Cin && wino43_short()) ? "igemm_wino43_group" : "igemm_wino<w4,F(2,3)>";
+}
 
 hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
@@ -1408,5 +1503,9 @@ hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
 extern "C" int capf_debug_wino_timeline(unsigned long long* dst, int blocks) {
     if (blocks > 8192) blocks = 8192;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_wino_timeline), (size_t)blocks * 64);
+}
+extern "C" int capf_debug_wino_phases(unsigned long long* dst, int blocks) {
+    if (blocks > 8192) blocks = 8192;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_wino_phases), (size_t)blocks * 64);
 }
 #endif

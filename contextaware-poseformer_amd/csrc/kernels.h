@@ -129,7 +129,7 @@ const char* gemm_f32_pw_kernel_name();
 bool gemm_wino_ok(const GemmArgs& a);
 hipError_t launch_gemm_wino(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s);
-const char* gemm_wino_kernel_name();
+const char* gemm_wino_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_wino(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                                  float eps, float* Wp, float* bias, int Cout, int Cin, hipStream_t s, int variant = 23);
 

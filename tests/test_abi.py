@@ -151,7 +151,7 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     assert table["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
     # the 3x3 stride-1 convs run the Winograd kernel from batch 8 up and the direct kernel (tall 256x32 tile for the
     # 32-channel 64x64 branch launched on its own) below
-    assert table["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_wino<")
+    assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"      # F(4,3): row length 64 is a multiple of 4
     small = {name: kern for name, kern, _ in eng.op_table(4)}
     assert small["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
     # layer1's HBM-bound 1x1 bottleneck convs: the pointwise kernel from 2048 tiles per launch, the general tile below

@@ -25,12 +25,15 @@ def short(name):
     m = re.match(r"(?:void )?capf::igemm_bf16_kernel<(\d+), (\d+),", name)
     if m:
         return f"igemm_bf16<w4,{m.group(1)}x{m.group(2)},conv>"
+    m = re.match(r"(?:void )?capf::igemm_wino43_group(_db)?_kernel", name)
+    if m:
+        return "igemm_wino43_group"
     m = re.match(r"(?:void )?capf::igemm_wino_group_kernel", name)
     if m:
         return "igemm_wino_group"
     m = re.match(r"(?:void )?capf::igemm_wino_kernel", name)
     if m:
-        return "igemm_wino<w4,F(2,3)/F(4,3)>"
+        return "igemm_wino<w4,F(2,3)>"
     m = re.match(r"(?:void )?capf::igemm_f32_pw_kernel", name)
     if m:
         return "igemm_f32_pw<w4,128x64>"
