@@ -93,11 +93,12 @@ def test_batch_independence_and_determinism():
     assert (a[2:3] - one).abs().max().item() <= 1e-5
 
 
-def test_mpi_variant_matches_reference_golden():
-    """N4: model.conpose.VolumetricTriangulationNet (context_blocks = 0) vs the sibling reference app."""
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].get("mpi")])
+def test_mpi_variant_matches_reference_golden(name):
+    """N4: model.conpose.VolumetricTriangulationNet (context_blocks = 0) vs the sibling reference app, both shipped widths."""
     from test_oracle_golden import _mpi_model
-    case = CASES["mpi_w32_e64_b2"]
-    g = load_golden("mpi_w32_e64_b2")
+    case = CASES[name]
+    g = load_golden(name)
     m, _ = _mpi_model(case, device="cuda")
     img, k2d, kc = case_inputs(case)
     kc_dev = kc.cuda()
@@ -106,5 +107,5 @@ def test_mpi_variant_matches_reference_golden():
     assert aux is None and tuple(out.shape) == (case["B"], 3, 1, 17, 1)
     np.testing.assert_array_equal(kc_dev.cpu().numpy(), g["ref"])
     err = np.abs(out.cpu().numpy() - g["out"]).max()
-    print(f"mpi variant: max|hip-ref| {err:.2e}")
+    print(f"mpi variant {name}: max|hip-ref| {err:.2e}")
     assert err <= TOL_OUT

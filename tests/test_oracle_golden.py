@@ -77,11 +77,12 @@ def _mpi_model(case, device=None):
     return (m.to(device) if device else m), sd
 
 
-def test_oracle_matches_mpi_variant_golden():
-    """the MPI-INF-3DHP model (no deformable blocks, embed 64, output [B,3,1,17,1]) — golden
-    captured from ContextPose_mpi/model/conpose.py; also pins the variant's state_dict names."""
-    case = CASES["mpi_w32_e64_b2"]
-    g = load_golden("mpi_w32_e64_b2")
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].get("mpi")])
+def test_oracle_matches_mpi_variant_golden(name):
+    """the MPI-INF-3DHP model (no deformable blocks, embed 64 with HRNet-32 / 96 with HRNet-48, output
+    [B,3,1,17,1]) — goldens captured from ContextPose_mpi/model/conpose.py; also pins the variant's state_dict names."""
+    case = CASES[name]
+    g = load_golden(name)
     m, sd = _mpi_model(case)
     assert sorted(m.state_dict().keys()) == sorted(str(n) for n in g["schema_names"])
     img, k2d, kc = case_inputs(case)
