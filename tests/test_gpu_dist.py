@@ -82,3 +82,52 @@ def test_bench_train_two_ranks_on_one_gpu():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["frames_per_step"] == 32 and j["value"] > 0
     assert "all-reduce" in j["config"]["parallelism"] and j["config"]["baseline_config"] is None
+
+
+def _rccl_worker(port, q):
+    for p in (os.path.join(ROOT, "contextaware-poseformer_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from capf import dist as cd, synth
+    from capf.optim import FusedAdamW, flatten_
+    from conftest import make_model
+    from mvn.models.loss import MPJPE
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)      # "nccl" IS RCCL on ROCm
+    model, _ = make_model("hrnet_32", device="cuda", wseed=11)
+    model.train(); model.backbone.eval(); model.drop_path_rate = 0.0
+    cd.broadcast_state_(model.volume_net)                      # world 1: no-op by construction
+    flat_p = flatten_(model.volume_net)
+    opt = FusedAdamW(flat_p, lr=1e-3, weight_decay=0.1)
+    model.flat_grad_only = True
+    img, k2d, kc, gt = synth.synth_inputs(4, 256, 192, seed=12, with_gt=True)
+    pred = model(img.cuda(), k2d.cuda(), kc.clone().cuda())
+    MPJPE()(pred, gt.cuda()).backward()
+    g = model.last_flat_grad
+    before = g.clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)                   # the REAL 56.4 MB buffer through an RCCL collective on the device
+    torch.cuda.synchronize()
+    same = torch.equal(g, before)
+    g2, scale = cd.allreduce_sum_(g)                           # the bench step's own path (skips the collective at world 1)
+    p0 = flat_p.clone()
+    opt.step(g2, grad_scale=scale)
+    torch.cuda.synchronize()
+    moved = (flat_p - p0).abs().max().item()
+    q.put((dist.get_backend(), g.numel(), same, scale, moved))
+    dist.destroy_process_group()
+
+
+def test_rccl_runs_an_allreduce_of_the_real_flat_gradient_single_rank():
+    """The only RCCL evidence a ONE-GPU box can give: the library loads, a communicator initialises (world size 1) and an
+    all-reduce of the real 14.09 M-element flat gradient that capf_backward wrote runs on the device and leaves it unchanged.
+    Multi-rank RCCL over xGMI is the driver's 8-GPU run (bench.py records backend / ranks_seen / per-rank rates for it)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    backend, n, same, scale, moved = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and n == 14094147 and same and scale == 1.0 and moved > 0
