@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -1016,44 +1017,69 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
     int so = 0;                                // float offset of the superstage being consumed (DB: 0 / STAGE)
     auto rd_a = [&](int q, int jj) { dn[jj] = *reinterpret_cast<const f32x4*>(a_ptr + so + jj * PSUB_A + q * 4); };
     auto rd_b = [&](int q, int k, int buf) { uf[buf][k] = *reinterpret_cast<const f32x4*>(b_ptr + so + k * PSUB_W + q * 4); };
-    float cf[3][5];
-    {
-        const float t0[3][5] = {{4.f, 0.f, -5.f, 0.f, 1.f}, {0.f, -4.f, -4.f, 1.f, 1.f}, {0.f, 4.f, -4.f, -1.f, 1.f}};     // p0 p1 p2 on d0..d4
-        const float t1[3][5] = {{-2.f, -1.f, 2.f, 1.f, 0.f}, {2.f, -1.f, -2.f, 1.f, 0.f}, {4.f, 0.f, -5.f, 0.f, 1.f}};     // p3 p4 p5 on d1..d5
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 5; ++b) cf[a][b] = pp == 0 ? t0[a][b] : t1[a][b];
-    }
-    auto xform1 = [&](int which, int e, int buf) {
+    // Input transform of one k sub-step e for this wave's triple, SPECIALISED per triple (a wave-uniform branch picks the loop
+    // body): with the B^T rows as run-time scalars every unit cost 6 VALU (two of five coefficients are 0 or +-1 in every row
+    // but the compiler cannot know), 72 per k-step; written out they are 8 (triple 0) / 6 (triple 1) per sub-step = 32 / 24:
+    //   triple 0 (d0..d4):  p0 = 4 d0 - 5 d2 + d4     p1 = -4 (d1 + d2) + (d3 + d4)     p2 = 4 (d1 - d2) + (d4 - d3)
+    //   triple 1 (d1..d5):  p3 = 2 (d3 - d1) + (d4 - d2)     p4 = -2 (d3 - d1) + (d4 - d2)     p5 = 4 d1 - 5 d3 + d5
+    auto xform_e = [&](auto ppc, int e, int buf) {
         const float x0 = dn[0][e], x1 = dn[1][e], x2 = dn[2][e], x3 = dn[3][e], x4 = dn[4][e];
-        v[buf][which][e] = ((cf[which][0] * x0 + cf[which][1] * x1) + (cf[which][2] * x2 + cf[which][3] * x3)) + cf[which][4] * x4;
+        if constexpr (decltype(ppc)::value == 0) {
+            v[buf][0][e] = __builtin_fmaf(-5.f, x2, __builtin_fmaf(4.f, x0, x4));
+            v[buf][1][e] = __builtin_fmaf(-4.f, x1 + x2, x3 + x4);
+            v[buf][2][e] = __builtin_fmaf(4.f, x1 - x2, x4 - x3);
+        } else {
+            const float a = x2 - x0, b = x3 - x1;
+            v[buf][0][e] = __builtin_fmaf(2.f, a, b);
+            v[buf][1][e] = __builtin_fmaf(-2.f, a, b);
+            v[buf][2][e] = __builtin_fmaf(-5.f, x2, __builtin_fmaf(4.f, x0, x4));
+        }
     };
-    auto first_frags = [&]() {
+    auto first_frags = [&](auto ppc) {
         const int q0 = fhalf ^ fsw;
 #pragma unroll
         for (int j = 0; j < 5; ++j) rd_a(q0, j);
 #pragma unroll
         for (int j = 0; j < 3; ++j) rd_b(q0, j, 0);
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xform1(w, e, 0);
+        for (int e = 0; e < 4; ++e) xform_e(ppc, e, 0);
     };
-    first_frags();
+    const int t = m0 + wm0 + (lane & 31);
+    const bool t_ok = t < p.M;
+    const long o_row = (long)(4 * t) * p.omap.S1 + p.omap.off;
+    const long r_row = (long)(4 * t) * p.rmap.S1 + p.rmap.off;
+
+    // bias and residual rows of the two register groups this wave finishes (g = 2 pp, 2 pp + 1), four output pixels each: requested
+    // before the LAST compute phase, whose 24 MFMAs (and the co-residents) hide the HBM latency; behind the K loop they cost
+    // every block ~2 us of its slot (tools/wino_level_timeline.py: epilogue 6-9 us with four residents)
+    f32x4 bv[2], rr[2][4];
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * (2 * pp + k);
+            bv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rr[k][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {
+                if (p.bias) bv[k] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.res && t_ok) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) rr[k][o] = *reinterpret_cast<const f32x4*>(p.res + r_row + (long)o * p.rmap.S1 + n);
+                }
+            }
+        }
+    };
+    auto kloop = [&](auto ppc) {
+    first_frags(ppc);
     WINO_STAMP(dbg_t1);
 #ifdef CAPF_DIAG
     dbg_last = dbg_t1;
     for (int k = 0; k < 8; ++k) dbg_ph[k] = 0;
 #endif
 
-    const int t = m0 + wm0 + (lane & 31);
-    const bool t_ok = t < p.M;
-    const long o_row = (long)(4 * t) * p.omap.S1 + p.omap.off;
-    const long r_row = (long)(4 * t) * p.rmap.S1 + p.rmap.off;
-
     for (int sc = 0; sc < nsc; ++sc) {
         const bool more = sc + 1 < nsc;
+        if (!more) load_epilogue_operands();
         float* const next_stage = lds + (DB ? STAGE - so : 0);
         if (DB && more) prepare();
 #pragma unroll
@@ -1069,11 +1095,7 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
                     else if (i == 1) { rd_a(q_next, 2); rd_a(q_next, 3); }
                     else if (i == 2) { rd_a(q_next, 4); rd_b(q_next, 0, nb); }
                     else if (i == 3) { rd_b(q_next, 1, nb); rd_b(q_next, 2, nb); }
-                    else if (i >= 6) {                 // 12 transform units over slots 6..11, two per slot
-                        const int u0 = (i - 6) * 2, u1 = u0 + 1;
-                        xform1(u0 / 4, u0 % 4, nb);
-                        xform1(u1 / 4, u1 % 4, nb);
-                    }
+                    else if (i >= 6 && i < 10) xform_e(ppc, i - 6, nb);      // the next k-step's transforms, one sub-step per slot
                 }
                 if (DB && more) {                      // the next superchunk's nine DMA instructions, one per MFMA slot
                     const int k = step == 0 ? i - 4 : i + 8;        // step 0 slots 4..11 -> 0..7, step 1 slot 0 -> 8
@@ -1096,31 +1118,19 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
                 WINO_PHASE(1);
                 load_superchunk(lds);
             }
-            first_frags();
+            first_frags(ppc);
             WINO_PHASE(5);
         }
     }
+    };
+    if (pp == 0) kloop(std::integral_constant<int, 0>{});
+    else kloop(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WINO_STAMP(dbg_t2);
     __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
 
-    // epilogue (as wino43_tile; the residual rows are requested here, behind the K loop: the two other resident blocks cover
-    // their latency, and 40 registers stay out of the loop's live set)
-    f32x4 bv[2], rr[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * (2 * pp + k);
-        bv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int o = 0; o < 4; ++o) rr[k][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n < p.N) {
-            if (p.bias) bv[k] = *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.res && t_ok) {
-#pragma unroll
-                for (int o = 0; o < 4; ++o) rr[k][o] = *reinterpret_cast<const f32x4*>(p.res + r_row + (long)o * p.rmap.S1 + n);
-            }
-        }
-    }
+    // epilogue (as wino43_tile): output transform of this wave's triple, exchange with the other triple through LDS, bias /
+    // residual / ReLU, stores.  bv / rr were requested before the last compute phase (load_epilogue_operands).
     float qf[4][3];                            // A^T columns of this wave's triple, wave-uniform
     {
         const float t0[4][3] = {{1.f, 1.f, 1.f}, {0.f, 1.f, -1.f}, {0.f, 1.f, 1.f}, {0.f, 1.f, -1.f}};
@@ -1261,6 +1271,9 @@ __device__ __forceinline__ void wino43_group_body(const Wino43GroupArgs& ga, flo
 #endif
 }
 
+// (the per-triple transform needs no coefficient registers: 128 registers without the residual prefetch, i.e. FOUR residents
+// would fit -- measured: no faster than three (124.7 vs 124.6 us per level, 6122 vs 6177 frames/s): every resident added
+// lengthens the others' phases, the level is bound by the shared matrix pipe + LDS-DMA path, not by occupancy)
 __global__ __launch_bounds__(256, 3) void igemm_wino43_group_kernel(Wino43GroupArgs ga) {          // ping-pong, three residents
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float wlds[W43S_LDS];
@@ -1400,6 +1413,13 @@ static hipError_t launch_wino43_group(const GemmArgs* prep, const int* cfgs, int
         it[i] = Item{i, wino_tiles(prep[i], cfgs[i]), (double)prep[i].Cin};          // both tile shapes do the same work per block
     for (int i = 1; i < n; ++i)                  // longest tile first
         for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    if (const char* ord = diag_env("CAPF_WINO43_ORDER")) {       // A/B runs only: dispatch order as a permutation of the cost ranks, e.g. "0312"
+        Item tmp[MAXG];
+        int m = 0;
+        for (const char* c = ord; *c && m < n; ++c)
+            if (*c >= '0' && *c - '0' < n) tmp[m++] = it[*c - '0'];
+        if (m == n) for (int i = 0; i < n; ++i) it[i] = tmp[i];
+    }
     Wino43GroupArgs ga;
     ga.n = n;
     int start = 0;

