@@ -1044,30 +1044,40 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
 #pragma unroll
         for (int e = 0; e < 4; ++e) xform_e(ppc, e, 0);
     };
-    const int t = m0 + wm0 + (lane & 31);
-    const bool t_ok = t < p.M;
-    const long o_row = (long)(4 * t) * p.omap.S1 + p.omap.off;
-    const long r_row = (long)(4 * t) * p.rmap.S1 + p.rmap.off;
-
-    // bias and residual rows of the two register groups this wave finishes (g = 2 pp, 2 pp + 1), four output pixels each: requested
-    // before the LAST compute phase, whose 24 MFMAs (and the co-residents) hide the HBM latency; behind the K loop they cost
-    // every block ~2 us of its slot (tools/wino_level_timeline.py: epilogue 6-9 us with four residents)
-    f32x4 bv[2], rr[2][4];
-    auto load_epilogue_operands = [&]() {
+    // Output tile of the block in LDS order: PXT output pixels x NQ 16-byte quads (32 KiB for both tile shapes).  The epilogue
+    // assembles it in LDS and every thread finishes EIGHT row-contiguous quads (piece i * 256 + tid): residual loads and stores are
+    // 16 B per lane with consecutive lanes on consecutive addresses (a whole 128 / 256 B pixel row per 8 / 16 lanes).  In the
+    // accumulator layout a store instruction touched 32 different cache lines for 32 B each (lanes = tiles, 4 pixels apart):
+    // 4x the line touches for the same bytes on the one address path the LDS-DMA loads of the co-resident blocks also need.
+    // The residual quads are requested right behind the K loop: the output transform, its two barriers and 16-32 LDS accesses
+    // per lane cover their latency, and no register is held through the K loop for them (prefetching them before the last
+    // compute phase needs 32 more registers there: 58 spilled at the three-resident budget).
+    constexpr int NQ = HBN / 4, PXT = 4 * HBT;
+    static_assert(PXT * NQ == 2048, "32 KiB output tile");
+    // Every epilogue access is a raw buffer load / store on a block-local descriptor: an invalid piece (ragged M / N) gets an
+    // out-of-range offset instead of a branch -- with divergent branches around them the compiler cannot count vmcnt and put
+    // `s_waitcnt vmcnt(0)` behind every bias load and in front of every store (each store then waited for the previous one to
+    // COMPLETE: 7-11 us of epilogue per block).  A null residual / bias is a descriptor of zero records: it reads as zeros.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB_E = 0x80000000u;
+    const rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        p.res ? (void*)(p.res + (long)(4 * m0) * p.rmap.S1 + p.rmap.off + n0) : (void*)p.out, 0, p.res ? 0x7FFFFF00u : 0u, 0x00020000);
+    const rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (long)(4 * m0) * p.omap.S1 + p.omap.off + n0), 0,
+                                                            0x7FFFFF00u, 0x00020000);
+    const rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)(p.bias + n0) : (void*)p.out, 0,
+                                                             p.bias ? (unsigned)(p.N - n0) * 4u : 0u, 0x00020000);
+    f32x4 rr[8];
+    auto piece_off = [&](int i, long S1) -> unsigned {     // byte offset of piece i * 256 + tid inside the block's output tile
+        const int piece = i * 256 + tid;
+        const int r = piece / NQ;                           // pixel row of the tile, channel quad (undoing the LDS swizzle)
+        const int q = (piece - r * NQ) ^ ((r >> 2) & (NQ - 1));
+        const bool ok = (m0 + (r >> 2)) < p.M && (n0 + 4 * q) < p.N;
+        return ok ? (unsigned)(r * (int)S1 + 4 * q) * 4u : OOB_E;
+    };
+    auto load_epilogue_operands = [&](int half) {          // residual quads 4 half .. 4 half + 3 of this thread
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * (2 * pp + k);
-            bv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < 4; ++o) rr[k][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (n < p.N) {
-                if (p.bias) bv[k] = *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (p.res && t_ok) {
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) rr[k][o] = *reinterpret_cast<const f32x4*>(p.res + r_row + (long)o * p.rmap.S1 + n);
-                }
-            }
-        }
+        for (int i = 4 * half; i < 4 * half + 4; ++i)
+            rr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, p.rmap.S1), 0, 0));
     };
     auto kloop = [&](auto ppc) {
     first_frags(ppc);
@@ -1077,9 +1087,8 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
     for (int k = 0; k < 8; ++k) dbg_ph[k] = 0;
 #endif
 
-    for (int sc = 0; sc < nsc; ++sc) {
-        const bool more = sc + 1 < nsc;
-        if (!more) load_epilogue_operands();
+    auto superchunk = [&](auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
         float* const next_stage = lds + (DB ? STAGE - so : 0);
         if (DB && more) prepare();
 #pragma unroll
@@ -1121,63 +1130,79 @@ __device__ __forceinline__ void wino43s_tile(const GemmArgs& p, const int bid, f
             first_frags(ppc);
             WINO_PHASE(5);
         }
-    }
+    };
+    for (int sc = 0; sc + 1 < nsc; ++sc) superchunk(std::true_type{});
+    // last superchunk peeled: HALF of the residual quads are requested in front of it (its 24 MFMAs and the co-residents hide
+    // their latency; 16 registers that are live only here, not around the loop -- all eight would need 182 registers, two
+    // residents), the other half right behind it, covered by the output transform's two barriers and LDS passes
+    load_epilogue_operands(0);
+    superchunk(std::false_type{});
     };
     if (pp == 0) kloop(std::integral_constant<int, 0>{});
     else kloop(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WINO_STAMP(dbg_t2);
-    __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the exchange buffer
+    // bias first (triple-0 waves need it right behind the barrier): vmcnt retires in order, so a bias load issued BEHIND the
+    // eight residual loads would make its consumer wait for all of them
+    f32x4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)                // (n >= N falls outside the descriptor: zeros)
+        bq[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (unsigned)(wn0 + 8 * g + 4 * fhalf) * 4u, 0, 0));
+    load_epilogue_operands(1);
+    __builtin_amdgcn_s_barrier();              // every wave is done with the superstage: it becomes the output tile
 
-    // epilogue (as wino43_tile): output transform of this wave's triple, exchange with the other triple through LDS, bias /
-    // residual / ReLU, stores.  bv / rr were requested before the last compute phase (load_epilogue_operands).
-    float qf[4][3];                            // A^T columns of this wave's triple, wave-uniform
-    {
-        const float t0[4][3] = {{1.f, 1.f, 1.f}, {0.f, 1.f, -1.f}, {0.f, 1.f, 1.f}, {0.f, 1.f, -1.f}};
-        const float t1[4][3] = {{1.f, 1.f, 0.f}, {2.f, -2.f, 0.f}, {4.f, 4.f, 0.f}, {8.f, -8.f, 1.f}};
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) qf[a][b] = pp == 0 ? t0[a][b] : t1[a][b];
-    }
-    auto partial = [&](int g, int o, int e) -> float {
-        return (qf[o][0] * acc[0][4 * g + e] + qf[o][1] * acc[1][4 * g + e]) + qf[o][2] * acc[2][4 * g + e];
+    // ---- epilogue: output transform of this wave's triple (A^T columns written out per triple, like the input transform)
+    //   triple 0 (m0 m1 m2): y0 += m0 + (m1 + m2)   y1 += m1 - m2         y2 += m1 + m2         y3 += m1 - m2
+    //   triple 1 (m3 m4 m5): y0 += m3 + m4          y1 += 2 (m3 - m4)     y2 += 4 (m3 + m4)     y3 += 8 (m3 - m4) + m5
+    // Triple 0 writes (its part + bias) into the LDS output tile, triple 1 adds its part in place (fixed order), then every
+    // thread finishes its eight row-contiguous quads: + residual, ReLU, store.  Quad q of pixel row r lives at position
+    // q ^ ((r >> 2) & (NQ - 1)) of the row: the 16 lanes of a ds_write_b128 group are 16 different tiles.
+    float* const T = lds;
+    const int tl = wm0 + frow;                                   // this lane's tile inside the block tile
+    auto quad_addr = [&](int g, int o) {
+        const int q = (wn0 >> 2) + 2 * g + fhalf;
+        return T + ((4 * tl + o) * NQ + (q ^ (tl & (NQ - 1)))) * 4;
     };
-    float* const xch = lds;                    // [sub][writer pp][8 slots][64 lanes] f32x4 = 32 KiB (<= the 36 KiB superstage)
-    {
-        float* dst = xch + (((sub * 2 + pp) * 8) * 64 + lane) * 4;
+    auto part = [&](int g, int o, int e) -> float {              // g, o, e compile-time after unrolling
+        const float a0 = acc[0][4 * g + e], a1 = acc[1][4 * g + e], a2 = acc[2][4 * g + e];
+        if (pp == 0) return o == 0 ? a0 + (a1 + a2) : (o == 2 ? a1 + a2 : a1 - a2);
+        return o == 0 ? a0 + a1 : (o == 1 ? 2.f * (a0 - a1) : (o == 2 ? 4.f * (a0 + a1) : __builtin_fmaf(8.f, a0 - a1, a2)));
+    };
+    if (pp == 0) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if ((g >> 1) == pp) continue;
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 f32x4 sv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sv[e] = partial(g, o, e);
-                *reinterpret_cast<f32x4*>(dst + (4 * (g & 1) + o) * 64 * 4) = sv;
+                for (int e = 0; e < 4; ++e) sv[e] = part(g, o, e) + bq[g][e];
+                *reinterpret_cast<f32x4*>(quad_addr(g, o)) = sv;
             }
         }
     }
     __syncthreads();
-    const float* src = xch + (((sub * 2 + (pp ^ 1)) * 8) * 64 + lane) * 4;
+    if (pp == 1) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if ((g >> 1) != pp) continue;
-        const int k = g & 1;
-        const int n = n0 + wn0 + 4 * (lane >> 5) + 8 * g;
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const f32x4 other = *reinterpret_cast<const f32x4*>(src + (4 * k + o) * 64 * 4);
-            f32x4 y;
+            for (int o = 0; o < 4; ++o) {
+                float* q = quad_addr(g, o);
+                f32x4 sv = *reinterpret_cast<const f32x4*>(q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float mine = partial(g, o, e);
-                float sv = (pp == 0 ? mine + other[e] : other[e] + mine) + bv[k][e] + rr[k][o][e];
-                if (p.act == ACT_RELU) sv = fmaxf(sv, 0.f);
-                y[e] = sv;
+                for (int e = 0; e < 4; ++e) sv[e] += part(g, o, e);
+                *reinterpret_cast<f32x4*>(q) = sv;
             }
-            if (t_ok && n < p.N) *reinterpret_cast<f32x4*>(p.out + o_row + (long)o * p.omap.S1 + n) = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f32x4 y = *reinterpret_cast<const f32x4*>(T + (i * 256 + tid) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] += rr[i][e];
+            if (p.act == ACT_RELU) y[e] = fmaxf(y[e], 0.f);
         }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, piece_off(i, p.omap.S1), 0, 0);
     }
 #ifdef CAPF_DIAG
     if (tid == 0 && blockIdx.x < 8192) {
