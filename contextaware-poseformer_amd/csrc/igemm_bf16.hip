@@ -223,25 +223,35 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 rr[TM][TN][2];
     f32x4 bb[TN][2];
+    // Every access of the vector epilogue is a raw buffer load / store on a block-local descriptor; a piece outside a ragged
+    // M / N edge gets an out-of-range offset (reads zeros, store dropped) instead of a branch.  With divergent branches around
+    // them the compiler cannot count vmcnt: it waited `vmcnt(0)` in front of every residual use, i.e. for the PREVIOUS STORE
+    // to complete -- the 2 TM TN stores of a block were serialised round trips.  A null residual / bias is a descriptor of
+    // zero records.
+    constexpr unsigned OOB_E = 0x80000000u;
+    const rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        (Rs && vec_ok) ? (void*)(Rs + (long)m0 * p.rmap.S1 + p.rmap.off + n0) : (void*)Out, 0, (Rs && vec_ok) ? 0x7FFFFF00u : 0u,
+        0x00020000);
+    const rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(Out + (long)m0 * p.omap.S1 + p.omap.off + n0), 0,
+                                                            vec_ok ? 0x7FFFFF00u : 0u, 0x00020000);
+    const rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)(p.bias + n0) : (void*)Out, 0,
+                                                             p.bias ? (unsigned)(p.N - n0) * 4u : 0u, 0x00020000);
+    auto piece_off = [&](int i, int j, int h, int S1) -> unsigned {   // byte offset of this lane's 8 channels inside the block's tile
+        const int ml = wm0 + i * 32 + h * 16 + er, nl = wn0 + j * 32 + ec;
+        return (m0 + ml < p.M && n0 + nl < p.N) ? (unsigned)(ml * S1 + nl) * 2u : OOB_E;
+    };
     auto prefetch_epilogue = [&]() {
         if (!vec_ok) return;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + ec;
-            bb[j][0] = bb[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias && (full || n < p.N)) {
-                bb[j][0] = *reinterpret_cast<const f32x4*>(p.bias + n);
-                bb[j][1] = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-            }
+            const unsigned nb = (unsigned)(wn0 + j * 32 + ec) * 4u;
+            bb[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, nb, 0, 0));
+            bb[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, nb + 16u, 0, 0));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int m = m0 + wm0 + i * 32 + h * 16 + er;
-                    rr[i][j][h] = u32x4{0u, 0u, 0u, 0u};
-                    if (Rs && (full || (m < p.M && n < p.N)))
-                        rr[i][j][h] = *reinterpret_cast<const u32x4*>(Rs + (long)m * p.rmap.S1 + p.rmap.off + n);
-                }
+                for (int h = 0; h < 2; ++h)
+                    rr[i][j][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, h, (int)p.rmap.S1), 0, 0);
         }
     };
 
@@ -410,28 +420,30 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
         constexpr int EPS = 36;                            // padded row stride (floats): b128 accesses stay conflict-free
         if (S != 1) __syncthreads();                       // ring schedule: other waves may still be reading the last stage
         float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
+        auto finish = [&](float t) {
+            if (GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+            if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+            return t;
+        };
+        auto transpose_block = [&](int i, int j) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(&ep[(lane & 31) * EPS + 8 * g + 4 * (lane >> 5)]) =
+                    f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (vec_ok) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn0 + j * 32 + ec;
-                __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(&ep[(lane & 31) * EPS + 8 * g + 4 * (lane >> 5)]) =
-                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < TN; ++j) {
+                    transpose_block(i, j);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = h * 16 + er, m = m0 + wm0 + i * 32 + row;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
-                    auto finish = [&](float t) {
-                        if (GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
-                        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-                        return t;
-                    };
-                    if (vec_ok) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = h * 16 + er;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
                         u32x4 o;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -441,9 +453,22 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                             const float bc = q < 2 ? bb[j][0][2 * q + 1] : bb[j][1][2 * q - 3];
                             o[q] = pack_bf16x2(finish(xa + ba + __uint_as_float(rw << 16)), finish(xb + bc + __uint_as_float(rw & 0xFFFF0000u)));
                         }
-                        if (full || (m < p.M && n < p.N))
-                            *reinterpret_cast<u32x4*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = o;
-                    } else if (m < p.M) {
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, piece_off(i, j, h, (int)p.omap.S1), 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn0 + j * 32 + ec;
+                    transpose_block(i, j);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = h * 16 + er, m = m0 + wm0 + i * 32 + row;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
+                        if (m >= p.M) continue;
                         for (int e = 0; e < 8 && n + e < p.N; ++e) {
                             const float x = e < 4 ? x0[e & 3] : x1[e & 3];
                             const float bsv = p.bias ? p.bias[n + e] : 0.f;
@@ -452,7 +477,7 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                         }
                     }
                 }
-            }
+        }
     }
 #ifdef CAPF_DIAG
     B16_STAMP(dbg_t3);
@@ -556,14 +581,15 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     // so the epilogue needs no bias operand; the loads retire behind the first superchunk's
     const int wm0 = wave * 32 * TM;
     const int frow = lane & 31, fhalf = lane >> 5;
+    const rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)(p.bias + n0) : (void*)Out, 0,
+                                                             p.bias ? (unsigned)(p.N - n0) * 4u : 0u, 0x00020000);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = n0 + j * 32 + 8 * g + 4 * fhalf;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rs_bias, (unsigned)(j * 32 + 8 * g + 4 * fhalf) * 4u, 0, 0));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -585,7 +611,17 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     const int er = lane >> 2, ec = (lane & 3) * 8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 rr[TM][TN][2];
+    // (raw buffer accesses on block-local descriptors, out-of-range offsets instead of branches: see igemm_bf16_tile)
+    const rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        (Rs && vec_ok) ? (void*)(Rs + (long)m0 * p.rmap.S1 + p.rmap.off + n0) : (void*)Out, 0, (Rs && vec_ok) ? 0x7FFFFF00u : 0u,
+        0x00020000);
+    const rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(Out + (long)m0 * p.omap.S1 + p.omap.off + n0), 0,
+                                                            vec_ok ? 0x7FFFFF00u : 0u, 0x00020000);
     auto row_ok = [&](int i_local, int m) { return i_local < BMO && m < p.M; };
+    auto piece_off = [&](int i, int j, int h, int S1) -> unsigned {
+        const int il = wm0 + i * 32 + h * 16 + er, nl = j * 32 + ec;
+        return (row_ok(il, m0 + il) && n0 + nl < p.N) ? (unsigned)(il * S1 + nl) * 2u : OOB;
+    };
     auto prefetch_epilogue = [&]() {
         if (!vec_ok) return;
 #pragma unroll
@@ -593,12 +629,8 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int il = wm0 + i * 32 + h * 16 + er, m = m0 + il, n = n0 + j * 32 + ec;
-                    rr[i][j][h] = u32x4{0u, 0u, 0u, 0u};
-                    if (Rs && row_ok(il, m) && n < p.N)
-                        rr[i][j][h] = *reinterpret_cast<const u32x4*>(Rs + (long)m * p.rmap.S1 + p.rmap.off + n);
-                }
+                for (int h = 0; h < 2; ++h)
+                    rr[i][j][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, h, (int)p.rmap.S1), 0, 0);
     };
 
     bf16x8 af[2][TM], bfr[2][TN];
@@ -654,40 +686,55 @@ __device__ __forceinline__ void igemm_bf16_rh_tile(const GemmArgs& p, const int 
     constexpr int EPS = 36;
     float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
     auto finish = [&](float t) { return p.act == ACT_RELU ? fmaxf(t, 0.f) : t; };
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 32 + ec;
+    auto transpose_block = [&](int i, int j) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(&ep[(lane & 31) * EPS + 8 * g + 4 * (lane >> 5)]) =
                 f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         __builtin_amdgcn_wave_barrier();
+    };
+    if (vec_ok) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = h * 16 + er, il = wm0 + i * 32 + row, m = m0 + il;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
-            if (!row_ok(il, m)) continue;
-            if (vec_ok) {
-                u32x4 o;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned rw = rr[i][j][h][q];
-                    const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
-                    o[q] = pack_bf16x2(finish(xa + __uint_as_float(rw << 16)), finish(xb + __uint_as_float(rw & 0xFFFF0000u)));
-                }
-                if (n < p.N) *reinterpret_cast<u32x4*>(Out + (long)m * p.omap.S1 + p.omap.off + n) = o;
-            } else {
-                for (int e = 0; e < 8 && n + e < p.N; ++e) {
-                    const float x = e < 4 ? x0[e & 3] : x1[e & 3];
-                    const float rsv = Rs ? bf2f(Rs[(long)m * p.rmap.S1 + p.rmap.off + n + e]) : 0.f;
-                    Out[(long)m * p.omap.S1 + p.omap.off + n + e] = f2bf(finish(x + rsv));
+            for (int j = 0; j < TN; ++j) {
+                transpose_block(i, j);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 16 + er;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
+                    u32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned rw = rr[i][j][h][q];
+                        const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+                        o[q] = pack_bf16x2(finish(xa + __uint_as_float(rw << 16)), finish(xb + __uint_as_float(rw & 0xFFFF0000u)));
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, piece_off(i, j, h, (int)p.omap.S1), 0, 0);
                 }
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 32 + ec;
+                transpose_block(i, j);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 16 + er, il = wm0 + i * 32 + row, m = m0 + il;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
+                    if (!row_ok(il, m)) continue;
+                    for (int e = 0; e < 8 && n + e < p.N; ++e) {
+                        const float x = e < 4 ? x0[e & 3] : x1[e & 3];
+                        const float rsv = Rs ? bf2f(Rs[(long)m * p.rmap.S1 + p.rmap.off + n + e]) : 0.f;
+                        Out[(long)m * p.omap.S1 + p.omap.off + n + e] = f2bf(finish(x + rsv));
+                    }
+                }
+            }
     }
 #ifdef CAPF_DIAG
     B16_STAMP(dbg_t3);
