@@ -32,7 +32,7 @@ class CapfConfig(ctypes.Structure):
         ("base_dim", c_int32), ("embed_dim_ratio", c_int32), ("levels", c_int32), ("num_joints", c_int32),
         ("num_heads", c_int32), ("deform_heads", c_int32), ("deform_samples", c_int32), ("context_blocks", c_int32),
         ("compute_dtype", c_int32), ("max_batch", c_int32), ("height", c_int32), ("width", c_int32),
-        ("training", c_int32), ("plan_flags", c_int32),
+        ("training", c_int32), ("plan_flags", c_int32), ("depth", c_int32),
     ]
 
 

@@ -529,8 +529,9 @@ void Engine::build_lifter(const Tensor feats[4]) {
         reg_linear(*this, p + ".mlp.fc1", 2 * dim, dim);
         reg_linear(*this, p + ".mlp.fc2", dim, 2 * dim);
     };
-    for (int i = 0; i < L; ++i) reg_block(V + ".joint_blocks." + std::to_string(i), D);
-    for (int i = 0; i < L; ++i) reg_block(V + ".res_blocks." + std::to_string(i), C);
+    const int DEP = cfg.depth > 0 ? cfg.depth : L;         // blocks per group (ContextPose_mpi pose_dformer.py:199)
+    for (int i = 0; i < DEP; ++i) reg_block(V + ".joint_blocks." + std::to_string(i), D);
+    for (int i = 0; i < DEP; ++i) reg_block(V + ".res_blocks." + std::to_string(i), C);
     if (cfg.context_blocks) {
         for (int i = 0; i < L; ++i) {
             const std::string p = V + ".context_blocks." + std::to_string(i);
@@ -719,7 +720,7 @@ void Engine::build_lifter(const Tensor feats[4]) {
     auto attn_blocks = [&](const std::string& group, const std::string& tag, int dim, long rows_pf, int tokens,
                            int groups_pf) {
         const bool ln_fold = ln_fold_ok(dim);
-        for (int i = 0; i < L; ++i) {
+        for (int i = 0; i < (cfg.depth > 0 ? cfg.depth : L); ++i) {
             const std::string p = V + "." + group + "." + std::to_string(i);
             const std::string n = tag + std::to_string(i);
             if (ln_fold) {
@@ -865,6 +866,11 @@ bool Engine::build() {
     if (cfg.levels != 4 || cfg.num_joints <= 0 || cfg.embed_dim_ratio % (4 * cfg.num_heads) != 0 ||
         cfg.embed_dim_ratio % (4 * cfg.deform_heads) != 0 || cfg.deform_samples != 4 || cfg.deform_heads != 4) {
         err = "unsupported lifter configuration (levels must be 4, 4x4 deformable sampling, embed_dim_ratio % 32 == 0)";
+        return false;
+    }
+    if (cfg.depth != 0 && cfg.depth != cfg.levels && (cfg.depth < 1 || cfg.depth > 8 || cfg.context_blocks || cfg.training)) {
+        err = "depth != levels: 1..8 blocks per group, only for the variant without context blocks (ContextPose_mpi) and only for "
+              "inference plans";
         return false;
     }
     if (cfg.plan_flags & CAPF_PLAN_NO_FUSED_LIFTER) fused_lifter = false;

@@ -14,10 +14,8 @@ class VolumetricTriangulationNet(CA_PF):
             raise NotImplementedError("This backbone is not implemented yet.")     # run_3dhp.py:234-235
         config.model.backbone["type"] = "hrnet_32" if width == 32 else "hrnet_48"
         pf = config.model.poseformer
-        # this variant's PoseTransformer builds `config.depth` blocks per group (pose_dformer.py:199, 217-227), the
-        # engine builds `levels` of them: only depth == levels (the shipped configuration, common/cfg.py:83) is covered
-        if getattr(pf, "depth", pf.levels) != pf.levels:
-            raise NotImplementedError("poseformer.depth ({}) != poseformer.levels ({}) is not supported".format(pf.depth, pf.levels))
+        # this variant's PoseTransformer builds `config.depth` blocks per group (pose_dformer.py:199, 217-227): the engine reads it
+        # from the same key (capf_config.depth; inference plans for depth != levels, the shipped configuration has 4 == 4)
         super().__init__(config, device, compute_dtype=compute_dtype, context_blocks=False)
 
     def forward(self, images, keypoints_2d_cpn, keypoints_2d_cpn_crop):

@@ -50,6 +50,8 @@ def make_capf_config(config, height=256, width=192, context_blocks=True, compute
     c.base_dim = pf.base_dim
     c.embed_dim_ratio = pf.embed_dim_ratio
     c.levels = pf.levels            # depth = config.levels (pose_dformer.py:169)
+    # the sibling app's PoseTransformer builds config.depth blocks per group instead (ContextPose_mpi/model/pose_dformer.py:199)
+    c.depth = 0 if context_blocks else int(getattr(pf, "depth", pf.levels))
     c.num_joints = 17
     c.num_heads = 8
     c.deform_heads = 4
@@ -60,7 +62,8 @@ def make_capf_config(config, height=256, width=192, context_blocks=True, compute
     c.compute_dtype = 1 if compute_dtype == "bf16" else 0
     c.max_batch = MAX_BATCH
     c.height, c.width = height, width
-    c.training = 1                  # workspace also holds what capf_backward needs (6.4 MB/frame)
+    # workspace also holds what capf_backward needs (6.4 MB/frame); the training path is built for depth == levels only
+    c.training = 0 if c.depth not in (0, c.levels) else 1
     c.plan_flags = int(plan_flags)  # 0 = the product plan (capf.lib.PLAN_*: take a kernel family out, parity tests only)
     return c
 

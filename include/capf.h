@@ -60,7 +60,7 @@ typedef struct capf_config {
     int32_t hr_blocks;         /* NUM_BLOCKS per branch: 4 */
     int32_t base_dim;          /* poseformer.base_dim: 32 / 48 / 256(cpn) */
     int32_t embed_dim_ratio;   /* 128 */
-    int32_t levels;            /* 4 (also the depth of every block group, pose_dformer.py:169) */
+    int32_t levels;            /* 4 feature levels (H36M model: also the depth of every block group, pose_dformer.py:169) */
     int32_t num_joints;        /* 17 */
     int32_t num_heads;         /* 8  (Block) */
     int32_t deform_heads;      /* 4  (DeformableBlock, pose_dformer.py:202) */
@@ -72,6 +72,9 @@ typedef struct capf_config {
     int32_t training;          /* 1: size the workspace for capf_forward_train / capf_backward as well */
     int32_t plan_flags;        /* 0 = the product plan.  capf_plan_flag bits take one kernel family out of the plan (parity
                                   tests compare the two routes; nothing else -- no environment variable -- changes a plan) */
+    int32_t depth;             /* blocks per group (res_blocks / joint_blocks).  0 = levels.  The MPI-INF-3DHP variant reads it from
+                                  config.model.poseformer.depth (ContextPose_mpi/model/pose_dformer.py:199, 217-227; 1..8); the H36M
+                                  model has depth == levels by construction, and so does the training path */
 } capf_config;
 
 enum capf_plan_flag {

@@ -185,7 +185,7 @@ def reference_losses():
 MPI_ROOT = "/root/reference/ContextPose_mpi"
 
 
-def build_reference_mpi(backbone="hrnet_32"):
+def build_reference_mpi(backbone="hrnet_32", depth=None):
     """The sibling app's model (ContextPose_mpi/model/conpose.py) with run_3dhp.py:219-235's config patch.
     Its packages are called `model` / `common` (the build's own mirror package is also called `model`)."""
     import contextlib, copy, importlib, io
@@ -198,6 +198,8 @@ def build_reference_mpi(backbone="hrnet_32"):
             c.model.backbone.STAGE4.NUM_CHANNELS = [32, 64, 128, 256]
             c.model.poseformer.base_dim = 32
             c.model.poseformer.embed_dim_ratio = 64
+        if depth is not None:
+            c.model.poseformer.depth = depth          # blocks per group (model/pose_dformer.py:199); common/cfg.py:83 ships 4
         net = importlib.import_module("model.conpose").VolumetricTriangulationNet
         ri.check("common.cfg", "model.conpose")
         with contextlib.redirect_stdout(io.StringIO()):

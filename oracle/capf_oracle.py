@@ -382,7 +382,7 @@ def split_drop_masks(masks, B, J=17, levels=4):
 
 
 def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=False, taps=None,
-                   context_blocks=True, drop_masks=None, emulate_bf16=False):
+                   context_blocks=True, drop_masks=None, emulate_bf16=False, depth=None):
     """PoseTransformer.forward pose_dformer.py:210-241.
 
     k2d [B,17,2], ref [B,17,2] (already normalised), feats: 4 NCHW maps -> [B,1,17,3].
@@ -414,12 +414,13 @@ def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=Fals
             taps["tokens_ctx"] = x
     L = x.shape[1]
     x = x.permute(0, 2, 1, 3).reshape(b * p, L, -1)                          # 'b l p c -> (b p) l c' :231
-    for i in range(levels):
+    depth = levels if depth is None else depth        # ContextPose_mpi/model/pose_dformer.py:199: its own config key there
+    for i in range(depth):
         x = _attn_block(P, f"{pre}.res_blocks.{i}", x, 8, keep=keep["res"][i] if keep else None, nm=nm)   # :233-234
     x = x.reshape(b, p, -1)                                                 # '(b p) l c -> b p (l c)' :235
     if taps is not None:
         taps["tokens_res"] = x
-    for i in range(levels):
+    for i in range(depth):
         x = _attn_block(P, f"{pre}.joint_blocks.{i}", x, 8, keep=keep["joint"][i] if keep else None, nm=nm)   # :237-238
     if taps is not None:
         taps["tokens_joint"] = x

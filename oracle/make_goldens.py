@@ -37,7 +37,7 @@ GRAD_KEYS = ["volume_net.head.1.weight", "volume_net.context_blocks.0.sampling_o
 def run_case_mpi(name, case):
     """ContextPose_mpi/model: outputs only (x [B,3,1,17,1], in-place ref)."""
     torch.set_num_threads(8)
-    model, _ = _refshim.build_reference_mpi(case["backbone"])
+    model, _ = _refshim.build_reference_mpi(case["backbone"], depth=case.get("depth"))
     synth.load_synthetic(model, seed=case["wseed"], bn_mode=case["bn"])
     img, k2d, kc = case_inputs(case)
     kc_io = kc.clone()

@@ -11,6 +11,8 @@ CASES = {
     "cpn_384x288_b1": dict(backbone="cpn", B=1, H=384, W=288, wseed=8, iseed=9, bn="random", crop=(288, 384)),
     # MPI-INF-3DHP variant (ContextPose_mpi): no deformable blocks, embed 64, output [B,3,1,17,1]
     "mpi_w32_e64_b2": dict(backbone="hrnet_32", B=2, H=256, W=192, wseed=12, iseed=13, bn="random", crop=(192, 256), mpi=True),
+    # depth != levels (ContextPose_mpi/model/pose_dformer.py:199): two blocks per group over the four feature levels
+    "mpi_w32_e64_d2_b2": dict(backbone="hrnet_32", B=2, H=256, W=192, wseed=16, iseed=17, bn="random", crop=(192, 256), mpi=True, depth=2),
     # ... and its shipped default: HRNet-48, embed 96 (run_3dhp.py:219-221, common/cfg.py:81-82); B = 2: the reference`s .squeeze() (:240) breaks at B = 1
     "mpi_w48_e96_b2": dict(backbone="hrnet_48", B=2, H=256, W=192, wseed=14, iseed=15, bn="random", crop=(192, 256), mpi=True),
     "cpn_256x192_b1": dict(backbone="cpn", B=1, H=256, W=192, wseed=8, iseed=10, bn="random", crop=(192, 256)),

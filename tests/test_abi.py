@@ -201,7 +201,7 @@ def test_integration_stub_struct_matches_the_header_and_the_binding():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     stub = doc[doc.index("class capf_config(ctypes.Structure)"):doc.index("class CA_PF(nn.Module):")]
     assert re.findall(r'\("(\w+)", ctypes\.c_int32', stub) == bound
-    assert ctypes.sizeof(CapfConfig) == 4 * 23
+    assert ctypes.sizeof(CapfConfig) == 4 * 24
     ctor = re.search(r"c = capf_config\(([^\n]*)\)\s+#", doc).group(1)
     assert len(re.sub(r"\([^)]*\)", "T", ctor).split(",")) == len(bound)
 
@@ -292,3 +292,29 @@ def test_sync_batchnorm_conversion_keeps_the_reference_state_dict():
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == want
     assert sum(isinstance(x, torch.nn.SyncBatchNorm) for x in m.modules()) == 292
     assert not any(p.requires_grad for p in m.backbone.parameters())
+
+
+def test_depth_is_a_plan_parameter_of_the_variant_without_context_blocks():
+    """capf_config.depth (ContextPose_mpi/model/pose_dformer.py:199): blocks per group of the MPI-INF-3DHP lifter.  0 = levels;
+    the H36M model and the training path are built for depth == levels only and say so."""
+    from capf import Engine
+    from capf.lib import CapfError
+    from mvn.models import _native
+
+    def plan(depth, context_blocks, training=0):
+        c = _native.make_capf_config(_cfg("hrnet_32"), 256, 192, context_blocks=context_blocks)
+        c.depth, c.training = depth, training
+        eng = Engine(c, device=None)
+        names = [n for n, _, _ in eng.op_table(2)]
+        schema = [s[0] for s in eng.schema()]
+        eng.close()
+        return names, schema
+
+    for depth, want in ((0, 4), (4, 4), (2, 2), (6, 6)):
+        names, schema = plan(depth, False)
+        assert sum(n.endswith(".qkv") and n.startswith("res") for n in names) == want
+        assert sum(n.endswith(".qkv") and n.startswith("joint") for n in names) == want
+        assert sum(s.endswith("attn.qkv.weight") for s in schema) == 2 * want
+    for bad in ((2, True, 0), (2, False, 1), (9, False, 0), (-1, False, 0)):
+        with pytest.raises(CapfError):
+            plan(*bad)

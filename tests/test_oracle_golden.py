@@ -71,6 +71,8 @@ def _mpi_model(case, device=None):
     from model.conpose import VolumetricTriangulationNet, mpi_preset
     from mvn.utils.cfg import config
     cfg = mpi_preset(copy.deepcopy(config), case["backbone"])
+    if case.get("depth"):
+        cfg.model.poseformer.depth = case["depth"]
     with contextlib.redirect_stdout(io.StringIO()):
         m = VolumetricTriangulationNet(cfg).eval()
     sd = synth.load_synthetic(m, seed=case["wseed"], bn_mode=case["bn"])
@@ -89,7 +91,7 @@ def test_oracle_matches_mpi_variant_golden(name):
     with torch.no_grad():
         ref = oracle.normalise_crop_keypoints_(kc)
         feats = oracle.hrnet_forward(sd, img.permute(0, 3, 1, 2).contiguous())
-        out = oracle.lifter_forward(sd, k2d, ref, feats, context_blocks=False)          # [B,1,17,3]
+        out = oracle.lifter_forward(sd, k2d, ref, feats, context_blocks=False, depth=case.get("depth"))   # [B,1,17,3]
     out = out.view(case["B"], 1, 17, 3, 1).permute(0, 3, 1, 2, 4)
     np.testing.assert_allclose(out.numpy(), g["out"], atol=TOL, rtol=0)
     np.testing.assert_array_equal(kc.numpy(), g["ref"])
