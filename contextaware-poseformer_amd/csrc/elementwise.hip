@@ -106,11 +106,11 @@ hipError_t launch_pack_linear_quad(const float* w, float* Wq, int N, int K, int 
 // Input i has resolution (H >> shift_i, W >> shift_i); nearest upsampling by 2^s reads (h>>s, w>>s).
 // V channels per lane: 4 (fp32 16 B, bf16 8 B) or 8 (bf16, 16 B); pixel arithmetic in 32 bits (B * H * W < 2^31, launcher checks)
 template <bool BF, int V>
-__global__ void fuse_sum_kernel(FuseSumArgs a) {
+__device__ __forceinline__ void fuse_sum_body(const FuseSumArgs& a, const long first, const long stride) {
     constexpr int Q = V / 4;                                  // 4-channel groups per lane
     const int CV = a.C / V, C4 = a.C >> 2;
     const long total = (long)a.B * a.H * a.W * CV;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = first; i < total; i += stride) {
         const unsigned pix = (unsigned)(i / CV);
         const int cv = (int)(i - (long)pix * CV);
         const unsigned row = pix / (unsigned)a.W;
@@ -155,6 +155,26 @@ __global__ void fuse_sum_kernel(FuseSumArgs a) {
     }
 }
 
+template <bool BF, int V>
+__global__ void fuse_sum_kernel(FuseSumArgs a) {
+    fuse_sum_body<BF, V>(a, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+struct FuseGroupArgs {
+    FuseSumArgs p[4];
+    int bstart[5];     // first block of problem i (bstart[n] = grid size)
+    int n;
+};
+template <bool BF, int V>
+__global__ void fuse_sum_group_kernel(FuseGroupArgs g) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.bstart[i]) pi = i;
+    const int nb = g.bstart[pi + 1] - g.bstart[pi];
+    fuse_sum_body<BF, V>(g.p[pi], (long)(blockIdx.x - g.bstart[pi]) * blockDim.x + threadIdx.x, (long)nb * blockDim.x);
+}
+
 hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s) {
     if ((long)a.B * a.H * a.W >= (1L << 31)) return hipErrorInvalidValue;
     const int V = (a.bf16 && a.C % 8 == 0) ? 8 : 4;
@@ -164,6 +184,30 @@ hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s) {
     if (V == 8) hipLaunchKernelGGL((fuse_sum_kernel<true, 8>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.bf16) hipLaunchKernelGGL((fuse_sum_kernel<true, 4>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((fuse_sum_kernel<false, 4>), dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse_sum_group(const FuseSumArgs* a, int n, hipStream_t s) {
+    if (n < 1 || n > 4) return hipErrorInvalidValue;
+    if (n == 1) return launch_fuse_sum(a[0], s);
+    FuseGroupArgs g{};
+    g.n = n;
+    const int V = (a[0].bf16 && a[0].C % 8 == 0) ? 8 : 4;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((long)a[i].B * a[i].H * a[i].W >= (1L << 31) || a[i].bf16 != a[0].bf16) return hipErrorInvalidValue;
+        if (((a[i].bf16 && a[i].C % 8 == 0) ? 8 : 4) != V) return hipErrorInvalidValue;
+        const long total = (long)a[i].B * a[i].H * a[i].W * (a[i].C / V);
+        const long want = (total + 255) / 256;
+        g.p[i] = a[i];
+        g.bstart[i] = blocks;
+        blocks += (int)(want < 8192 ? want : 8192);
+    }
+    g.bstart[n] = blocks;
+    for (int i = n + 1; i < 5; ++i) g.bstart[i] = blocks;
+    if (V == 8) hipLaunchKernelGGL((fuse_sum_group_kernel<true, 8>), dim3(blocks), dim3(256), 0, s, g);
+    else if (a[0].bf16) hipLaunchKernelGGL((fuse_sum_group_kernel<true, 4>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((fuse_sum_group_kernel<false, 4>), dim3(blocks), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 

@@ -120,6 +120,19 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     return a;
 }
 
+FuseSumArgs Engine::fuse_args(const Op& op, int batch) const {
+    FuseSumArgs a{};
+    a.n_in = op.n_in;
+    for (int i = 0; i < op.n_in; ++i) {
+        a.in[i] = op.in[i] >= 0 ? bptr(op.in[i], batch) : nullptr;
+        a.shift[i] = op.shift[i];
+    }
+    a.out = op.out >= 0 ? bptr(op.out, batch) : nullptr;
+    a.B = batch; a.H = op.H; a.W = op.W; a.C = op.C; a.relu = op.relu;
+    a.bf16 = op.bf16;
+    return a;
+}
+
 // one non-control op on stream s
 int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
     auto ptr = [&](int buf) -> float* {
@@ -138,16 +151,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
         }
         case OP_FUSE: {
             if (op.i0 == 1 && !debug) break;
-            FuseSumArgs a{};
-            a.n_in = op.n_in;
-            for (int i = 0; i < op.n_in; ++i) {
-                a.in[i] = ptr(op.in[i]);
-                a.shift[i] = op.shift[i];
-            }
-            a.out = ptr(op.out);
-            a.B = batch; a.H = op.H; a.W = op.W; a.C = op.C; a.relu = op.relu;
-            a.bf16 = op.bf16;
-            HIP_TRY(launch_fuse_sum(a, s));
+            HIP_TRY(launch_fuse_sum(fuse_args(op, batch), s));
             break;
         }
         case OP_MAXPOOL:
@@ -275,13 +279,33 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
             int rc = flush();
             if (rc) return rc;
         }
-        for (int oi : level) {
-            const Op& op = ops[oi];
-            if (op.kind == OP_GEMM && groupable(op, gemm_args(op, batch))) continue;
-            if (op.kind == OP_FUSE && op.i0 == 1 && !debug) continue;
-            if (log) HIP_TRY(log->mark(s, &oi, 1));
-            int rc = exec_op(op, s, batch);
-            if (rc) return rc;
+        {   // the fuse sums of a level (schedule_regions gathers a module's sums in its last level): one launch
+            FuseSumArgs fg[4];
+            int fm[4], nf = 0;
+            for (int oi : level) {
+                const Op& op = ops[oi];
+                if (op.kind != OP_FUSE || (op.i0 == 1 && !debug)) continue;
+                if (nf > 0 && (op.bf16 != ops[fm[0]].bf16 || (op.C % 8 == 0) != (ops[fm[0]].C % 8 == 0))) continue;
+                if (nf == 4) break;
+                fg[nf] = fuse_args(op, batch);
+                fm[nf++] = oi;
+            }
+            if (nf < 2) nf = 0;
+            if (nf) {
+                if (log) HIP_TRY(log->mark(s, fm, nf));
+                HIP_TRY(launch_fuse_sum_group(fg, nf, s));
+            }
+            for (int oi : level) {
+                const Op& op = ops[oi];
+                if (op.kind == OP_GEMM && groupable(op, gemm_args(op, batch))) continue;
+                if (op.kind == OP_FUSE && op.i0 == 1 && !debug) continue;
+                bool done = false;
+                for (int k = 0; k < nf; ++k) done |= fm[k] == oi;
+                if (done) continue;
+                if (log) HIP_TRY(log->mark(s, &oi, 1));
+                int rc = exec_op(op, s, batch);
+                if (rc) return rc;
+            }
         }
     }
     return CAPF_OK;

@@ -228,6 +228,7 @@ struct Engine {
     int repack(hipStream_t s, bool lifter_only = false);
     int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr, LaunchLog* log = nullptr);
     int exec_op(const Op& op, hipStream_t s, int batch);
+    FuseSumArgs fuse_args(const Op& op, int batch) const;
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log);
     GemmArgs gemm_args(const Op& op, int batch) const;
 };

@@ -180,6 +180,8 @@ struct FuseSumArgs {
     int bf16;      // tensors are bf16 (arithmetic stays fp32)
 };
 hipError_t launch_fuse_sum(const FuseSumArgs& a, hipStream_t s);
+// up to 4 independent sums (the outputs of one HRNet fuse module) as ONE launch; same arithmetic per element as launch_fuse_sum
+hipError_t launch_fuse_sum_group(const FuseSumArgs* a, int n, hipStream_t s);
 
 // 3x3 s2 p1 max-pool NHWC (resnet.py:140), bilinear align_corners=True resize NHWC (+ optional add)
 hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,

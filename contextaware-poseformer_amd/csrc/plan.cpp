@@ -853,6 +853,19 @@ void Engine::schedule_regions() {
             }
             max_level = std::max(max_level, level[i - lo]);
         }
+        // A fuse sum nothing else in the region depends on (the HRNet fuse: its outputs are read after the join) moves to the
+        // LAST level, where run_region_grouped issues all of a module's sums as one launch instead of 2-4 small ones.
+        for (int i = lo; i < hi; ++i) {
+            const Op& oi = ops[i];
+            if (oi.kind != OP_FUSE || oi.i0 == 1) continue;
+            bool sink = true;
+            for (int j = i + 1; j < hi && sink; ++j) {
+                const Op& oj = ops[j];
+                for (int b : touched(oj))
+                    if (writes(oi, b) || (reads(oi, b) && writes(oj, b))) { sink = false; break; }
+            }
+            if (sink) level[i - lo] = max_level;
+        }
         region_levels[r].assign(max_level + 1, {});
         for (int i = lo; i < hi; ++i) region_levels[r][level[i - lo]].push_back(i);
     }
