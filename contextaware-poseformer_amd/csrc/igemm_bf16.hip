@@ -1016,6 +1016,192 @@ __global__ __launch_bounds__(256) void igemm_bf16_stem_kernel(GemmArgs p) {
 #endif
 }
 
+// Stem, third version: PERSISTENT blocks with the weights staged once and the next tile's runs in flight while the current
+// tile is multiplied and stored.  The second version above is one latency chain per block -- gather (6 x 16-byte loads per run
+// behind per-quad branches, i.e. one L2 round trip after the other), LDS, 11 MFMAs, 8-byte strided stores -- with only two
+// 70 KiB blocks per CU to hide it: 488 us for CPN's 7x7 at batch 128 (1.3 TB/s; 453 MB out + 170 MB in would take 125 us at
+// 5 TB/s).  Here: 64-pixel tiles (47 KiB of operands + 18 KiB of epilogue scratch: two blocks per CU), every run fetched with
+// raw buffer loads on ONE descriptor over the whole image tensor (a quad outside it, or of a row above / below the image,
+// gets an out-of-range offset; a quad only PARTLY beyond the tensor's end returns its in-range dwords -- range checking is
+// per dword, tools/buffer_oob.hip), so all of a thread's 12 / 3 loads are in flight at once and stay in flight across the
+// MFMAs and the stores of the previous tile; the epilogue transposes through LDS and stores 16 bytes per lane, 64 B
+// contiguous per row.  XCD-aware tile order: each XCD walks its own contiguous eighth of the tiles, so the 7 / 3 input rows
+// that vertically adjacent tiles share are fetched into ONE L2.  Only the handful of runs at the very start of the tensor (negative
+// offsets cannot be expressed) are patched element-wise by the blocks that own those pixels.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_stem_stream_kernel(GemmArgs p, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 64, BN = 64;
+    constexpr int RUN = KS * 3;                      // contiguous floats per (pixel, kh)
+    constexpr int NX4 = RUN / 4;                     // 16-byte loads per run (5 / 2) ...
+    static_assert(RUN % 4 == 1, "... plus ONE dword: a 16-byte load whose upper dwords nobody reads leaves dead destination "
+                                "registers that the allocator reuses -- and a vmcnt(0) in front of that reuse");
+    constexpr int PKH = (RUN + 7) / 8 * 8;           // halves per kh in LDS (24 / 16)
+    constexpr int KP = (KS * PKH + 15) / 16 * 16;    // staged K (176 / 48)
+    constexpr int PITCH = KP + 8;                    // halves per LDS row: 16-byte aligned, conflict-free b128 reads
+    constexpr int NT = (BM * KS + 255) / 256;        // runs per thread and tile (2 / 1)
+    constexpr int EPS = 36;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * PITCH + 4 * 32 * EPS * 2];
+    unsigned short* As = lds;
+    unsigned short* Bs = lds + BM * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* ep = reinterpret_cast<float*>(lds + (BM + BN) * PITCH) + wave * (32 * EPS);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned short* Out = reinterpret_cast<unsigned short*>(p.out);
+    const long total = (long)(p.M / (p.Ho * p.Wo)) * p.H * p.W * 3;              // floats of the image tensor (< 2^29: launcher)
+    const rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)(total * 4), 0x00020000);
+    const rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)p.bias : (void*)Out, 0,
+                                                             p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
+
+    auto put_run = [&](unsigned short* dst, const f32x4 (&q)[NX4], float last, unsigned mask, int kh) {   // RUN values (+ zeros) -> LDS
+        auto val = [&](int e) { return e < NX4 * 4 ? q[e >> 2][e & 3] : (e == NX4 * 4 ? last : 0.f); };
+        unsigned pk[PKH / 2];
+#pragma unroll
+        for (int e = 0; e < PKH / 2; ++e) {
+            const float a = 2 * e < RUN && ((mask >> (2 * e)) & 1u) ? val(2 * e) : 0.f;
+            const float b = 2 * e + 1 < RUN && ((mask >> (2 * e + 1)) & 1u) ? val(2 * e + 1) : 0.f;
+            pk[e] = pack_bf16x2(a, b);
+        }
+#pragma unroll
+        for (int g = 0; g < PKH / 8; ++g)
+            *reinterpret_cast<u32x4*>(dst + kh * PKH + g * 8) = u32x4{pk[4 * g], pk[4 * g + 1], pk[4 * g + 2], pk[4 * g + 3]};
+        if (KP > KS * PKH && kh == KS - 1)                                         // the tail of the last k-step
+            *reinterpret_cast<u32x4*>(dst + KS * PKH) = u32x4{0u, 0u, 0u, 0u};
+    };
+
+    // ---- weights, once per block: runs of the fp32 pack [N][Kpad], K order (kh, kw, c)
+    {
+        const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)p.N * (unsigned)p.Kpad * 4u, 0x00020000);
+        for (int t = tid; t < BN * KS; t += 256) {
+            const int kh = t / BN, n = t - kh * BN;
+            f32x4 q[NX4];
+            const unsigned wo = n < p.N ? (unsigned)(n * p.Kpad + kh * RUN) * 4u : OOB;
+#pragma unroll
+            for (int x = 0; x < NX4; ++x)
+                q[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, n < p.N ? wo + 16u * x : OOB, 0, 0));
+            const float last = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, n < p.N ? wo + 16u * NX4 : OOB, 0, 0));
+            put_run(Bs + n * PITCH, q, last, (1u << RUN) - 1u, kh);
+        }
+    }
+    // XCD-aware persistent walk: XCD x owns tiles [x * per_xcd, (x + 1) * per_xcd); its blocks take them round-robin
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;        // (gridDim.x % 8 == 0: launcher)
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * per_xcd);
+    int tile = xcd * per_xcd + slot;
+
+    f32x4 q[NT][NX4];
+    float qlast[NT];
+    unsigned mask[NT];
+    // run i of this thread; a thread without an i-th run repeats another one (same loads, the same LDS bytes written twice) --
+    // a branch around put_run would leave "maybe pending" loads behind it and cost a vmcnt(0) in front of the next requests
+    auto run_of = [&](int i) { return (tid + 256 * i) % (BM * KS); };
+    auto issue = [&](int tl) {                       // request the runs of tile tl (tl >= t_end: every offset out of range)
+        const int m0 = tl * BM;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = run_of(i);
+            const int kh = t / BM, row = t - kh * BM;
+            const int m = m0 + row;
+            bool ok = tl < t_end && m < p.M;
+            const int mm = ok ? m : 0;
+            const int b = fast_div_b(mm, p.fd_hw), rem = mm - b * p.Ho * p.Wo;
+            const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
+            const int hi = ho * p.stride - p.pad + kh, wi0 = wo * p.stride - p.pad;
+            ok = ok && (unsigned)hi < (unsigned)p.H;
+            const int o = ((b * p.H + hi) * p.W + wi0) * 3;                      // floats from the tensor start (may be < 0 at its start)
+            unsigned mk = 0u;
+#pragma unroll
+            for (int e = 0; e < RUN; ++e)
+                if ((unsigned)(wi0 + e / 3) < (unsigned)p.W) mk |= 1u << e;
+            mask[i] = ok ? mk : 0u;
+#pragma unroll
+            for (int x = 0; x < NX4; ++x)
+                q[i][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rs_in, (ok && o + 4 * x >= 0) ? (unsigned)(o + 4 * x) * 4u : OOB, 0, 0));
+            qlast[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rs_in, (ok && o + 4 * NX4 >= 0) ? (unsigned)(o + 4 * NX4) * 4u : OOB, 0, 0));
+        }
+    };
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int er = lane >> 2, ec = (lane & 3) * 8;
+    const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (unsigned)(wn0 + ec) * 4u, 0, 0));
+    const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (unsigned)(wn0 + ec + 4) * 4u, 0, 0));
+
+    issue(tile);
+    {   // two dropped stores: the loop is entered with the same "loads, then two stores" in flight as its back edge leaves, so the
+        // wait in front of the LDS writes is a counted vmcnt(2) -- not a vmcnt(0) that would sit out the previous tile's stores
+        const rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)Out, 0, 0u, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rs_none, OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rs_none, OOB, 0, 0);
+    }
+    for (; tile < t_end; tile += nslots) {
+        const int m0 = tile * BM;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = run_of(i);
+            const int kh = t / BM, row = t - kh * BM;
+            put_run(As + row * PITCH, q[i], qlast[i], mask[i], kh);
+        }
+        const int ho_max = p.pad / p.stride;           // output rows (of frame 0) with a window row on input row 0
+        if (m0 < (ho_max + 1) * p.Wo) {
+            // Frame 0, input row 0, window starting left of the image: the run begins at a NEGATIVE offset from the tensor start,
+            // which a buffer offset cannot express -- its first quads were requested out of range above.  The few such runs
+            // (output rows ho = (pad - kh) / stride, columns wo * stride < pad) are rewritten here element by element.
+            __syncthreads();
+            const int nw = min(p.Wo, (p.pad + p.stride - 1) / p.stride);
+            for (int idx = tid; idx < (ho_max + 1) * nw * PKH; idx += 256) {
+                const int e = idx % PKH, r = idx / PKH, wo = r % nw, ho = r / nw;
+                const int kh = p.pad - ho * p.stride, m = ho * p.Wo + wo;
+                if (kh >= 0 && kh < KS && m >= m0 && m < m0 + BM) {
+                    const int wi = wo * p.stride - p.pad + e / 3;
+                    float v = 0.f;
+                    if (e < RUN && (unsigned)wi < (unsigned)p.W) v = p.A[wi * 3 + e % 3];
+                    As[(m - m0) * PITCH + kh * PKH + e] = f2bf(v);
+                }
+            }
+        }
+        __syncthreads();
+        issue(tile + nslots);                         // in flight across this tile's MFMAs and stores
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int step = 0; step < KP / 16; ++step) {
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Bs[(wn0 + frow) * PITCH + step * 16 + fhalf * 8]));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&As[(wm0 + frow) * PITCH + step * 16 + fhalf * 8]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc, 0, 0, 0);
+        }
+        // transposed accumulator (lane = row, register group g = channels 8 g + 4 fhalf ..) -> LDS -> 8 channels of a row per lane
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(&ep[frow * EPS + 8 * g + 4 * fhalf]) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        __builtin_amdgcn_wave_barrier();
+        const rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(Out + (long)m0 * p.omap.S1 + p.omap.off), 0, 0x7FFFFF00u, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 16 + er, ml = wm0 + row, nl = wn0 + ec;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec + 4]);
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { t[e] = x0[e] + b0[e]; t[4 + e] = x1[e] + b1[e]; }
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
+            }
+            const u32x4 o = u32x4{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (m0 + ml < p.M && nl < p.N) ? (unsigned)(ml * (int)p.omap.S1 + nl) * 2u : OOB, 0, 0);
+        }
+        __syncthreads();                              // every wave has read As: the next tile's runs may overwrite it
+    }
+#endif
+}
+
 // fp32 NHWC image (Cin % 4 != 0), fp32 packed weights [N][Kpad32], bf16 NHWC result; no residual.
 bool gemm_bf16_smallc_ok(const GemmArgs& a) {
     return a.conv && a.out_bf16 && !a.res && a.omap.G == 1 && a.N % 4 == 0 && a.omap.S1 % 4 == 0 && a.omap.off % 4 == 0 &&
@@ -1030,16 +1216,34 @@ static int stem_runs_ks(const GemmArgs& a) {     // 7 / 3: the run-based stem ke
     return 0;
 }
 
-const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a) { return stem_runs_ks(a) ? "igemm_bf16_stem<w4,128x64>" : "igemm_bf16_smallc<w4,128x64>"; }
+// the persistent streaming stem: one 64-column tile, 8-channel vector stores, 32-bit float offsets into the image tensor
+static bool stem_stream_ok(const GemmArgs& a) {
+    static const int on = [] { const char* e = diag_env("CAPF_STEM_STREAM"); return e ? atoi(e) : 1; }();        // A/B runs only
+    const long total = (long)(a.M / (a.Ho * a.Wo)) * a.H * a.W * 3;
+    return on && a.N <= 64 && a.N % 8 == 0 && a.omap.S1 % 8 == 0 && a.omap.off % 8 == 0 && total < (1L << 29) && a.Wo >= 4;
+}
+
+const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a) {
+    if (!stem_runs_ks(a)) return "igemm_bf16_smallc<w4,128x64>";
+    return stem_stream_ok(a) ? "igemm_bf16_stem_stream<w4,64x64>" : "igemm_bf16_stem<w4,128x64>";
+}
 
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a_in, hipStream_t s) {
     if (!gemm_bf16_smallc_ok(a_in)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.fd_hw = make_fastdiv((unsigned)(a.Ho * a.Wo));
     a.fd_wo = make_fastdiv((unsigned)a.Wo);
+    const int ks = stem_runs_ks(a);
+    if (ks && stem_stream_ok(a)) {
+        const int ntiles = (a.M + 63) / 64;
+        int blocks = 512;                              // two per CU
+        while (blocks > 8 && blocks / 2 >= ntiles) blocks /= 2;
+        if (ks == 7) hipLaunchKernelGGL((igemm_bf16_stem_stream_kernel<7>), dim3(blocks), dim3(256), 0, s, a, ntiles);
+        else hipLaunchKernelGGL((igemm_bf16_stem_stream_kernel<3>), dim3(blocks), dim3(256), 0, s, a, ntiles);
+        return hipGetLastError();
+    }
     const dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64));
     // (64-pixel tiles -- 47 KiB, three blocks per CU for the 7x7 -- measured slower: 0.50 -> 0.59 ms for CPN, 0.30 -> 0.35 for HRNet)
-    const int ks = stem_runs_ks(a);
     if (ks == 7) hipLaunchKernelGGL((igemm_bf16_stem_kernel<7, 128>), grid, dim3(256), 0, s, a);
     else if (ks == 3) hipLaunchKernelGGL((igemm_bf16_stem_kernel<3, 128>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(igemm_bf16_smallc_kernel, grid, dim3(256), 0, s, a);

@@ -46,6 +46,9 @@ def short(name):
     m = re.match(r"(?:void )?capf::igemm_bf16_rh_kernel", name)
     if m:
         return "igemm_bf16_rh<w4,126x64,conv>"
+    m = re.match(r"(?:void )?capf::igemm_bf16_stem_stream_kernel", name)
+    if m:
+        return "igemm_bf16_stem_stream<w4,64x64>"
     m = re.match(r"(?:void )?capf::igemm_bf16_stem_kernel", name)
     if m:
         return "igemm_bf16_stem<w4,128x64>"
