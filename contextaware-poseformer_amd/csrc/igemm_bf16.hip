@@ -1058,11 +1058,16 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_stem_stream_kernel(GemmArgs
     auto put_run = [&](unsigned short* dst, const f32x4 (&q)[NX4], float last, unsigned mask, int kh) {   // RUN values (+ zeros) -> LDS
         auto val = [&](int e) { return e < NX4 * 4 ? q[e >> 2][e & 3] : (e == NX4 * 4 ? last : 0.f); };
         unsigned pk[PKH / 2];
+        if (mask == (1u << RUN) - 1u) {              // interior pixel (all but ~1 run in 70): no per-element selects
 #pragma unroll
-        for (int e = 0; e < PKH / 2; ++e) {
-            const float a = 2 * e < RUN && ((mask >> (2 * e)) & 1u) ? val(2 * e) : 0.f;
-            const float b = 2 * e + 1 < RUN && ((mask >> (2 * e + 1)) & 1u) ? val(2 * e + 1) : 0.f;
-            pk[e] = pack_bf16x2(a, b);
+            for (int e = 0; e < PKH / 2; ++e) pk[e] = pack_bf16x2(2 * e < RUN ? val(2 * e) : 0.f, 2 * e + 1 < RUN ? val(2 * e + 1) : 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < PKH / 2; ++e) {
+                const float a = 2 * e < RUN && ((mask >> (2 * e)) & 1u) ? val(2 * e) : 0.f;
+                const float b = 2 * e + 1 < RUN && ((mask >> (2 * e + 1)) & 1u) ? val(2 * e + 1) : 0.f;
+                pk[e] = pack_bf16x2(a, b);
+            }
         }
 #pragma unroll
         for (int g = 0; g < PKH / 8; ++g)
@@ -1111,10 +1116,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_stem_stream_kernel(GemmArgs
             const int hi = ho * p.stride - p.pad + kh, wi0 = wo * p.stride - p.pad;
             ok = ok && (unsigned)hi < (unsigned)p.H;
             const int o = ((b * p.H + hi) * p.W + wi0) * 3;                      // floats from the tensor start (may be < 0 at its start)
-            unsigned mk = 0u;
-#pragma unroll
-            for (int e = 0; e < RUN; ++e)
-                if ((unsigned)(wi0 + e / 3) < (unsigned)p.W) mk |= 1u << e;
+            // elements 3 lo .. 3 hn - 1 of the run lie inside the image row
+            const int lo = max(0, -wi0), hn = max(lo, min(KS, p.W - wi0));
+            const unsigned mk = ((1u << (3 * hn)) - 1u) & ~((1u << (3 * lo)) - 1u);
             mask[i] = ok ? mk : 0u;
 #pragma unroll
             for (int x = 0; x < NX4; ++x)
