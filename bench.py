@@ -79,7 +79,8 @@ def parse(argv=None):
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
     ap.add_argument("--lanes", type=int, default=-1,
-                    help="independent backbone branches: 2 grouped launches (default), 1 side streams, 0 program order")
+                    help="independent backbone branches: 3 two grouped chains on two streams (default), 2 one grouped chain, 1 side streams, "
+                         "0 program order")
     ap.add_argument("--overlap", type=int, default=2,
                     help="inference, rank 0 at N=1: after the contract's one-batch-at-a-time measurement, ALSO time the same K steps "
                          "issued round-robin over this many engines (own workspaces, own HIP streams) so that consecutive batches "

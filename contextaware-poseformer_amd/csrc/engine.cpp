@@ -240,7 +240,8 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
 // topological order is valid on a single stream, and no two buffers of a region share memory
 // (assign_offsets keeps them alive for the whole region).  With `log` every launch is bracketed by
 // events (profiling): log gets (event index, leader op) pairs and member ops point at their leader.
-int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log) {
+int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask) {
+    auto mine = [&](const Op& op) { return ((lane_mask >> op.lane) & 1u) != 0; };
     auto groupable = [&](const Op& op, const GemmArgs& a) {
         if (op.kind != OP_GEMM) return false;
         if (op.bf16) return gemm_bf16_groupable(a);
@@ -267,7 +268,7 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
             };
             for (int oi : level) {
                 const Op& op = ops[oi];
-                if (op.kind != OP_GEMM) continue;
+                if (op.kind != OP_GEMM || !mine(op)) continue;
                 const int kind = op.bf16 ? 1 : (wino_now(op, batch) ? 2 : 0);
                 if (kind != pass) continue;
                 const GemmArgs a = gemm_args(op, batch);
@@ -284,7 +285,7 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
             int fm[4], nf = 0;
             for (int oi : level) {
                 const Op& op = ops[oi];
-                if (op.kind != OP_FUSE || (op.i0 == 1 && !debug)) continue;
+                if (op.kind != OP_FUSE || (op.i0 == 1 && !debug) || !mine(op)) continue;
                 if (nf > 0 && (op.bf16 != ops[fm[0]].bf16 || (op.C % 8 == 0) != (ops[fm[0]].C % 8 == 0))) continue;
                 if (nf == 4) break;
                 fg[nf] = fuse_args(op, batch);
@@ -297,6 +298,7 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
             }
             for (int oi : level) {
                 const Op& op = ops[oi];
+                if (!mine(op)) continue;
                 if (op.kind == OP_GEMM && groupable(op, gemm_args(op, batch))) continue;
                 if (op.kind == OP_FUSE && op.i0 == 1 && !debug) continue;
                 bool done = false;
@@ -315,7 +317,7 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
 // the product schedule (grouped launches included).
 int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev, LaunchLog* log) {
     hipStream_t main_stream = s;
-    const bool grouped = lanes == 2 && !ev;
+    const bool grouped = (lanes == 2 || lanes == 3) && !ev;
     const bool par = lanes == 1 && !ev && !log && side[0];
     for (int oi = first_op; oi < last_op; ++oi) {
         const Op& op = ops[oi];
@@ -324,6 +326,25 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
         switch (op.kind) {
             case OP_FORK:
                 if (grouped && regions[op.region].second <= last_op) {
+                    // lanes == 3: the lanes of a region as TWO grouped chains on two streams (lanes 0 + 3 on the caller's, 1 + 2 on a
+                    // side stream), so that one chain's launch ramp / tail overlaps the other's body.  Measured at batch 64 (one
+                    // box, frames/s): one chain 6418; {0,3}|{1,2} 6497; {0,1}|{2,3} 5964; {0,2}|{1,3} 6101; {0,1,2}|{3} 6149;
+                    // {0}|{1,2,3} 6398.  Across the configurations: cfg1 +0.4..1.2 %, cfg2 +0.9 %, cfg4 +1.3 %, but -0.8 % at batch 512 (every launch already fills
+                    // the chip many times over), and below batch 16 a region is a handful of tiles (and may use the split-K scratch):
+                    // one chain outside 16..256.
+                    const bool two = lanes == 3 && !log && side[0] && op.i0 >= 2 && batch >= 16 && batch <= 256;
+                    if (two) {
+                        HIP_TRY(hipEventRecord(events[op.i1], main_stream));
+                        HIP_TRY(hipStreamWaitEvent(side[0], events[op.i1], 0));
+                        int rc = run_region_grouped(side[0], batch, op.region, nullptr, 0x6u);
+                        if (rc) return rc;
+                        rc = run_region_grouped(main_stream, batch, op.region, nullptr, ~0x6u);
+                        if (rc) return rc;
+                        HIP_TRY(hipEventRecord(events[op.i1 + 1], side[0]));
+                        HIP_TRY(hipStreamWaitEvent(main_stream, events[op.i1 + 1], 0));
+                        oi = regions[op.region].second;
+                        break;
+                    }
                     int rc = run_region_grouped(main_stream, batch, op.region, log);
                     if (rc) return rc;
                     oi = regions[op.region].second;      // continue after the join
@@ -499,7 +520,7 @@ int capf_set_workspace(capf_handle* h, void* dev_ptr, size_t bytes) {
 
 int capf_set_lanes(capf_handle* h, int on) {
     if (!h) return CAPF_ERR_INVALID;
-    if (on < 0 || on > 2) return CAPF_ERR_INVALID;
+    if (on < 0 || on > 3) return CAPF_ERR_INVALID;
     h->e.lanes = on;
     return CAPF_OK;
 }

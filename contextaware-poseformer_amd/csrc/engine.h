@@ -177,7 +177,8 @@ struct Engine {
     bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)
     bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)
-    int lanes = 2;                 // fork/join regions: 0 in program order, 1 on side streams, 2 as grouped launches (capf_set_lanes)
+    int lanes = 3;                 // fork/join regions: 0 in program order, 1 one side stream per lane, 2 grouped launches on one stream,
+                                   // 3 grouped launches as two chains on two streams (capf_set_lanes)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> events;
     int last_batch = 0;
@@ -229,7 +230,7 @@ struct Engine {
     int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr, LaunchLog* log = nullptr);
     int exec_op(const Op& op, hipStream_t s, int batch);
     FuseSumArgs fuse_args(const Op& op, int batch) const;
-    int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log);
+    int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
     GemmArgs gemm_args(const Op& op, int batch) const;
 };
 

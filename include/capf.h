@@ -176,9 +176,11 @@ int capf_lifter_forward(capf_handle* h, void* stream, const float* k2d, float* k
  * fused outputs, the CPN refine cascades) are issued:
  *   0 = everything in program order on the caller's stream;
  *   1 = on library-owned side streams, forked from / joined to the caller's stream with events;
- *   2 = (default) by dependency level on the caller's stream, the convolutions of a level sharing ONE
- *       grouped launch.
- * The results are bit-identical in all three modes. */
+ *   2 = by dependency level on the caller's stream, the convolutions of a level sharing ONE grouped launch;
+ *   3 = (default) as 2, but at batch 16..256 the lanes of a region form TWO such chains -- lanes 0 + 3 on the caller's stream,
+ *       1 + 2 on a library-owned side stream (fork / join with events) -- so that one chain's launch ramp and tail overlap
+ *       the other's body.
+ * The results are bit-identical in modes 0, 2 and 3 (mode 1 has no split-K scratch: equal to roundoff at small batches). */
 int capf_set_lanes(capf_handle* h, int on);
 
 /* When on, forward also snapshots the token buffer after each block group (tok_ctx/tok_res/tok_joint). */
@@ -332,8 +334,8 @@ int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* 
  * capf_forward_profile: capf_forward with a hipEvent pair recorded on `stream` around every launch;
  *   synchronises the stream and writes the elapsed milliseconds per op into op_ms[0..n_ops).  Every op is
  *   launched on its own, in program order (capf_set_lanes is ignored).
- * capf_forward_profile_launches: the same for the PRODUCT schedule (capf_set_lanes 0 or 2; side streams are
- *   not used): one event pair per launch.  op_leader[i] = first op of the launch op i rode in (-1: not
+ * capf_forward_profile_launches: the same for the PRODUCT schedule (capf_set_lanes 0 or 2 / 3; side streams are
+ *   not used: mode 3 is timed as its one-chain form): one event pair per launch.  op_leader[i] = first op of the launch op i rode in (-1: not
  *   launched); op_ms[i] = elapsed ms of that launch if i is a leader, else 0.  A grouped launch therefore
  *   shows up as one time for several ops.                                                              */
 int capf_num_ops(const capf_handle* h);

@@ -338,6 +338,38 @@ def test_engine_modes_are_bit_identical(dtype, backbone):
     assert (outs[0] - outs[1]).abs().max().item() <= (2e-6 if dtype == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("dtype,backbone", [("fp32", "hrnet_32"), ("bf16", "hrnet_48"), ("bf16", "cpn")])
+def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone):
+    """capf_set_lanes 3 (the default at batch 16..256: a region's lanes as two grouped chains on two streams, fork / join with
+    events) against mode 2 (one chain on the caller's stream) at batch 24: same kernels on the same operands, only their
+    grouping and their stream differ -> the same bits, call after call (a missing event dependency would show up as a
+    run-to-run difference)."""
+    import copy, contextlib, io
+    from capf import synth
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), backbone)
+    cfg.model.backbone.fix_weights = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = CA_PF(cfg, compute_dtype=dtype).eval()
+    synth.load_synthetic(model, seed=3, bn_mode="random")
+    model = model.cuda()
+    img, k2d, kc = synth.synth_inputs(24, 256, 192, seed=5, crop_range=(192, 256))
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    eng_out = {}
+    with torch.no_grad():
+        for mode in (2, 3, 3, 2, 3):
+            eng = model.engine_for(img)
+            eng.set_lanes(mode)
+            out = model(img, k2d, kc.clone()).clone()
+            maps = [eng.tensor(f"feat{l}").clone() for l in range(4)]
+            if not eng_out:
+                eng_out = {"out": out, "maps": maps}
+            assert torch.equal(out, eng_out["out"]), f"mode {mode}"
+            for a, b in zip(maps, eng_out["maps"]):
+                assert torch.equal(a, b), f"mode {mode}"
+
+
 def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
     """The engine's bf16 grouped launch (igemm_bf16_group_kernel) against single bf16 launches: run the
     backbone of a bf16 model with capf_set_lanes 0 and 2 and compare the four context maps bit for bit."""
