@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_stem_stream_kernel(GemmArgs
         // wait in front of the LDS writes is a counted vmcnt(2) -- not a vmcnt(0) that would sit out the previous tile's stores
         const rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)Out, 0, 0u, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rs_none, OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rs_none, OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rs_none, OOB + 16u, 0, 0);   // (distinct: identical stores are merged)
     }
     for (; tile < t_end; tile += nslots) {
         const int m0 = tile * BM;

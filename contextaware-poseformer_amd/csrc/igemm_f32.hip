@@ -767,6 +767,162 @@ __global__ __launch_bounds__(256) void igemm_f32_smallc_kernel(GemmArgs p) {
 }
 
 // =====================================================================================================
+// The 3x3 / stride-2 fp32 stem as a persistent streaming kernel -- the fp32 twin of igemm_bf16_stem_stream_kernel
+// (igemm_bf16.hip, where the scheme is described): weights staged once per block, the next 64-pixel tile's runs (for a fixed
+// (pixel, kh) the 9 input floats are contiguous in the NHWC image: two 16-byte loads + one dword, raw buffer loads with
+// out-of-range offsets instead of branches) in flight across the MFMAs and stores of the current tile, LDS-transposed 16-byte
+// stores (128 B contiguous per row), XCD-contiguous tile walk.  K in LDS = (kh, 12): 9 values + 3 zeros per kh, 40 staged
+// floats per row.  The element-wise kernel above moved 2.0 TB/s at batch 64 (155 us for 268 MB out + 50 MB in).
+// =====================================================================================================
+template <int KS>
+__global__ __launch_bounds__(256, 2) void igemm_f32_stem_stream_kernel(GemmArgs p, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 64, BN = 64;
+    constexpr int RUN = KS * 3, NX4 = RUN / 4;      // 9 floats = 2 quads + 1 dword
+    static_assert(RUN % 4 == 1, "one dword behind the quads (a 16-byte load with dead upper dwords costs a vmcnt(0))");
+    constexpr int PKH = (RUN + 3) / 4 * 4;          // floats per kh in LDS (12)
+    constexpr int KP = (KS * PKH + 7) / 8 * 8;      // staged K (40)
+    constexpr int SP = KP + 4;                      // floats per LDS row: conflict-free b128 reads
+    constexpr int EPS = 36;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(BM * KS <= 256, "one run per thread");
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * SP + 4 * 32 * EPS];
+    float* As = lds;
+    float* Bs = lds + BM * SP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* ep = lds + (BM + BN) * SP + wave * (32 * EPS);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const long total = (long)(p.M / (p.Ho * p.Wo)) * p.H * p.W * 3;              // floats of the image tensor (< 2^29: launcher)
+    const rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)(total * 4), 0x00020000);
+    const rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)p.bias : (void*)p.out, 0,
+                                                             p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
+    auto ldq = [&](rsrc_t r, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
+    auto ldd = [&](rsrc_t r, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); };
+    auto put_run = [&](float* dst, const f32x4 (&q)[NX4], float last, unsigned mask, int kh) {
+        auto val = [&](int e) { return e < NX4 * 4 ? q[e >> 2][e & 3] : (e == NX4 * 4 ? last : 0.f); };
+#pragma unroll
+        for (int g = 0; g < PKH / 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (4 * g + e < RUN && ((mask >> (4 * g + e)) & 1u)) ? val(4 * g + e) : 0.f;
+            *reinterpret_cast<f32x4*>(dst + kh * PKH + 4 * g) = v;
+        }
+        if (KP > KS * PKH && kh == KS - 1) *reinterpret_cast<f32x4*>(dst + KS * PKH) = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    {   // weights, once per block: runs of the fp32 pack [N][Kpad], K order (kh, kw, c)
+        const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)p.N * (unsigned)p.Kpad * 4u, 0x00020000);
+        for (int t = tid; t < BN * KS; t += 256) {
+            const int kh = t / BN, n = t - kh * BN;
+            const unsigned wo = n < p.N ? (unsigned)(n * p.Kpad + kh * RUN) * 4u : OOB;
+            f32x4 q[NX4];
+#pragma unroll
+            for (int x = 0; x < NX4; ++x) q[x] = ldq(rs_w, n < p.N ? wo + 16u * x : OOB);
+            const float last = ldd(rs_w, n < p.N ? wo + 16u * NX4 : OOB);
+            put_run(Bs + n * SP, q, last, (1u << RUN) - 1u, kh);
+        }
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * per_xcd);
+    int tile = xcd * per_xcd + slot;
+
+    f32x4 q[NX4];
+    float qlast;
+    unsigned mask;
+    const int t_run = tid % (BM * KS);              // (threads beyond the 192 runs repeat one: same loads, same LDS bytes)
+    const int r_kh = t_run / BM, r_row = t_run - r_kh * BM;
+    auto issue = [&](int tl) {
+        const int m = tl * BM + r_row;
+        bool ok = tl < t_end && m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = fast_div(mm, p.fd_hw), rem = mm - b * p.Ho * p.Wo;
+        const int ho = fast_div(rem, p.fd_wo), wo = rem - ho * p.Wo;
+        const int hi = ho * p.stride - p.pad + r_kh, wi0 = wo * p.stride - p.pad;
+        ok = ok && (unsigned)hi < (unsigned)p.H;
+        const int o = ((b * p.H + hi) * p.W + wi0) * 3;
+        const int lo = max(0, -wi0), hn = max(lo, min(KS, p.W - wi0));
+        mask = ok ? (((1u << (3 * hn)) - 1u) & ~((1u << (3 * lo)) - 1u)) : 0u;
+#pragma unroll
+        for (int x = 0; x < NX4; ++x) q[x] = ldq(rs_in, (ok && o + 4 * x >= 0) ? (unsigned)(o + 4 * x) * 4u : OOB);
+        qlast = ldd(rs_in, (ok && o + 4 * NX4 >= 0) ? (unsigned)(o + 4 * NX4) * 4u : OOB);
+    };
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int frow = lane & 31, fhalf = lane >> 5, fk = fhalf * 4;
+    const int er = lane >> 3, ec = (lane & 7) * 4;          // epilogue: 8 lanes x 16 B = one 128-B row of the wave's 32 channels
+    const f32x4 bv = ldq(rs_bias, (unsigned)(wn0 + ec) * 4u);
+
+    issue(tile);
+    {   // four dropped stores: the loop is entered with the same "loads, then four stores" in flight as its back edge leaves
+        const rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0u, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)                 // (distinct offsets: identical stores would be merged into one)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rs_none, OOB + 16u * k, 0, 0);
+    }
+    for (; tile < t_end; tile += nslots) {
+        const int m0 = tile * BM;
+        put_run(As + r_row * SP, q, qlast, mask, r_kh);
+        const int ho_max = p.pad / p.stride;
+        if (m0 < (ho_max + 1) * p.Wo) {             // frame 0, input row 0, window left of the image: negative tensor offsets
+            __syncthreads();
+            const int nw = min(p.Wo, (p.pad + p.stride - 1) / p.stride);
+            for (int idx = tid; idx < (ho_max + 1) * nw * PKH; idx += 256) {
+                const int e = idx % PKH, r = idx / PKH, wo = r % nw, ho = r / nw;
+                const int kh = p.pad - ho * p.stride, m = ho * p.Wo + wo;
+                if (kh >= 0 && kh < KS && m >= m0 && m < m0 + BM) {
+                    const int wi = wo * p.stride - p.pad + e / 3;
+                    float v = 0.f;
+                    if (e < RUN && (unsigned)wi < (unsigned)p.W) v = p.A[wi * 3 + e % 3];
+                    As[(m - m0) * SP + kh * PKH + e] = v;
+                }
+            }
+        }
+        __syncthreads();
+        issue(tile + nslots);
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KP; kk += 8) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm0 + frow) * SP + kk + fk]);
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(wn0 + frow) * SP + kk + fk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[e], af[e], acc, 0, 0, 0);
+        }
+        // transposed accumulator: lane = row m (lane & 31), register 4 g + e = channel 8 g + 4 fhalf + e
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(&ep[frow * EPS + 8 * g + 4 * fhalf]) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        __builtin_amdgcn_wave_barrier();
+        const rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (long)m0 * p.omap.S1 + p.omap.off), 0, 0x7FFFFF00u, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int row = h * 8 + er, ml = wm0 + row, nl = wn0 + ec;
+            f32x4 x = *reinterpret_cast<const f32x4*>(&ep[row * EPS + ec]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] += bv[e];
+                if (p.act == ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs_out,
+                                                   (m0 + ml < p.M && nl < p.N) ? (unsigned)(ml * (int)p.omap.S1 + nl) * 4u : OOB, 0, 0);
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+static bool stem_stream_f32_ok(const GemmArgs& a) {
+    static const int on = [] { const char* e = diag_env("CAPF_STEM_STREAM"); return e ? atoi(e) : 1; }();        // A/B runs only
+    const long total = (long)(a.M / (a.Ho * a.Wo)) * a.H * a.W * 3;
+    return on && a.conv && a.Cin == 3 && a.ks == 3 && a.pad == 1 && a.K == 27 && a.Kpad >= 2 * 9 + 12 && !a.res && !a.out_bf16 &&
+           !a.rscale && a.act != ACT_GELU && a.omap.G == 1 && a.rmap.G <= 1 && a.N <= 64 && a.N % 4 == 0 && a.omap.S1 % 4 == 0 &&
+           a.omap.off % 4 == 0 && total < (1L << 29) && a.Wo >= 4;
+}
+
+// =====================================================================================================
 // host side: tile selection + launch
 // =====================================================================================================
 FastDiv make_fastdiv(unsigned d) {
@@ -827,7 +983,8 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
             for (int m = 0; m < 2; ++m) snprintf(buf[t][m], sizeof(buf[t][m]), "igemm_f32<%s,%s>", kTileNames[t], modes[m]);
         init = true;
     }
-    if (a.conv && a.Cin % 4 != 0) return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : "igemm_f32_smallc<w4,128x64>";
+    if (a.conv && a.Cin % 4 != 0)
+        return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : (stem_stream_f32_ok(a) ? "igemm_f32_stem_stream<w4,64x64>" : "igemm_f32_smallc<w4,128x64>");
     if (gemm_f32_pw_ok(a)) return gemm_f32_pw_kernel_name();
     return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
@@ -1017,6 +1174,13 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
         if (!prep_conv(a)) return hipErrorInvalidValue;
         if (a.Cin % 4 != 0) {
             if (stem_on_bf16(a)) return launch_gemm_bf16_smallc(a, s);
+            if (stem_stream_f32_ok(a)) {
+                const int ntiles = (a.M + 63) / 64;
+                int blocks = 512;                          // two per CU
+                while (blocks > 8 && blocks / 2 >= ntiles) blocks /= 2;
+                hipLaunchKernelGGL((igemm_f32_stem_stream_kernel<3>), dim3(blocks), dim3(256), 0, s, a, ntiles);
+                return hipGetLastError();
+            }
             dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64)), block(256);
             hipLaunchKernelGGL((igemm_f32_smallc_kernel<128, 64, 64, 32>), grid, block, 0, s, a);
             return hipGetLastError();

@@ -338,7 +338,31 @@ def _attn_block(P, pre, x, heads, keep=None, nm=FP32):
     return x + (h if keep is None else h * keep[1])
 
 
-def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False, keep=None, nm=FP32):
+def grid_sample_in_cells(feat, grid, ix0, iy0):
+    """F.grid_sample(feat, grid, 'bilinear', 'border', align_corners=True) with the bilinear CELL of every sample given
+    (ix0, iy0 = its NW corner, integer tensors shaped like grid[..., 0]) instead of derived by floor(): differentiable w.r.t.
+    `grid` and `feat`, and continuous across cell boundaries for a fixed choice of cells.  grid_sample's derivative w.r.t. the
+    position is one-sided at a boundary; two evaluations whose positions differ by roundoff may take different sides there.
+    A gradient test hands the cells the implementation under test used (its `cidx` taps) to this function, so that both sides
+    differentiate the same branch of the same piecewise-bilinear function (ATen: grid_sampler_compute_source_index with
+    clip_coordinates_set_grad -- no gradient through a clipped coordinate -- and within-bounds corner masks)."""
+    B, C, H, W = feat.shape
+    def unnorm(g, size):                                     # align_corners=True; border: clip to [0, size-1], zero grad outside
+        return (((g + 1) / 2) * (size - 1)).clamp(0, size - 1)
+    ix, iy = unnorm(grid[..., 0], W), unnorm(grid[..., 1], H)
+    fx, fy = ix - ix0.to(ix.dtype), iy - iy0.to(iy.dtype)
+    flat = feat.reshape(B, C, H * W)
+    out = 0
+    for dx, dy, w in ((0, 0, (1 - fx) * (1 - fy)), (1, 0, fx * (1 - fy)), (0, 1, (1 - fx) * fy), (1, 1, fx * fy)):
+        xx, yy = ix0 + dx, iy0 + dy
+        inside = ((xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)).to(feat.dtype)
+        idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).reshape(B, 1, -1).expand(B, C, -1)
+        v = torch.gather(flat, 2, idx).reshape(B, C, *grid.shape[1:3])
+        out = out + v * (w * inside).unsqueeze(1)
+    return out
+
+
+def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False, keep=None, nm=FP32, cells=None):
     """DeformableBlock.forward pose_dformer.py:115-141; LN eps 1e-5 (default nn.LayerNorm, :84).
     bf16 mode: the attention half (query LayerNorm, logits / offsets, sampling of the bf16-valued maps, embed_proj) is fp32
     in the engine (ctx_attn_kernel); only the MLP half runs bf16 operands."""
@@ -351,7 +375,9 @@ def _deformable_block(P, pre, x, ref, feats, heads=4, samples=4, explicit=False,
     pos = off + ref.view(b, 1, p, 1, -1)
     sampled = []
     for idx, f in enumerate(feats):
-        if explicit:
+        if cells is not None:                                               # [b, p, l, hs, 2] NW corners (the engine's cidx tap)
+            s = grid_sample_in_cells(f, pos[:, idx], cells[:, :, idx, :, 0], cells[:, :, idx, :, 1])
+        elif explicit:
             s = grid_sample_explicit(f, pos[:, idx], "border")
         else:
             s = F.grid_sample(f, pos[:, idx], mode="bilinear", padding_mode="border", align_corners=True)
@@ -382,11 +408,13 @@ def split_drop_masks(masks, B, J=17, levels=4):
 
 
 def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=False, taps=None,
-                   context_blocks=True, drop_masks=None, emulate_bf16=False, depth=None):
+                   context_blocks=True, drop_masks=None, emulate_bf16=False, depth=None, cells=None):
     """PoseTransformer.forward pose_dformer.py:210-241.
 
     k2d [B,17,2], ref [B,17,2] (already normalised), feats: 4 NCHW maps -> [B,1,17,3].
     taps: optional dict that receives intermediates for stage-level parity tests.
+    cells: optional list (one per context block) of int64 [B,17,levels,16,2] NW corners: the deformable samplers evaluate
+    grid_sample_in_cells with them (gradient tests: same bilinear cells as the implementation under test).
     """
     b, p, _ = k2d.shape
     nm = BF16 if emulate_bf16 else FP32
@@ -407,7 +435,7 @@ def lifter_forward(P, k2d, ref, feats, pre="volume_net", levels=4, explicit=Fals
     if context_blocks:
         for i in range(levels):                                             # :228-229 (depth = levels, :169)
             x, pos = _deformable_block(P, f"{pre}.context_blocks.{i}", x, ref, feats, explicit=explicit,
-                                       keep=keep["ctx"][i] if keep else None, nm=nm)
+                                       keep=keep["ctx"][i] if keep else None, nm=nm, cells=cells[i] if cells is not None else None)
             if taps is not None:
                 taps.setdefault("ctx_pos", []).append(pos)
         if taps is not None:

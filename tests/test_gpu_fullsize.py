@@ -159,6 +159,8 @@ def test_cfg3_training_step_batch512_vs_oracle_autograd():
     B = 512
     model, sd, crit, (img, k2d, kc, gt) = _train_model(B, False)
     torch.set_num_threads(min(64, torch.get_num_threads()))
+    eng = model.engine_for(img.cuda())
+    eng.set_debug(True)                                        # cidx{i} taps: the bilinear cells of the deformable samplers
     pred = model(img.cuda(), k2d.cuda(), kc.clone().cuda())
     loss = crit(pred, gt.cuda())
     loss.backward()
@@ -178,35 +180,49 @@ def test_cfg3_training_step_batch512_vs_oracle_autograd():
     err, mpj = _report("cfg3 B=512 train (DropPath off) prediction", pred.detach().cpu(), want.detach())
     assert err <= 1e-3 and abs(loss.item() - ol.item()) < 1e-5
     # The yardstick for the gradients is the SAME lifter evaluated in fp64 (on the fp32 oracle's context maps).  Two things make
-    # a per-element bound on the offset-path gradients meaningless and are accounted for instead of being tuned away:
+    # a naive bound on the offset-path gradients meaningless and are dealt with instead of being tuned away:
     #  (a) conditioning: a sampling-offset gradient is the small remainder of 34816 cancelling rows (differences of bilinear
-    #      corners) — the fp32 ORACLE itself sits 1e-3 of the gradient's max from fp64;
-    #  (b) the bilinear sampler's derivative w.r.t. position is DISCONTINUOUS at cell boundaries: of the 2.2 M border-mode samples
-    #      of this step a handful lie within fp32 roundoff of a boundary, take the other one-sided derivative in another
-    #      evaluation and move single entries of the offset-path gradients by their whole contribution (observed: one entry of
-    #      context_blocks.0.sampling_offsets.weight by 3.8e-3 of the max after an unrelated 1e-6 change of the context maps).
-    # So: relative L2 error of every gradient <= max(1e-3, 3 x the fp32 oracle's own), and no entry further than 2e-2 of the
-    # gradient's max (a wrong kernel is wrong everywhere, not in one entry).
-    P64 = {k: (v.double().clone().requires_grad_(True) if k.startswith("volume_net.") else v.double()) for k, v in sd.items()
-           if k.startswith("volume_net.")}
-    w64 = oracle.lifter_forward(P64, k2d.double(), ref.double(), [f.double() for f in feats])
-    oracle.mpjpe(w64, gt.double()).backward()
+    #      corners) -- the fp32 ORACLE itself sits up to 1e-3 of the gradient's max from fp64, so the bound is relative to it;
+    #  (b) grid_sample's derivative w.r.t. the position is ONE-SIDED at cell boundaries: of the 2.2 M border-mode samples of this
+    #      step a few dozen lie within fp32 roundoff of a boundary, and two correct evaluations whose positions differ in the last
+    #      bits differentiate different cells there (a kernel change that only reordered the stem conv's summation moved
+    #      context_blocks.0.sampling_offsets.weight by 1.9e-3 relative L2 that way).  The yardstick therefore evaluates its
+    #      samplers IN THE CELLS THE ENGINE USED (its cidx taps -- themselves checked bit for bit against ATen's index rule
+    #      in test_gpu_sampling.py): capf_oracle.grid_sample_in_cells, the same piecewise-bilinear function without the floor().
+    # With the cells shared, (a) disappears from the comparison as well (both sides sum the same rows; measured: every one of the
+    # 191 gradients within 1.4e-6 relative L2 and 3.1e-6 of its max per entry, where the fp32 oracle with its own floor() cells
+    # sits up to 2.3e-4 from the fp64 yardstick).  Bound: 2e-5 for both.
+    cells = [eng.tensor(f"cidx{i}")[:B].cpu().view(B, 17, 4, 16, 2).long() for i in range(4)]
+
+    def lifter64(fs, cells=None):
+        Q = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("volume_net.")}
+        w = oracle.lifter_forward(Q, k2d.double(), ref.double(), fs, cells=cells)
+        oracle.mpjpe(w, gt.double()).backward()
+        return {k: q.grad for k, q in Q.items()}, w.detach()
+
+    f64 = [f.double() for f in feats]
+    g64, w64 = lifter64(f64)                                  # floor() cells: the yardstick of the fp32 oracle
+    g64c, w64c = lifter64(f64, cells)                         # the engine's cells: the yardstick of the engine
+    dcell = (w64c - w64).abs().max().item()
+    print(f"  fp64 lifter, engine's cells vs floor() cells: prediction differs by {dcell:.2e} (same function, other branch at a few boundaries)")
+    assert dcell <= 1e-6
     rows = []
     for k, p in P.items():
         if not k.startswith("volume_net."):
             continue
-        t = P64[k].grad
+        t, tc = g64[k], g64c[k]
         nrm, scale = t.norm().clamp_min(1e-30), t.abs().max().clamp_min(1e-30)
-        dh, df = grads[k].double() - t, p.grad.double() - t
-        rows.append(((dh.norm() / nrm).item(), (df.norm() / nrm).item(), (dh.abs().max() / scale).item(), (df.abs().max() / scale).item(), k))
+        dh, df = grads[k].double() - tc, p.grad.double() - t
+        rows.append(((dh.norm() / nrm).item(), (df.norm() / nrm).item(), (dh.abs().max() / scale).item(), (df.abs().max() / scale).item(),
+                     ((tc - t).norm() / nrm).item(), k))
     rows.sort(reverse=True)
-    print(f"  {len(rows)} gradients at B=512 vs the fp64 lifter; worst five (relative L2: HIP, fp32 oracle | max entry / max: HIP, fp32 oracle):")
-    for l2h, l2f, mh, mf, k in rows[:5]:
-        print(f"    {k:58s} {l2h:9.2e} {l2f:9.2e} | {mh:9.2e} {mf:9.2e}")
+    print(f"  {len(rows)} gradients at B=512 vs the fp64 lifter; worst five (relative L2: HIP, fp32 oracle | max entry / max: HIP, fp32 "
+          f"oracle | what the choice of cells alone moves):")
+    for l2h, l2f, mh, mf, l2c, k in rows[:5]:
+        print(f"    {k:58s} {l2h:9.2e} {l2f:9.2e} | {mh:9.2e} {mf:9.2e} | {l2c:9.2e}")
     assert len(rows) == 191
-    for l2h, l2f, mh, mf, k in rows:
-        assert l2h <= max(1e-3, 3.0 * l2f), (k, l2h, l2f)
-        assert mh <= 2e-2, (k, mh, mf)
+    for l2h, l2f, mh, mf, l2c, k in rows:
+        assert l2h <= 2e-5 and mh <= 2e-5, (k, l2h, mh, l2f, mf)
     with torch.no_grad():
         model.eval()
         sub = model(img[128:192].cuda(), k2d[128:192].cuda(), kc[128:192].clone().cuda()).cpu()

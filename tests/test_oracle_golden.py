@@ -207,3 +207,31 @@ def test_prefetch_restatement_equals_the_reference_prefetcher_golden():
         # one ulp of a quotient in [0, 1] is 6e-8; / std (>= 0.224) scales it by <= 4.5; + the roundings of values up to 2.7 (ulp 2.4e-7)
         assert d.max() <= 1e-6, (name, d.max())
         assert d.max() > 0 or backbone == "cpn"            # the two modes are not vacuously identical
+
+
+def test_grid_sample_in_cells_is_grid_sample_with_the_cells_given():
+    """The differentiable sampler of the gradient tests (capf_oracle.grid_sample_in_cells): with ATen's own cells (floor of the
+    clipped pixel coordinate, bilinear_corners) it reproduces F.grid_sample(padding_mode='border', align_corners=True) and
+    both of its gradients; with a neighbouring cell forced at a boundary it is the continuous extension of that branch."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    f = torch.randn(2, 5, 9, 7, dtype=torch.float64, requires_grad=True)
+    g = (torch.rand(2, 3, 4, 2, dtype=torch.float64) * 2.4 - 1.2).requires_grad_(True)          # some samples clipped at the border
+    c = oracle.bilinear_corners(g.detach().numpy(), 9, 7, "border")
+    ix0, iy0 = torch.from_numpy(c["ix0"].astype(np.int64)), torch.from_numpy(c["iy0"].astype(np.int64))
+    a = F.grid_sample(f, g, mode="bilinear", padding_mode="border", align_corners=True)
+    b = oracle.grid_sample_in_cells(f, g, ix0, iy0)
+    assert (a - b).abs().max().item() < 1e-14
+    ga = torch.autograd.grad(a.square().sum(), [f, g])
+    gb = torch.autograd.grad(b.square().sum(), [f, g])
+    assert (ga[0] - gb[0]).abs().max().item() < 1e-12 and (ga[1] - gb[1]).abs().max().item() < 1e-12
+    # a sample exactly ON a vertical cell boundary (x = 3 of 0..6): the left and the right cell give the same value ...
+    gx = torch.tensor([[[[2 * 3 / 6 - 1, 0.1]]]], dtype=torch.float64).expand(2, 1, 1, 2).clone().requires_grad_(True)
+    cy = oracle.bilinear_corners(gx.detach().numpy(), 9, 7, "border")["iy0"].astype(np.int64)
+    left = oracle.grid_sample_in_cells(f, gx, torch.full((2, 1, 1), 2), torch.from_numpy(cy))
+    right = oracle.grid_sample_in_cells(f, gx, torch.full((2, 1, 1), 3), torch.from_numpy(cy))
+    assert (left - right).abs().max().item() < 1e-14
+    # ... and different one-sided derivatives w.r.t. x: what two evaluations a roundoff apart may disagree on
+    dl = torch.autograd.grad(left.sum(), gx, retain_graph=True)[0][..., 0]
+    dr = torch.autograd.grad(right.sum(), gx)[0][..., 0]
+    assert (dl - dr).abs().max().item() > 1e-3
