@@ -196,13 +196,14 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             time.sleep(0.002 * (1 + rank))
+        own_s = time.perf_counter() - t0                       # this rank's own time (the per-rank rate) ...
         cdist.barrier()
-        mine_s = time.perf_counter() - t0
+        mine_s = time.perf_counter() - t0                      # ... and the bracketed one (max over ranks -> value)
         dry_dist = None
         if world > 1:
             ones = torch.ones(1)
             dist.all_reduce(ones)
-            mine = torch.tensor([B * a.steps / mine_s], dtype=torch.float64)
+            mine = torch.tensor([B * a.steps / own_s], dtype=torch.float64)
             rates = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(rates, mine)
             dry_dist = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()), "devices_visible": torch.cuda.device_count(),
@@ -286,8 +287,10 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             out = step()
+        torch.cuda.synchronize(dev)
+        own_elapsed = time.perf_counter() - t0                 # this rank alone (per_rank_frames_per_s)
         fence()
-        elapsed = time.perf_counter() - t0
+        elapsed = time.perf_counter() - t0                     # bracketed by barrier + synchronize on both sides
     assert torch.isfinite(out).all()
 
     # ---- consecutive batches in flight on separate HIP streams (a serving loop's option, NOT the contract's step: two batches
@@ -331,7 +334,7 @@ def main():
         on_host = dist.get_backend() == "gloo"
         ones = torch.ones(1, dtype=torch.float32, device="cpu" if on_host else dev)
         dist.all_reduce(ones)
-        mine = torch.tensor([B * a.steps / elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
+        mine = torch.tensor([B * a.steps / own_elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
         rates = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(rates, mine)
         dist_info = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()),
