@@ -265,7 +265,7 @@ hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W,
 // l1 = src - i0, l0 = 1 - l1;  out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).
 template <bool BF, int V>      // V channels per lane: 4 (fp32: 16 B; bf16: 8 B) or 8 (bf16: 16 B)
 __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
-                                int C, int Ho, int Wo, float sh, float sw) {
+                                int C, int Ho, int Wo, float sh, float sw, const float* __restrict__ add) {
     const int CV = C / V;
     const long total = (long)B * Ho * Wo * CV;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -285,13 +285,17 @@ __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict_
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4* src = reinterpret_cast<const u32x4*>(in);
             const u32x4 q00 = src[o00 >> 1], q01 = src[o01 >> 1], q10 = src[o10 >> 1], q11 = src[o11 >> 1];
+            u32x4 qa = {0u, 0u, 0u, 0u};
+            if (add) qa = reinterpret_cast<const u32x4*>(add)[i];
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float lo = lh0 * (lw0 * __uint_as_float(q00[e] << 16) + lw1 * __uint_as_float(q01[e] << 16)) +
-                                 lh1 * (lw0 * __uint_as_float(q10[e] << 16) + lw1 * __uint_as_float(q11[e] << 16));
-                const float hi = lh0 * (lw0 * __uint_as_float(q00[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q01[e] & 0xFFFF0000u)) +
-                                 lh1 * (lw0 * __uint_as_float(q10[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q11[e] & 0xFFFF0000u));
+                float lo = lh0 * (lw0 * __uint_as_float(q00[e] << 16) + lw1 * __uint_as_float(q01[e] << 16)) +
+                           lh1 * (lw0 * __uint_as_float(q10[e] << 16) + lw1 * __uint_as_float(q11[e] << 16));
+                float hi = lh0 * (lw0 * __uint_as_float(q00[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q01[e] & 0xFFFF0000u)) +
+                           lh1 * (lw0 * __uint_as_float(q10[e] & 0xFFFF0000u) + lw1 * __uint_as_float(q11[e] & 0xFFFF0000u));
+                lo += __uint_as_float(qa[e] << 16);
+                hi += __uint_as_float(qa[e] & 0xFFFF0000u);
                 o[e] = pack_bf16x2(lo, hi);
             }
             reinterpret_cast<u32x4*>(out)[i] = o;
@@ -301,13 +305,18 @@ __global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 r[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
+            if (add) {
+                const f32x4 a = load4<BF>(add, i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] += a[e];
+            }
             store4<BF>(out, i, r);
         }
     }
 }
 
 hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
-                                  hipStream_t s, int bf16) {
+                                  hipStream_t s, int bf16, const float* add) {
     if ((long)B * Ho * Wo >= (1L << 31)) return hipErrorInvalidValue;
     const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -315,9 +324,9 @@ hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int
     const long total = (long)B * Ho * Wo * (C / V);
     const long want = (total + 255) / 256;
     const dim3 grid((int)(want < 16384 ? want : 16384));
-    if (V == 8) hipLaunchKernelGGL((bilinear_kernel<true, 8>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
-    else if (bf16) hipLaunchKernelGGL((bilinear_kernel<true, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
-    else hipLaunchKernelGGL((bilinear_kernel<false, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw);
+    if (V == 8) hipLaunchKernelGGL((bilinear_kernel<true, 8>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw, add);
+    else if (bf16) hipLaunchKernelGGL((bilinear_kernel<true, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw, add);
+    else hipLaunchKernelGGL((bilinear_kernel<false, 4>), grid, dim3(256), 0, s, in, out, B, H, W, C, Ho, Wo, sh, sw, add);
     return hipGetLastError();
 }
 

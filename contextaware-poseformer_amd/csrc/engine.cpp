@@ -158,7 +158,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
             HIP_TRY(launch_maxpool3x3s2(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
             break;
         case OP_RESIZE:
-            HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16));
+            HIP_TRY(launch_bilinear_resize(ptr(op.in[0]), ptr(op.out), batch, op.H, op.W, op.C, op.Ho, op.Wo, s, op.bf16, ptr(op.aux)));
             break;
         case OP_PREP_EMBED:
             HIP_TRY(launch_prep_embed(kcrop, k2d, params[op.p0].ptr, params[op.p1].ptr, params[op.p2].ptr,
@@ -953,7 +953,7 @@ int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes) {
         }
         case capf::OP_MAXPOOL:
         case capf::OP_RESIZE:
-            b = B * op.C * act * ((double)op.H * op.W + (double)op.Ho * op.Wo);
+            b = B * op.C * act * ((double)op.H * op.W + (double)op.Ho * op.Wo * (op.aux >= 0 ? 2.0 : 1.0));   // (+ the added map)
             break;
         case capf::OP_LAYERNORM:
             b = (double)op.rows_per_frame * B * op.C * 4.0 * (op.aux >= 0 ? 3.0 : 2.0);
@@ -1063,6 +1063,7 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
     } else {
         d->Cin = d->Cout = op.C;
         d->n_in = op.n_in; d->relu = op.relu;
+        d->has_residual = op.kind == capf::OP_RESIZE && op.aux >= 0;      // out = resize(in) + aux
         for (int i = 0; i < 4; ++i) d->shift[i] = op.shift[i];
         if (op.kind == capf::OP_FUSE) { d->Ho = op.H; d->Wo = op.W; }
     }

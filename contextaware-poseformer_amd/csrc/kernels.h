@@ -187,7 +187,7 @@ hipError_t launch_fuse_sum_group(const FuseSumArgs* a, int n, hipStream_t s);
 hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
                                hipStream_t s, int bf16 = 0);
 hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
-                                  hipStream_t s, int bf16 = 0);
+                                  hipStream_t s, int bf16 = 0, const float* add = nullptr);   // out = resize(in) (+ add, same shape as out)
 
 // ---- lifter -----------------------------------------------------------------------------------
 // kcrop -> ref in place (conpose.py:34-35);  X[b,p,0,:] = coord_embed(k2d[b,p]) + pos[0,p,:]

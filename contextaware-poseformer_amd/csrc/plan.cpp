@@ -300,12 +300,14 @@ void Engine::build_hrnet(Tensor img, Tensor feats[4]) {
 // ---------------------------------------------------------------------------------------------------
 // CPN-50 (networks/)
 // ---------------------------------------------------------------------------------------------------
-static Tensor pool_or_resize(Engine& e, OpKind kind, const std::string& name, const Tensor& x, int Ho, int Wo) {
+static Tensor pool_or_resize(Engine& e, OpKind kind, const std::string& name, const Tensor& x, int Ho, int Wo,
+                             const Tensor* add = nullptr) {
     Op op;
     op.kind = kind;
     op.name = name;
     op.in[0] = x.buf;
     e.use(x.buf);
+    if (add) { op.aux = add->buf; e.use(add->buf); }           // resize only: out = resize(x) + add
     op.H = x.H; op.W = x.W; op.C = x.C; op.Ho = Ho; op.Wo = Wo;
     op.bf16 = e.bf16() ? 1 : 0;
     Tensor y{-1, Ho, Wo, x.C};
@@ -358,10 +360,15 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
         if (i == 0) {
             fms[i] = lat;
         } else {
-            // up = BN(conv1x1(bilinear x2(feature_{i-1})));  feature_i = lateral_i + up  (add in the epilogue)
+            // reference: up = BN(conv1x1(bilinear x2(feature_{i-1}))), feature_i = lateral_i + up (globalNet.py:40-46, :66).  A
+            // 1x1 conv without bias + eval-mode BN is a per-pixel affine map and bilinear interpolation is a convex combination
+            // of pixels, so the two COMMUTE exactly in real arithmetic: the conv runs on the LOW-resolution map (a quarter of
+            // the pixels: 116 -> 29 GFLOP and 300 -> 75 us for the largest level at batch 128), the resize adds the lateral.
             const std::string upn = G + ".upsamples." + std::to_string(i - 1);
-            Tensor u = pool_or_resize(*this, OP_RESIZE, upn + ".0", fms[i - 1], fms[i - 1].H * 2, fms[i - 1].W * 2);
-            fms[i] = conv_bn(upn + ".1", upn + ".2", u, 256, 1, 1, ACT_NONE, &lat);
+            Tensor t = conv_bn(upn + ".1", upn + ".2", fms[i - 1], 256, 1, 1, ACT_NONE, nullptr);
+            ops.back().flops_per_frame *= 4.0;       // ALGORITHMIC FLOPs stay the reference's (conv at the upsampled resolution,
+                                                     // SURVEY 8d); capf_op_executed_flops reports what runs (rows_per_frame)
+            fms[i] = pool_or_resize(*this, OP_RESIZE, upn + ".0", t, t.H * 2, t.W * 2, &lat);
         }
         // predict heads: computed-then-discarded by the reference (:71) -> parameters only
         const std::string pp = G + ".predict." + std::to_string(i);

@@ -467,10 +467,11 @@ def normalise_crop_keypoints_(kcrop):
 
 
 def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit=False, taps=None, drop_masks=None,
-                  emulate_bf16=False):
+                  emulate_bf16=False, cells=None):
     """CA_PF.forward conpose.py:30-42.  images [B,H,W,3] NHWC fp32; mutates kcrop in place.
     drop_masks: training-mode DropPath multipliers (see split_drop_masks), None = eval / no drop.
-    emulate_bf16: the engine's compute_dtype = bf16 storage roundings (module docstring); False = the reference's fp32."""
+    emulate_bf16: the engine's compute_dtype = bf16 storage roundings (module docstring); False = the reference's fp32.
+    cells: see lifter_forward (gradient tests)."""
     nm = BF16 if emulate_bf16 else FP32
     x = images.permute(0, 3, 1, 2).contiguous()
     ref = normalise_crop_keypoints_(kcrop)
@@ -479,7 +480,7 @@ def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit
         taps["ref"] = ref.clone()
         taps["features"] = feats
     return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps, drop_masks=drop_masks,
-                          emulate_bf16=emulate_bf16)
+                          emulate_bf16=emulate_bf16, cells=cells)
 
 
 def mpjpe(pred, gt):

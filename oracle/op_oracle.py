@@ -67,9 +67,14 @@ def maxpool(x_nhwc):
     return _nhwc(F.max_pool2d(_nchw(x_nhwc), 3, 2, 1))
 
 
-def resize(x_nhwc, Ho, Wo, bf16):
+def resize(x_nhwc, Ho, Wo, bf16, add_nhwc=None):
+    """bilinear, align_corners=True (+ a map of the output's shape added in fp32 before the one storage rounding: the engine's
+    globalNet runs the 1x1 conv of an `upsamples` branch BEFORE the interpolation and adds the lateral here)"""
     nm = oracle.BF16 if bf16 else oracle.FP32
-    return _nhwc(nm.r(F.interpolate(_nchw(x_nhwc), size=(Ho, Wo), mode="bilinear", align_corners=True)))
+    y = F.interpolate(_nchw(x_nhwc), size=(Ho, Wo), mode="bilinear", align_corners=True)
+    if add_nhwc is not None:
+        y = y + _nchw(add_nhwc)
+    return _nhwc(nm.r(y))
 
 
 def compare(got, want, bf16, mass=None, term=None):

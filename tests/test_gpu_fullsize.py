@@ -127,12 +127,16 @@ def test_cfg3_training_step_batch64_all_191_gradients_vs_oracle_autograd(drop):
         masks = model._drop_masks(B, torch.device("cuda"))
         assert (masks == 0).any() and masks.numel() == 2 * 4 * (B + 17 * B + B)
         model._drop_masks = lambda b, dev: masks                 # the step below uses exactly these multipliers
+    eng = model.engine_for(img.cuda())
+    eng.set_debug(True)                                        # cidx{i} taps: the bilinear cells of the deformable samplers
     pred = model(img.cuda(), k2d.cuda(), kc.clone().cuda())
     loss = crit(pred, gt.cuda())
     loss.backward()
     torch.cuda.synchronize()
+    # the oracle differentiates the deformable samplers in the cells the engine used (see the batch-512 test below)
+    cells = [eng.tensor(f"cidx{i}")[:B].cpu().view(B, 17, 4, 16, 2).long() for i in range(4)]
     P = {k: (v.clone().requires_grad_(True) if k.startswith("volume_net.") else v) for k, v in sd.items()}
-    want = oracle.ca_pf_forward(P, img, k2d, kc.clone(), backbone="hrnet_32", drop_masks=masks.cpu() if drop else None)
+    want = oracle.ca_pf_forward(P, img, k2d, kc.clone(), backbone="hrnet_32", drop_masks=masks.cpu() if drop else None, cells=cells)
     ol = oracle.mpjpe(want, gt)
     ol.backward()
     err, mpj = _report(f"cfg3 B=64 train (DropPath {'on' if drop else 'off'}) prediction", pred.detach().cpu(), want.detach())
@@ -145,7 +149,7 @@ def test_cfg3_training_step_batch64_all_191_gradients_vs_oracle_autograd(drop):
         g_hip, g_ref = named[k].grad.cpu(), p.grad
         rel = ((g_hip - g_ref).abs().max() / g_ref.abs().max().clamp_min(1e-12)).item()
         worst = max(worst, rel); n += 1
-        assert rel < 2e-3, (k, rel)
+        assert rel < 1e-4, (k, rel)                            # (fp32 against fp32: measured 4e-6)
     print(f"  {n} gradients, worst max-abs error relative to the gradient's own max: {worst:.2e}")
     assert n == 191
 

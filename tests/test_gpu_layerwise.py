@@ -55,7 +55,8 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
                 elif d.kind == 2:
                     want = op_oracle.maxpool(take(0, d.H, d.W, d.Cin, d.in_dtype))
                 else:
-                    want = op_oracle.resize(take(0, d.H, d.W, d.Cin, d.in_dtype), d.Ho, d.Wo, out_bf)
+                    add = take(4, d.Ho, d.Wo, d.Cout, d.out_dtype) if d.has_residual else None
+                    want = op_oracle.resize(take(0, d.H, d.W, d.Cin, d.in_dtype), d.Ho, d.Wo, out_bf, add)
             r = op_oracle.compare(got, want, out_bf, mass, term)
             flips += r["weight_flips"]
             kern = table[i][1] or ("fuse_sum", "maxpool", "resize")[d.kind - 1]
