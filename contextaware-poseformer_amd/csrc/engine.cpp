@@ -120,6 +120,15 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     return a;
 }
 
+bool Engine::pwchain_head(int i, int batch, int last_op) const {
+    if (!use_pwchain || i < 0 || i + 1 >= last_op || i + 1 >= (int)ops.size()) return false;
+    const Op& a = ops[i];
+    const Op& b = ops[i + 1];
+    if (a.kind != OP_GEMM || !a.conv || a.bf16 || b.kind != OP_GEMM || !b.conv || b.bf16) return false;
+    if (b.in[0] != a.out || b.region != a.region || b.lane != a.lane) return false;
+    return gemm_f32_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch));
+}
+
 FuseSumArgs Engine::fuse_args(const Op& op, int batch) const {
     FuseSumArgs a{};
     a.n_in = op.n_in;
@@ -363,6 +372,14 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 break;
             default: {
                 if (op.kind == OP_FUSE && op.i0 == 1 && !debug) break;
+                // a 64 -> 256 pointwise conv directly followed by the 256 -> 64 one that reads it (layer1's conv3 -> next conv1): one launch
+                if (!ev && pwchain_head(oi, batch, last_op)) {
+                    const int pair[2] = {oi, oi + 1};
+                    if (log) HIP_TRY(log->mark(s, pair, 2));
+                    HIP_TRY(launch_gemm_f32_pwchain(gemm_args(op, batch), gemm_args(ops[oi + 1], batch), s));
+                    ++oi;
+                    break;
+                }
                 if (log) HIP_TRY(log->mark(s, &oi, 1));
                 int rc = exec_op(op, s, batch);
                 if (rc) return rc;
@@ -404,7 +421,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~15) {
+    if (cfg->plan_flags & ~31) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -896,6 +913,13 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
                                "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn"};
     if (name) *name = op.name.c_str();
+    const int n_all = (int)h->e.ops.size();
+    if (kernel && (h->e.pwchain_head(index, batch, n_all) || h->e.pwchain_head(index - 1, batch, n_all))) {
+        *kernel = capf::gemm_f32_pwchain_kernel_name();        // (both ops of the pair ride in one launch)
+        if (name) *name = op.name.c_str();
+        if (flops) *flops = op.flops_per_frame * batch;
+        return CAPF_OK;
+    }
     if (kernel) *kernel = op.kind != capf::OP_GEMM ? kn[op.kind] : (op.bf16 == 2 ? capf::gemm_bf16_rows_kernel_name((int)(op.rows_per_frame * batch), op.N)
                                                                       : op.bf16 ? capf::gemm_bf16_kernel_name(h->e.gemm_args(op, batch))
                                                                       : h->e.wino_now(op, batch) ? capf::gemm_wino_kernel_name(h->e.gemm_args(op, batch))

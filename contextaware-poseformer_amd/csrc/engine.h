@@ -230,6 +230,9 @@ struct Engine {
     int run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev = nullptr, LaunchLog* log = nullptr);
     int exec_op(const Op& op, hipStream_t s, int batch);
     FuseSumArgs fuse_args(const Op& op, int batch) const;
+    // op i and op i + 1 are a 64 -> 256 / 256 -> 64 pointwise conv pair that runs as ONE launch at this batch (igemm_f32_pwchain.hip)
+    bool pwchain_head(int i, int batch, int last_op) const;
+    bool use_pwchain = true;       // plan_flags & CAPF_PLAN_NO_PWCHAIN clears it
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
     GemmArgs gemm_args(const Op& op, int batch) const;
 };

@@ -123,6 +123,11 @@ const char* gemm_f32_kernel_name(const GemmArgs& a);   // which template instant
 bool gemm_f32_pw_ok(const GemmArgs& a);
 hipError_t launch_gemm_f32_pw(const GemmArgs& a, hipStream_t s);
 const char* gemm_f32_pw_kernel_name();
+// two pointwise convs back to back (64 -> 256 + residual + ReLU, then 256 -> 64 + ReLU on its output) as ONE launch: the first conv's
+// accumulators are the second conv's A operand (igemm_f32_pwchain.hip); bit-identical to the two launches
+bool gemm_f32_pwchain_ok(const GemmArgs& a, const GemmArgs& b);
+hipError_t launch_gemm_f32_pwchain(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
+const char* gemm_f32_pwchain_kernel_name();
 
 // Winograd F(2,3)-along-W variant of the 3x3 / stride-1 / pad-1 fp32 conv (igemm_wino.hip): same GemmArgs as the direct conv,
 // Wp = weights packed by launch_pack_conv_wino ([N][12 * Cin]); needs Cin % 32 == 0, even W, N % 4 == 0

@@ -897,6 +897,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_NO_WINOGRAD) use_wino = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_ROW_HALO) use_rh = false;
     if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
     // tuning knobs of the diagnostic build only (diag_env is a constant nullptr in the product library)
     if (const char* fz = diag_env("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;
     if (const char* wz = diag_env("CAPF_WINO")) use_wino = atoi(wz) != 0;

@@ -81,7 +81,8 @@ enum capf_plan_flag {
     CAPF_PLAN_NO_FUSED_LIFTER = 1,  /* one kernel per lifter op instead of embed_kernel / ctx_attn_kernel / LayerNorm-in-GEMM */
     CAPF_PLAN_NO_WINOGRAD = 2,      /* fp32 3x3 stride-1 convs on the direct MFMA kernel */
     CAPF_PLAN_NO_ROW_HALO = 4,      /* bf16 3x3 stride-1 convs on the direct bf16 kernel */
-    CAPF_PLAN_WINOGRAD_F23_ONLY = 8 /* F(2,3) where F(4,3) would be chosen */
+    CAPF_PLAN_WINOGRAD_F23_ONLY = 8, /* F(2,3) where F(4,3) would be chosen */
+    CAPF_PLAN_NO_PWCHAIN = 16       /* layer1's conv3 -> next conv1 pairs as two pointwise launches instead of one chained kernel */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------

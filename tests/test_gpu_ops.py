@@ -370,6 +370,39 @@ def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone):
                 assert torch.equal(a, b), f"mode {mode}"
 
 
+def test_pointwise_chain_is_bit_identical_to_its_two_launches():
+    """igemm_f32_pwchain (layer1's conv3 -> next conv1 as one launch, the first conv's accumulators feeding the second conv's
+    MFMAs from registers) against the same plan with CAPF_PLAN_NO_PWCHAIN: same K order, same ((acc + bias) + res) epilogue ->
+    the same bits in the four context maps and in the joints, at batch 64 (8 tiles per wave) and at a ragged 41 frames."""
+    import copy, contextlib, io
+    from capf import synth
+    from capf.lib import PLAN_NO_PWCHAIN
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    models = []
+    for flags in (0, PLAN_NO_PWCHAIN):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = CA_PF(cfg, compute_dtype="fp32", plan_flags=flags).eval()
+        synth.load_synthetic(m, seed=3, bn_mode="random")
+        models.append(m.cuda())
+    for B in (64, 41):
+        img, k2d, kc = synth.synth_inputs(B, 256, 256, seed=5 + B, crop_range=(256, 256))
+        img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+        res = []
+        with torch.no_grad():
+            for m in models:
+                out = m(img, k2d, kc.clone()).clone()
+                eng = m.engine_for(img)
+                res.append((out, [eng.tensor(f"feat{l}")[:B].clone() for l in range(4)],
+                            {n: k for n, k, _ in eng.op_table(B)}["backbone.layer1.1.conv3"]))
+        assert res[0][2].startswith("igemm_f32_pwchain") and res[1][2].startswith("igemm_f32_pw<")
+        assert torch.equal(res[0][0], res[1][0])
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b)
+
+
 def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
     """The engine's bf16 grouped launch (igemm_bf16_group_kernel) against single bf16 launches: run the
     backbone of a bf16 model with capf_set_lanes 0 and 2 and compare the four context maps bit for bit."""
