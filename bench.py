@@ -375,7 +375,10 @@ def main():
                         # (the grouped bf16 launch has three device kernels: name the one this launch ran, as rocprofv3 will)
                         kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh")[max(0, variants[l])] if kern.startswith("igemm_bf16")
                                 else ("igemm_wino43_group" if kern.startswith("igemm_wino43") else
-                                      "igemm_wino_group" if kern.startswith("igemm_wino") else "igemm_f32_group"))
+                                      "igemm_wino_group" if kern.startswith("igemm_wino") else
+                                      kern if kern.startswith("igemm_f32_pwchain") else "igemm_f32_group"))
+                        if table[l][1].startswith("igemm_bf16_pwchain"):
+                            kern = table[l][1]
                     if not kern or table[l][0].startswith("copy."):
                         continue
                     e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0, 0.0])

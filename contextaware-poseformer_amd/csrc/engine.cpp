@@ -124,9 +124,9 @@ bool Engine::pwchain_head(int i, int batch, int last_op) const {
     if (!use_pwchain || i < 0 || i + 1 >= last_op || i + 1 >= (int)ops.size()) return false;
     const Op& a = ops[i];
     const Op& b = ops[i + 1];
-    if (a.kind != OP_GEMM || !a.conv || a.bf16 || b.kind != OP_GEMM || !b.conv || b.bf16) return false;
+    if (a.kind != OP_GEMM || !a.conv || b.kind != OP_GEMM || !b.conv || a.bf16 != b.bf16 || a.bf16 > 1) return false;
     if (b.in[0] != a.out || b.region != a.region || b.lane != a.lane) return false;
-    return gemm_f32_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch));
+    return a.bf16 ? gemm_bf16_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch)) : gemm_f32_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch));
 }
 
 FuseSumArgs Engine::fuse_args(const Op& op, int batch) const {
@@ -376,7 +376,8 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 if (!ev && pwchain_head(oi, batch, last_op)) {
                     const int pair[2] = {oi, oi + 1};
                     if (log) HIP_TRY(log->mark(s, pair, 2));
-                    HIP_TRY(launch_gemm_f32_pwchain(gemm_args(op, batch), gemm_args(ops[oi + 1], batch), s));
+                    if (op.bf16) HIP_TRY(launch_gemm_bf16_pwchain(gemm_args(op, batch), gemm_args(ops[oi + 1], batch), s));
+                    else HIP_TRY(launch_gemm_f32_pwchain(gemm_args(op, batch), gemm_args(ops[oi + 1], batch), s));
                     ++oi;
                     break;
                 }
@@ -915,7 +916,7 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     if (name) *name = op.name.c_str();
     const int n_all = (int)h->e.ops.size();
     if (kernel && (h->e.pwchain_head(index, batch, n_all) || h->e.pwchain_head(index - 1, batch, n_all))) {
-        *kernel = capf::gemm_f32_pwchain_kernel_name();        // (both ops of the pair ride in one launch)
+        *kernel = op.bf16 ? capf::gemm_bf16_pwchain_kernel_name() : capf::gemm_f32_pwchain_kernel_name();      // (both ops ride in one launch)
         if (name) *name = op.name.c_str();
         if (flops) *flops = op.flops_per_frame * batch;
         return CAPF_OK;

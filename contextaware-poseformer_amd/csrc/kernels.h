@@ -128,6 +128,10 @@ const char* gemm_f32_pw_kernel_name();
 bool gemm_f32_pwchain_ok(const GemmArgs& a, const GemmArgs& b);
 hipError_t launch_gemm_f32_pwchain(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 const char* gemm_f32_pwchain_kernel_name();
+// the bf16 twin (igemm_bf16_pwchain.hip): CPN's / HRNet's layer1 pairs under compute_dtype = bf16
+bool gemm_bf16_pwchain_ok(const GemmArgs& a, const GemmArgs& b);
+hipError_t launch_gemm_bf16_pwchain(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
+const char* gemm_bf16_pwchain_kernel_name();
 
 // Winograd F(2,3)-along-W variant of the 3x3 / stride-1 / pad-1 fp32 conv (igemm_wino.hip): same GemmArgs as the direct conv,
 // Wp = weights packed by launch_pack_conv_wino ([N][12 * Cin]); needs Cin % 32 == 0, even W, N % 4 == 0

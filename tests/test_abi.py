@@ -229,7 +229,7 @@ def test_hot_kernels_do_not_spill_registers():
         return [(n, c) for n, c in zip(names, counts) if c]
 
     with concurrent.futures.ThreadPoolExecutor(4) as ex:
-        bad = sum(ex.map(spills, ["igemm_bf16", "igemm_f32", "igemm_f32_pw", "igemm_f32_pwchain", "igemm_wino"]), [])
+        bad = sum(ex.map(spills, ["igemm_bf16", "igemm_f32", "igemm_f32_pw", "igemm_f32_pwchain", "igemm_bf16_pwchain", "igemm_wino"]), [])
     assert not bad, f"kernels with register spills: {bad}"
 
 

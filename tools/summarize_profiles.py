@@ -58,6 +58,9 @@ def short(name):
     m = re.match(r"(?:void )?capf::igemm_bf16_group_kernel", name)
     if m:
         return "igemm_bf16_group"
+    m = re.match(r"(?:void )?capf::igemm_bf16_pwchain_kernel", name)
+    if m:
+        return "igemm_bf16_pwchain<64,256,64>"
     m = re.match(r"(?:void )?capf::igemm_f32_pwchain_kernel", name)
     if m:
         return "igemm_f32_pwchain<64,256,64>"
