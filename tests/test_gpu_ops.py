@@ -373,7 +373,7 @@ def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone):
 def test_pointwise_chain_is_bit_identical_to_its_two_launches():
     """igemm_f32_pwchain (layer1's conv3 -> next conv1 as one launch, the first conv's accumulators feeding the second conv's
     MFMAs from registers) against the same plan with CAPF_PLAN_NO_PWCHAIN: same K order, same ((acc + bias) + res) epilogue ->
-    the same bits in the four context maps and in the joints, at batch 64 (8 tiles per wave) and at a ragged 41 frames."""
+    the same bits in the four context maps and in the joints, at batch 64 (8 tiles per wave), at 41 frames and on 256 x 192 crops."""
     import copy, contextlib, io
     from capf import synth
     from capf.lib import PLAN_NO_PWCHAIN
@@ -387,8 +387,8 @@ def test_pointwise_chain_is_bit_identical_to_its_two_launches():
             m = CA_PF(cfg, compute_dtype="fp32", plan_flags=flags).eval()
         synth.load_synthetic(m, seed=3, bn_mode="random")
         models.append(m.cuda())
-    for B in (64, 41):
-        img, k2d, kc = synth.synth_inputs(B, 256, 256, seed=5 + B, crop_range=(256, 256))
+    for B, W in ((64, 256), (41, 256), (48, 192)):                # (256 x 192: the reference's own crop, 64 x 48 maps)
+        img, k2d, kc = synth.synth_inputs(B, 256, W, seed=5 + B, crop_range=(W, 256))
         img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
         res = []
         with torch.no_grad():
