@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_pwchain_kernel(GemmArgs p3, 
     constexpr int NT1 = N1 / 32, NT2 = N2 / 32, ST1 = K1 / 8;     // N-tiles of the two convs, k-steps of the first
     constexpr int W3F = N1 * K1, W1F = N2 * N1;                    // floats of the two weight matrices
     constexpr unsigned OOB = 0x80000000u;
-    static_assert(K1 % 32 == 0 && N1 % 32 == 0 && N2 % 32 == 0, "whole 32-float sub-chunks");
+    static_assert(K1 % 32 == 0 && N1 % 32 == 0 && N2 == 64, "whole 32-float sub-chunks; eight MFMA groups per sub-chunk of the second conv");
     constexpr int EPS = 36;                                        // padded row of a wave's 32 x 32 transpose scratch
     extern __shared__ __attribute__((aligned(16))) float lds[];   // W3 | W1 | b3 | b1 | 4 x transpose scratch
     float* W3s = lds;
@@ -132,17 +132,18 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_pwchain_kernel(GemmArgs p3, 
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        request_a(tile + nw);                         // (a1 is free; lands during the second conv)
         // ---- y = relu((acc + b3) + res), stored, and kept as the second conv's A operand
         const rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(p3.out + m0 * s_y + p3.omap.off), 0, 0x7FFFFF00u, 0x00020000);
+        // The epilogue of N-tile j in seven pieces; N-tile 0 runs here, N-tile j + 1 rides behind the eight MFMA groups of the second
+        // conv's sub-chunk j (which only needs N-tiles <= j): the VALU / LDS / store work of 7/8 of y's epilogue issues under MFMAs.
+        auto epi_piece = [&](int j, int piece) {
+            if (piece == 0) {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < NT1; ++j) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int h = 0; h < 4; ++h) *reinterpret_cast<f32x4*>(&ep[(8 * h + er) * EPS + ec]) = res[j][h];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
+                for (int h = 0; h < 4; ++h) *reinterpret_cast<f32x4*>(&ep[(8 * h + er) * EPS + ec]) = res[j][h];
+                __builtin_amdgcn_wave_barrier();
+            } else if (piece <= 4) {
+                const int g = piece - 1;
                 float* cell = &ep[frow * EPS + 8 * g + 4 * fhalf];          // this lane's 4 channels, accumulator layout
                 const f32x4 rv = *reinterpret_cast<const f32x4*>(cell);
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(&B3s[32 * j + 8 * g + 4 * fhalf]);
@@ -155,15 +156,19 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_pwchain_kernel(GemmArgs p3, 
                     v[e] = t;
                 }
                 *reinterpret_cast<f32x4*>(cell) = v;                        // (same lane, same cell: in place)
-            }
-            __builtin_amdgcn_wave_barrier();
+                if (piece == 4) __builtin_amdgcn_wave_barrier();
+            } else {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(8 * h + er) * EPS + ec]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y,
-                                                       m0 + 8 * h + er < p3.M ? (unsigned)((8 * h + er) * (int)s_y + 32 * j + ec) * 4u : OOB, 0, 0);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int h = (piece - 5) * 2 + hh;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(8 * h + er) * EPS + ec]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y,
+                                                           m0 + 8 * h + er < p3.M ? (unsigned)((8 * h + er) * (int)s_y + 32 * j + ec) * 4u : OOB, 0, 0);
+                }
             }
-        }
+        };
+#pragma unroll
+        for (int piece = 0; piece < 7; ++piece) epi_piece(0, piece);
         // ---- second conv: K = N1 from the registers above, N2 channels
         f32x16 z[NT2];
 #pragma unroll
@@ -188,6 +193,9 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_pwchain_kernel(GemmArgs p3, 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) z[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[e], y[j][4 * g + e], z[jn], 0, 0, 0);
                         bf = nx;
+                        if (j + 1 < NT1 && g * NT2 + jn < 7) epi_piece(j + 1, g * NT2 + jn);       // (NT2 == 2: eight groups per sub-chunk)
+                        if (j == NT1 / 2 && g == 0 && jn == 0) request_a(tile + nw);     // (a1 is free since the first conv; requested here, where
+                                                                                     // half of the residual registers are free again)
                         // the first half of the NEXT tile's residual, one N-tile per sub-chunk of the second half of this loop (the
                         // other half follows during the next tile's first k-steps): a trickle under the MFMAs, far ahead of its
                         // use.  All of it this early does not fit: y and the residual both live in the 256 architectural VGPRs.
