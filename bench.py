@@ -373,7 +373,7 @@ def main():
                     kern = table[l][1]
                     if len(ops_) > 1 and kern.startswith("igemm"):
                         # (the grouped bf16 launch has three device kernels: name the one this launch ran, as rocprofv3 will)
-                        kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh")[max(0, variants[l])] if kern.startswith("igemm_bf16")
+                        kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh", "igemm_bf16_group_ws")[max(0, variants[l])] if kern.startswith("igemm_bf16")
                                 else ("igemm_wino43_group" if kern.startswith("igemm_wino43") else
                                       "igemm_wino_group" if kern.startswith("igemm_wino") else
                                       kern if kern.startswith("igemm_f32_pwchain") else "igemm_f32_group"))

@@ -8,7 +8,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
-PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN = 1, 2, 4, 8, 16     # capf_plan_flag
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS = 1, 2, 4, 8, 16, 32     # capf_plan_flag
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
@@ -19,6 +19,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
     "capf_op_bilinear_corners", "capf_mpjpe_nd", "capf_op_executed_flops",
     "capf_forward_prefix", "capf_op_describe", "capf_op_tensor",
+    "capf_op_conv_bf16_ws_pack_elems", "capf_op_pack_conv_bf16_ws", "capf_op_conv_bf16_ws_group",
 ]
 
 
@@ -116,6 +117,9 @@ def load_library():
     lib.capf_op_conv_bf16_rh_width.argtypes = [c_int]
     lib.capf_op_pack_conv_bf16_rh.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
     lib.capf_op_conv_bf16_rh.argtypes = [P, P, P, P, P, P] + [c_int] * 6
+    lib.capf_op_conv_bf16_ws_pack_elems.argtypes = [c_int, c_int]
+    lib.capf_op_conv_bf16_ws_pack_elems.restype = c_int64
+    lib.capf_op_pack_conv_bf16_ws.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
     lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -574,6 +578,46 @@ def conv_nhwc_bf16_rh(x, wp, bias, act=0, residual=None):
     if rc:
         raise CapfError(f"capf_op_conv_bf16_rh failed ({rc})")
     return y
+
+
+def pack_conv_bf16_ws(w, bn=None, eps=1e-5):
+    """3x3 weights for the 2-D halo bf16 conv tile (csrc/igemm_bf16_ws.hip) -> (packed bf16 [elems], fp32 bias [Cout])."""
+    import torch
+    lib = load_library()
+    co, ci, ks, _ = w.shape
+    n = lib.capf_op_conv_bf16_ws_pack_elems(co, ci)
+    if ks != 3 or n <= 0 or co % 8:
+        raise CapfError(f"2-D halo conv needs a 3x3 kernel, Cin % 16 == 0 and Cout % 8 == 0 (got ks={ks}, Cin={ci}, Cout={co})")
+    wp = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+    bias = torch.empty(co, device=w.device)
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    rc = lib.capf_op_pack_conv_bf16_ws(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci)
+    if rc:
+        raise CapfError(f"capf_op_pack_conv_bf16_ws failed ({rc})")
+    return wp, bias
+
+
+def conv_nhwc_bf16_ws_group(problems):
+    """problems: list of (x, wp_ws, bias, act, residual, Cout), x / residual bf16 NHWC -> list of outputs (one grouped launch of the
+    2-D halo tile, 3x3 / stride 1 / pad 1)."""
+    import torch
+    lib = load_library()
+    n = len(problems)
+    descs = (ConvDesc * n)()
+    outs = []
+    for i, (x, wp, bias, act, res, co) in enumerate(problems):
+        B, H, W, ci = x.shape
+        y = torch.empty(B, H, W, co, device=x.device, dtype=torch.bfloat16)
+        outs.append(y)
+        d = descs[i]
+        d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
+        d.residual = res.data_ptr() if res is not None else None
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, co, 3, 1, act
+    lib.capf_op_conv_bf16_ws_group.argtypes = [c_void_p, c_int, POINTER(ConvDesc)]
+    rc = lib.capf_op_conv_bf16_ws_group(_stream(problems[0][0]), n, descs)
+    if rc:
+        raise CapfError(f"capf_op_conv_bf16_ws_group failed ({rc})")
+    return outs
 
 
 def conv_nhwc_bf16_group(problems):

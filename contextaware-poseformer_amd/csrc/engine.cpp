@@ -39,6 +39,9 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                 HIP_TRY(launch_pack_conv_bf16_rh(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                                  params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w2_off, B, pk.N, pk.Cin,
                                                  bf16_rh_width(pk.Cin), s));
+            if (pk.ws)
+                HIP_TRY(launch_pack_conv_bf16_ws(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
+                                                 params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w3_off, B, pk.N, pk.Cin, s));
         } else if (pk.kind == 0 && pk.wino) {
             HIP_TRY(launch_pack_conv_wino(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s, pk.Kpad == 18 * pk.Cin ? 43 : 23));
@@ -97,6 +100,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.M = (int)(op.rows_per_frame * batch);
     a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
     if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
+    if (pk.ws) a.Wp3 = pack_arena + pk.w3_off;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
@@ -422,7 +426,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~31) {
+    if (cfg->plan_flags & ~63) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -825,6 +829,27 @@ int capf_op_conv_bf16_rh(void* stream, const void* x, const void* wp, const floa
                          int H, int W, int Cin, int Cout, int act) {
     const capf::GemmArgs a = rh_args(x, wp, bias, residual, y, B, H, W, Cin, Cout, act);
     return capf::launch_gemm_bf16_rh(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_UNSUPPORTED;
+}
+
+int64_t capf_op_conv_bf16_ws_pack_elems(int Cout, int Cin) { return Cin % 16 == 0 && Cout > 0 ? capf::bf16_ws_pack_elems(Cout, Cin) : 0; }
+
+int capf_op_pack_conv_bf16_ws(void* stream, const float* w, const float* gamma, const float* beta, const float* mean,
+                              const float* var, float eps, void* wp, float* bias, int Cout, int Cin) {
+    if (!w || !wp || Cin % 16 != 0 || Cout % 8 != 0) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_pack_conv_bf16_ws(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* d) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i) {
+        if (d[i].ks != 3 || d[i].stride != 1) return CAPF_ERR_UNSUPPORTED;
+        g[i] = rh_args(d[i].x, nullptr, d[i].bias, d[i].residual, d[i].y, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].Cout, d[i].act);
+        g[i].Wp3 = d[i].w_packed;
+        if (!capf::gemm_bf16_ws_ok(g[i])) return CAPF_ERR_UNSUPPORTED;
+    }
+    return capf::launch_gemm_bf16_ws_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
 int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* d, const void* const* w_rh, int32_t* variant) {

@@ -1442,6 +1442,7 @@ static hipError_t launch_cfg_b(const GemmArgs& a, hipStream_t s) {
 }
 
 const char* gemm_bf16_kernel_name(const GemmArgs& a) {
+    if (gemm_bf16_ws_wanted(a)) return gemm_bf16_ws_kernel_name(a);
     if (a.Wp2 && gemm_bf16_rh_cw(a) && (long)((a.M + 127) / 128) * ((a.N + 63) / 64) >= pp_min_tiles()) return "igemm_bf16_rh<w4,126x64,conv>";
     if (a.N <= 32) return "igemm_bf16<w4,128x32,conv>";
     if (a.N <= 64) return ((long)a.M >= 128L * 512) ? "igemm_bf16<w4,128x64,conv>" : "igemm_bf16<w4,64x64,conv>";
@@ -1469,8 +1470,24 @@ bool gemm_bf16_groupable(const GemmArgs& a) { return bf16_ok(a) && a.omap.G == 1
 hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s, int* variant) {
     if (variant) *variant = -1;
     if (n <= 0) return hipSuccess;
-    if (n == 1) return launch_gemm_bf16(list[0], s);
     if (n > MAXG) return hipErrorInvalidValue;
+    {   // the 3x3 stride-1 problems the 2-D halo tile wants (a per-problem rule, igemm_bf16_ws.hip) share one grid of that kernel;
+        // whatever else the level holds follows as a second launch on the kernels below
+        GemmArgs wsl[MAXG], rest[MAXG];
+        int nws = 0, nrest = 0;
+        for (int i = 0; i < n; ++i) {
+            if (gemm_bf16_ws_wanted(list[i])) wsl[nws++] = list[i];
+            else rest[nrest++] = list[i];
+        }
+        if (nws) {
+            const hipError_t e = launch_gemm_bf16_ws_group(wsl, nws, s);
+            if (e != hipSuccess) return e;
+            if (variant) *variant = 3;
+            int v2 = -1;
+            return nrest ? launch_gemm_bf16_group(rest, nrest, s, &v2) : hipSuccess;
+        }
+    }
+    if (n == 1) return launch_gemm_bf16(list[0], s);
     static const int BMs[3] = {128, 64, 128}, BNs[3] = {64, 64, 32};
     double total = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -1539,6 +1556,7 @@ hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     a.fd_wo = make_fastdiv((unsigned)a.Wo);
     a.spread = 0ull;
     for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+    if (gemm_bf16_ws_wanted(a)) return launch_gemm_bf16_ws(a, s);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
     if (tiles128 >= pp_min_tiles()) {
         if (a.Wp2 && gemm_bf16_rh_cw(a)) {

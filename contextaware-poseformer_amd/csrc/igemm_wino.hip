@@ -1274,7 +1274,6 @@ struct Wino43GroupArgs {
     int prio[MAXG];                            // s_setprio level of the problem's waves (see launch_wino43_group)
     int n;
 };
-static constexpr int W43S_LDS = 6 * (64 + 32) * 16;              // floats per superstage (36 KiB)
 
 template <bool DB>
 __device__ __forceinline__ void wino43_group_body(const Wino43GroupArgs& ga, float* wlds) {

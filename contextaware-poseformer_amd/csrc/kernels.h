@@ -84,6 +84,8 @@ struct GemmArgs {
     const float* Wp;    // packed weights [N][Kpad], K-contiguous, zero padded to Kpad (multiple of 32)
     const float* Wp2;   // bf16 3x3 stride-1 convs: the same weights in the row-halo layout ([N][9 * Cin], igemm_bf16.hip), or
                         // nullptr; launch_gemm_bf16 / _group switch to that kernel for launches of >= 2048 tiles
+    const float* Wp3;   // bf16 3x3 stride-1 convs: the same weights in the 2-D halo tile's layout (igemm_bf16_ws.hip), or nullptr;
+                        // launch_gemm_bf16 / _group run the problems gemm_bf16_ws_wanted() accepts on that kernel
     const float* bias;  // [N] or nullptr
     const float* res;   // residual, addressed by rmap, or nullptr
     float* out;         // addressed by omap
@@ -155,7 +157,8 @@ hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float
 hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
 bool gemm_bf16_groupable(const GemmArgs& a);
 // bf16 twin of launch_gemm_f32_group; *variant (optional) = the device kernel it chose: 0 ring (igemm_bf16_group_kernel),
-// 1 ping-pong (igemm_bf16_group_pp_kernel), 2 ping-pong with row-halo tiles (igemm_bf16_group_rh_kernel), -1 single launch
+// 1 ping-pong (igemm_bf16_group_pp_kernel), 2 ping-pong with row-halo tiles (igemm_bf16_group_rh_kernel), 3 the 2-D halo tile
+// (igemm_bf16_group_ws_kernel; problems of the list it cannot take go out as a second, ring / ping-pong launch), -1 single launch
 hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s, int* variant = nullptr);
 const char* gemm_bf16_kernel_name(const GemmArgs& a);
 // row-halo variant of the 3x3 / stride-1 bf16 conv (one staged A tile serves the three kw taps): chunk width 64 / 48 / 32 or
@@ -165,6 +168,18 @@ int gemm_bf16_rh_cw(const GemmArgs& a);
 hipError_t launch_gemm_bf16_rh(const GemmArgs& a, hipStream_t s);
 hipError_t launch_pack_conv_bf16_rh(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                                     float eps, void* Wp_bf16, float* bias, int Cout, int Cin, int CW, hipStream_t s);
+// "2-D halo" tile of the 3x3 / stride-1 bf16 conv (igemm_bf16_ws.hip, igemm_bf16_ws_tile.h): 256 pixels x 32 / 64 / 96 channels per
+// block with the accumulators resident for the whole K, 16-channel chunks staged once for all nine taps; weights packed by
+// launch_pack_conv_bf16_ws (bf16_ws_pack_elems(Cout, Cin) bf16 elements), passed as GemmArgs::Wp3
+bool gemm_bf16_ws_ok(const GemmArgs& a);
+int gemm_bf16_ws_tiles(const GemmArgs& a);              // blocks the problem needs (0 = not eligible)
+bool gemm_bf16_ws_wanted(const GemmArgs& a);            // eligible, carries Wp3, and large enough for this tile (a function of the conv alone)
+long bf16_ws_pack_elems(int Cout, int Cin);
+hipError_t launch_gemm_bf16_ws(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s);
+const char* gemm_bf16_ws_kernel_name(const GemmArgs& a);
+hipError_t launch_pack_conv_bf16_ws(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                                    float eps, void* Wp_bf16, float* bias, int Cout, int Cin, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);

@@ -129,6 +129,8 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     // bf16: the 3x3 stride-1 convs also keep their weights in the row-halo layout (igemm_bf16.hip: one staged activation tile
     // for the three kw taps); launches of >= 2048 tiles run that kernel, smaller ones the ring kernel on the standard layout
     if (use_bf16 && use_rh && ks == 3 && stride == 1 && bf16_rh_width(x.C) && Cout % 4 == 0) { pk.rh = true; pk.Kpad2 = 9 * x.C; }
+    // ... and in the layout of the 2-D halo tile (igemm_bf16_ws.hip), which takes them from 512 tiles per launch
+    if (use_bf16 && use_ws && ks == 3 && stride == 1 && x.C % 16 == 0 && Cout % 8 == 0) pk.ws = true;
     packs.push_back(pk);
 
     Op op;
@@ -898,6 +900,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_NO_ROW_HALO) use_rh = false;
     if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     // tuning knobs of the diagnostic build only (diag_env is a constant nullptr in the product library)
     if (const char* fz = diag_env("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;
     if (const char* wz = diag_env("CAPF_WINO")) use_wino = atoi(wz) != 0;
@@ -974,6 +977,10 @@ bool Engine::build() {
         if (pk.rh) {
             pk.w2_off = off;
             off += round64(((size_t)pk.N * pk.Kpad2 + 1) / 2);
+        }
+        if (pk.ws) {
+            pk.w3_off = off;
+            off += round64(((size_t)bf16_ws_pack_elems(pk.N, pk.Cin) + 1) / 2);
         }
         pk.b_off = off;
         off += round64((size_t)pk.N);

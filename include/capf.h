@@ -82,7 +82,8 @@ enum capf_plan_flag {
     CAPF_PLAN_NO_WINOGRAD = 2,      /* fp32 3x3 stride-1 convs on the direct MFMA kernel */
     CAPF_PLAN_NO_ROW_HALO = 4,      /* bf16 3x3 stride-1 convs on the direct bf16 kernel */
     CAPF_PLAN_WINOGRAD_F23_ONLY = 8, /* F(2,3) where F(4,3) would be chosen */
-    CAPF_PLAN_NO_PWCHAIN = 16       /* layer1's conv3 -> next conv1 pairs as two pointwise launches instead of one chained kernel */
+    CAPF_PLAN_NO_PWCHAIN = 16,      /* layer1's conv3 -> next conv1 pairs as two pointwise launches instead of one chained kernel */
+    CAPF_PLAN_NO_WS = 32            /* bf16 3x3 stride-1 convs without the 2-D halo tile (row-halo / direct kernels as in round 3) */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -204,7 +205,7 @@ int capf_tensor(const capf_handle* h, const char* name, const void** dev_ptr, in
  * `batch`; used by bench.py for the roofline line. */
 /* after capf_forward_profile_launches: for every leader op of a grouped bf16 conv launch, which device kernel the launch ran
  * (0 igemm_bf16_group_kernel: ring schedule, 1 igemm_bf16_group_pp_kernel: ping-pong, 2 igemm_bf16_group_rh_kernel: ping-pong
- * with row-halo tiles); -1 for every other op.  Lets bench.py name launches the way rocprofv3 does.                         */
+ * with row-halo tiles, 3 igemm_bf16_group_ws_kernel: the 2-D halo tile); -1 for every other op.  Lets bench.py name launches the way rocprofv3 does.                         */
 int capf_forward_profile_variants(const capf_handle* h, int32_t* op_variant, int n_ops);
 int capf_forward_stats(const capf_handle* h, int batch, int64_t* launches, double* flops);
 
@@ -270,6 +271,19 @@ int capf_op_pack_conv_bf16_rh(void* stream, const float* w_oihw, const float* ga
                               const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);
 int capf_op_conv_bf16_rh(void* stream, const void* x_nhwc_bf16, const void* w_packed_bf16, const float* bias,
                          const void* residual_bf16, void* y_nhwc_bf16, int B, int H, int W, int Cin, int Cout, int act);
+
+/* "2-D halo" tile of the 3x3 / stride-1 / pad-1 bf16 conv (csrc/igemm_bf16_ws.hip; what capf_forward runs for the BasicBlock convs
+ * of a bf16 model, pose_hrnet.py:66-95, and the 3x3 of the ResNet / refine bottlenecks, networks/resnet.py:58-93, from 512 tiles
+ * per launch): a block keeps 256 output pixels x 32 / 64 / 96 channels in its accumulators for the whole K and stages every
+ * 16-channel chunk of its pixels (with halo) once for all nine taps.  Cin % 16 == 0, Cout % 8 == 0, (rows + 2) x (W + 2) <= 416
+ * for some row count dividing H.  w_packed holds capf_op_conv_bf16_ws_pack_elems(Cout, Cin) bf16 elements written by
+ * capf_op_pack_conv_bf16_ws (BatchNorm folded as in capf_op_pack_conv_bf16; bias fp32 [Cout], may be NULL).
+ * capf_op_conv_bf16_ws_group: up to 8 such convs in ONE grid, capf_conv_desc with bf16 x / residual / y and w_packed in this
+ * layout (ks = 3, stride = 1).                                                                                                */
+int64_t capf_op_conv_bf16_ws_pack_elems(int Cout, int Cin);
+int capf_op_pack_conv_bf16_ws(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
+                              const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);
+int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* convs);
 
 /* Up to 8 independent bf16 convs in one grid (what capf_forward issues per dependency level of the HRNet branches of a bf16 model):
  * capf_conv_desc with bf16 x / w_packed / residual / y.  w_row_halo[i] (optional array, entries may be NULL): the same weights

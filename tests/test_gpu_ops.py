@@ -444,8 +444,8 @@ def test_row_halo_engine_path_agrees_with_the_direct_bf16_kernels():
     img, k2d, kc = synth.synth_inputs(48, 256, 256, seed=16)
     img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
     maps, variants = [], []
-    from capf.lib import PLAN_NO_ROW_HALO
-    for flags in (0, PLAN_NO_ROW_HALO):
+    from capf.lib import PLAN_NO_ROW_HALO, PLAN_NO_WS
+    for flags in (PLAN_NO_WS, PLAN_NO_WS | PLAN_NO_ROW_HALO):
         with contextlib.redirect_stdout(io.StringIO()):
             model = CA_PF(cfg, compute_dtype="bf16", plan_flags=flags).eval()
         synth.load_synthetic(model, seed=4, bn_mode="random")
@@ -699,3 +699,114 @@ def test_row_halo_fuzz_against_torch():
         tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
         err = (got - want).abs().max().item()
         assert err <= tol, f"case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}: {err:.3e} > {tol:.3e}"
+
+
+def _ws_fold(wp, co, ci):
+    """Undo capf_op_pack_conv_bf16_ws: packed [slice][Cin / 16][tap][NS][quad position][8] -> folded weights [co, ci, 3, 3] (fp32)."""
+    ns = 96 if co % 96 == 0 else (32 if co <= 32 else 64)
+    nsl = (co + ns - 1) // ns
+    t = wp.float().cpu().view(nsl, ci // 16, 9, ns, 2, 8)
+    n = torch.arange(ns)
+    swap = ((n >> 3) & 1).bool()
+    t = torch.where(swap[None, None, None, :, None, None], t.flip(4), t)           # quad position -> channel half
+    w = t.permute(0, 3, 1, 4, 5, 2).reshape(nsl * ns, ci, 9)[:co]                  # [n, (cc, half, e), tap]
+    return w.reshape(co, ci, 3, 3).contiguous()
+
+
+def test_ws_fuzz_against_torch():
+    """Seeded random 3x3 / stride-1 problems through the 2-D halo tile (csrc/igemm_bf16_ws.hip): every channel-slice width (Cout
+    <= 32, multiples of 96, everything else on 64 with padded rows), Cin multiples of 16, image sizes whose tiles are part rows,
+    whole images and several images, ragged last tiles, with and without residual / ReLU -- against fp32 F.conv2d of the same
+    bf16-rounded operands (the folded weights are read back from the packed layout, which also checks the pack)."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(20260930)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    for case in range(28):
+        ci = 16 * ri(1, 14)
+        co = (8 * ri(1, 4), 96 * ri(1, 3), 8 * ri(5, 40))[case % 3]
+        H, W, B = ri(1, 40), ri(1, 70), ri(1, 5)
+        if case == 5:
+            H, W, B = 8, 8, 9                     # several images per tile, ragged last tile
+        if case == 6:
+            H, W, B = 64, 64, 2                   # part rows of an image per tile
+        act, res = ri(0, 1), bool(ri(0, 1))
+        x = torch.randn(B, ci, H, W, generator=rng).bfloat16()
+        w = torch.randn(co, ci, 3, 3, generator=rng) / (ci * 9) ** 0.5
+        bnp = (torch.rand(co, generator=rng) + 0.5, torch.randn(co, generator=rng) * 0.1, torch.randn(co, generator=rng) * 0.1,
+               torch.rand(co, generator=rng) * 0.4 + 0.8)
+        wp, bias = capf.pack_conv_bf16_ws(w.cuda(), tuple(t.cuda() for t in bnp))
+        w_fold = _ws_fold(wp, co, ci)
+        want = F.conv2d(x.float(), w_fold, bias.cpu(), 1, 1)
+        r = torch.randn_like(want).bfloat16() if res else None
+        if res:
+            want = want + r.float()
+        if act:
+            want = F.relu(want)
+        got, = capf.conv_nhwc_bf16_ws_group([(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
+                                              r.permute(0, 2, 3, 1).contiguous().cuda() if res else None, co)])
+        got = got.float().cpu().permute(0, 3, 1, 2)
+        tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
+        err = (got - want).abs().max().item()
+        assert err <= tol, f"case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}: {err:.3e} > {tol:.3e}"
+
+
+@pytest.mark.parametrize("chans,B", [((48, 96, 192, 384), 24), ((32, 64, 128, 256), 9), ((64, 128, 256, 512), 3)])
+def test_grouped_ws_launch_matches_torch_and_single_launches(chans, B):
+    """The four HRNet branch convs (3x3, stride 1, residual, ReLU) as ONE grouped launch of the 2-D halo tile -- slices of 32 / 64 /
+    96 channels, padded tile ids, problems of different K in one grid -- against fp32 F.conv2d of the same bf16-rounded operands,
+    and bit-identical to the four single launches."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(sum(chans) + B)
+    probs, wants = [], []
+    for i, c in enumerate(chans):
+        r = 64 >> i
+        x = torch.randn(B, c, r, r, generator=g).bfloat16()
+        w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+        bnp = (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+               torch.rand(c, generator=g) * 0.4 + 0.8)
+        res = torch.randn(B, c, r, r, generator=g).bfloat16()
+        wp, bias = capf.pack_conv_bf16_ws(w.cuda(), tuple(t.cuda() for t in bnp))
+        wants.append(F.relu(F.conv2d(x.float(), _ws_fold(wp, c, c), bias.cpu(), 1, 1) + res.float()))
+        probs.append((x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, 1, res.permute(0, 2, 3, 1).contiguous().cuda(), c))
+    outs = capf.conv_nhwc_bf16_ws_group(probs)
+    for y, want, pr in zip(outs, wants, probs):
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        tol = 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
+        assert (got - want).abs().max().item() <= tol
+        single, = capf.conv_nhwc_bf16_ws_group([pr])
+        assert torch.equal(single, y)
+
+
+def test_ws_engine_path_agrees_with_the_row_halo_kernels():
+    """Batch 48 HRNet-32 bf16: the product plan runs the branch levels on igemm_bf16_group_ws_kernel (capf_forward_profile_variants
+    reports 3), a plan with CAPF_PLAN_NO_WS on the row-halo kernel (2).  Same bf16 operands, different summation order: the four
+    context maps agree to the noise two bf16 evaluations accumulate over ~50 layers."""
+    import copy, contextlib, io
+    from capf import synth
+    from capf.lib import PLAN_NO_WS
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    img, k2d, kc = synth.synth_inputs(48, 256, 256, seed=16)
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    maps, variants = [], []
+    for flags in (0, PLAN_NO_WS):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = CA_PF(cfg, compute_dtype="bf16", plan_flags=flags).eval()
+        synth.load_synthetic(model, seed=4, bn_mode="random")
+        model = model.cuda()
+        with torch.no_grad():
+            out = model(img, k2d, kc.clone())
+            eng = model.engine_for(img)
+            eng.forward_profile_launches(img, k2d, kc.clone(), torch.empty_like(out), torch.cuda.current_stream().cuda_stream)
+        variants.append(set(v for v in eng.profile_variants() if v >= 0))
+        maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
+    assert 3 in variants[0] and 3 not in variants[1] and 2 in variants[1]
+    for a, b in zip(*maps):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"2-D halo vs row-halo: relative L2 {rel:.2e}")
+        assert rel < 1.5e-2
