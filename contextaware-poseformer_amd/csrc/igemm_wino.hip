@@ -1275,6 +1275,7 @@ struct Wino43GroupArgs {
     int n;
 };
 
+[[maybe_unused]] static constexpr int W43S_LDS = 6 * (64 + 32) * 16;              // floats per superstage (36 KiB); device code only
 template <bool DB>
 __device__ __forceinline__ void wino43_group_body(const Wino43GroupArgs& ga, float* wlds) {
 #if defined(__HIP_DEVICE_COMPILE__)
