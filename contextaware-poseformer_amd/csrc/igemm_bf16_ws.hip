@@ -55,6 +55,11 @@ bool gemm_bf16_ws_wanted(const GemmArgs& a) {
     return a.Wp3 && 2.0 * (double)a.M * a.N * 9.0 * a.Cin >= min_flop && gemm_bf16_ws_ok(a);
 }
 
+// Problems are laid out one after the other, longest K loop first, each padded to a multiple of 8 blocks so that block b of a
+// problem runs on XCD b % 8 and walks that XCD's contiguous eighth of the tiles (neighbouring tiles share halo rows and, for
+// several channel slices, the pixel tile in L2).  Measured and rejected: dealing the grid out in rounds, every problem in
+// proportion to its size, so that memory-bound (48-channel) and matrix-bound (384-channel) tiles are co-resident throughout:
+// HRNet-48 level at batch 256 224 -> 247 us, cfg2 14.39k -> 13.9k frames/s.
 struct WsGroupArgs {
     WsProblem g[MAXG];
     int start[MAXG + 1];
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_group_ws_kernel(WsGroupArgs
     int pi = 0;
     while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
     const int l = b - ga.start[pi];
-    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;      // XCD-contiguous tile order inside a problem (block b runs on XCD b % 8)
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
     const WsProblem& p = ga.g[pi];

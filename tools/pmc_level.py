@@ -17,12 +17,13 @@ from capf import lib as capf
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kind", default="wino43", choices=["wino43", "wino23", "bf16rh"])
+    ap.add_argument("--kind", default="wino43", choices=["wino43", "wino23", "bf16rh", "bf16ws"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--branches", default="0,1,2,3")
     a = ap.parse_args()
-    bf = a.kind == "bf16rh"
+    bf = a.kind in ("bf16rh", "bf16ws")
+    ws = a.kind == "bf16ws"
     B = a.batch or (256 if bf else 64)
     base = 48 if bf else 32
     sel = [int(v) for v in a.branches.split(",")]
@@ -34,7 +35,10 @@ def main():
         w = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).cuda()
         res = torch.randn(B, r, r, c, generator=g).cuda()
         alg += 2.0 * B * r * r * c * c * 9
-        if bf:
+        if ws:
+            wp, b = capf.pack_conv_bf16_ws(w)
+            probs.append((x.bfloat16(), wp, b, 1, res.bfloat16(), c))
+        elif bf:
             wp, b = capf.pack_conv_bf16(w)
             wrh, _, _ = capf.pack_conv_bf16_rh(w)
             probs.append((x.bfloat16(), wp, b, 3, 1, 1, res.bfloat16(), wrh))
@@ -43,6 +47,9 @@ def main():
             probs.append((x, wp, b, 1, res))
 
     def launch():
+        if ws:
+            capf.conv_nhwc_bf16_ws_group(probs)
+            return 3
         if bf:
             return capf.conv_nhwc_bf16_group(probs)[1]
         capf.conv_nhwc_wino_group(probs)
@@ -57,7 +64,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
-    frac = {"wino43": 0.5, "wino23": 2.0 / 3.0, "bf16rh": 1.0}[a.kind]
+    frac = {"wino43": 0.5, "wino23": 2.0 / 3.0, "bf16rh": 1.0, "bf16ws": 1.0}[a.kind]
     ex = alg * frac
     # v_mfma_f32_32x32x2_f32: 4096 FLOP, 64 cycles / SIMD;  v_mfma_f32_32x32x16_bf16: 32768 FLOP, 32 cycles / SIMD
     n_mfma = ex / (32768.0 if bf else 4096.0)
