@@ -118,10 +118,67 @@ hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_bf16_ws(const GemmArgs& a, hipStream_t s) { return launch_gemm_bf16_ws_group(&a, 1, s); }
+// ---- persistent, weight-resident form for narrow inputs (igemm_bf16_wsp_block): Cin = 32 / 48, one channel slice, at least two
+// tiles per CU.  Same results bit for bit as the tile above, so which of the two a conv takes is free to depend on its size.
+template <int TN, int NCC>
+__global__ __launch_bounds__(256, 1) void igemm_bf16_wsp_kernel(WsProblem p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsp_lds[];
+    igemm_bf16_wsp_block<TN, NCC>(p, wsp_lds);
+#endif
+}
+
+static bool wsp_from_args(const GemmArgs& a, WsProblem* p) {
+    static const int on = [] { const char* e = diag_env("CAPF_BF16_WSP"); return e ? atoi(e) : 1; }();     // A/B runs only
+    if (!on || !a.Wp3 || !ws_from_args(a, p)) return false;
+    const int ncc = p->C / 16;
+    return p->NSL == 1 && (ncc == 2 || ncc == 3) && p->NS <= 64 && p->tiles_m >= 512;
+}
+
+bool gemm_bf16_wsp_wanted(const GemmArgs& a) {
+    WsProblem p;
+    return gemm_bf16_ws_wanted(a) && wsp_from_args(a, &p);
+}
+
+hipError_t launch_gemm_bf16_wsp(const GemmArgs& a, hipStream_t s) {
+    WsProblem p;
+    if (!wsp_from_args(a, &p)) return hipErrorInvalidValue;
+    const int tn = p.NS / 32, ncc = p.C / 16;
+    const int grid = p.tiles_m >= 256 ? 256 : ((p.tiles_m + 7) & ~7);
+    const size_t lds_bytes = (size_t)wsp_lds_bytes(p.NS, ncc);
+#define WSP_CASE(TN_, NCC_)                                                                                                            \
+    if (tn == TN_ && ncc == NCC_) {                                                                                                    \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_wsp_kernel<TN_, NCC_>),           \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, wsp_lds_bytes(32 * TN_, NCC_)); \
+        if (attr != hipSuccess) return attr;                                                                                           \
+        hipLaunchKernelGGL((igemm_bf16_wsp_kernel<TN_, NCC_>), dim3(grid), dim3(256), lds_bytes, s, p);                                \
+        return hipGetLastError();                                                                                                      \
+    }
+    WSP_CASE(2, 3) WSP_CASE(1, 2) WSP_CASE(2, 2) WSP_CASE(1, 3)
+#undef WSP_CASE
+    return hipErrorInvalidValue;
+}
+
+// what the engine issues for the 2-D halo problems of a level: the narrow ones on the persistent form, a launch each (one block per
+// CU: nothing else fits beside it), the others as one grouped launch
+hipError_t launch_gemm_bf16_ws_level(const GemmArgs* list, int n, hipStream_t s) {
+    if (n > MAXG) return hipErrorInvalidValue;
+    GemmArgs grp[MAXG];
+    int ng = 0;
+    for (int i = 0; i < n; ++i) {
+        if (gemm_bf16_wsp_wanted(list[i])) {
+            const hipError_t e = launch_gemm_bf16_wsp(list[i], s);
+            if (e != hipSuccess) return e;
+        } else grp[ng++] = list[i];
+    }
+    return launch_gemm_bf16_ws_group(grp, ng, s);
+}
+
+hipError_t launch_gemm_bf16_ws(const GemmArgs& a, hipStream_t s) { return launch_gemm_bf16_ws_level(&a, 1, s); }
 
 const char* gemm_bf16_ws_kernel_name(const GemmArgs& a) {
     const int ns = ws_ns(a.N);
+    if (gemm_bf16_wsp_wanted(a)) return ns == 64 ? "igemm_bf16_wsp<w4,256x64,conv>" : "igemm_bf16_wsp<w4,256x32,conv>";
     return ns == 96 ? "igemm_bf16_ws<w4,256x96,conv>" : (ns == 64 ? "igemm_bf16_ws<w4,256x64,conv>" : "igemm_bf16_ws<w4,256x32,conv>");
 }
 
