@@ -60,21 +60,39 @@ bool gemm_bf16_ws_wanted(const GemmArgs& a) {
 // several channel slices, the pixel tile in L2).  Measured and rejected: dealing the grid out in rounds, every problem in
 // proportion to its size, so that memory-bound (48-channel) and matrix-bound (384-channel) tiles are co-resident throughout:
 // HRNet-48 level at batch 256 224 -> 247 us, cfg2 14.39k -> 13.9k frames/s.
+// Two-stream mix (rounds > 0): stream 0 = the matrix-bound problems, longest first as above; stream 1 = the memory-bound ones (two or
+// three chunks per tile: their blocks mostly wait for HBM).  The grid is dealt in rounds of per_round[0] + per_round[1] units of 8
+// blocks, so that for the whole launch a CU's two slots tend to hold one tile of each kind, while the long tiles still all start early.
 struct WsGroupArgs {
     WsProblem g[MAXG];
-    int start[MAXG + 1];
+    int start[MAXG + 1];   // first block of the problem inside its stream (stream 1's problems follow stream 0's in this array)
     int tiles[MAXG];
-    int n;
+    int n, n0;             // problems, problems of stream 0
+    int rounds, per_round[2], units[2];
 };
 
 __global__ __launch_bounds__(256, 2) void igemm_bf16_group_ws_kernel(WsGroupArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
-    const int b = blockIdx.x;
-    int pi = 0;
-    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
+    int b = blockIdx.x, lo = 0, hi = ga.n;
+    if (ga.rounds > 0) {                                   // block -> (stream, index in the stream); indices keep b's residue mod 8
+        const int m0 = 8 * ga.per_round[0], m1 = 8 * ga.per_round[1], rb = m0 + m1, main_blocks = ga.rounds * rb;
+        int st;
+        if (b < main_blocks) {
+            const int r = b / rb, o = b - r * rb;
+            st = o >= m0;
+            b = st ? r * m1 + (o - m0) : r * m0 + o;
+        } else {
+            const int t = b - main_blocks, rem0 = 8 * ga.units[0] - ga.rounds * m0;
+            st = t >= rem0;
+            b = st ? ga.rounds * m1 + (t - rem0) : ga.rounds * m0 + t;
+        }
+        if (st) lo = ga.n0; else hi = ga.n0;
+    }
+    int pi = lo;
+    while (pi + 1 < hi && b >= ga.start[pi + 1]) ++pi;
     const int l = b - ga.start[pi];
-    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
+    const int per_xcd = (ga.tiles[pi] + 7) >> 3;
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
     const WsProblem& p = ga.g[pi];
@@ -99,17 +117,33 @@ hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s)
     }
     for (int i = 1; i < n; ++i)
         for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
+    static const int mix = [] { const char* e = diag_env("CAPF_BF16_WS_MIX"); return e ? atoi(e) : 0; }();   // A/B runs only
     WsGroupArgs ga;
     ga.n = n;
-    int start = 0;
+    // (sorted by K length, descending: the memory-bound problems -- at most three chunks per tile -- are the tail of the list)
+    int n0 = n;
+    while (mix && n0 > 0 && it[n0 - 1].p.C <= 48) --n0;
+    if (n0 == 0 || n0 == n) n0 = n;                                  // one kind only: a single stream
+    ga.n0 = n0;
+    int start = 0, total = 0;
     for (int i = 0; i < n; ++i) {
+        if (i == n0) { ga.units[0] = start >> 3; start = 0; }
         ga.g[i] = it[i].p;
         ga.tiles[i] = it[i].p.tiles_m * it[i].p.NSL;
         ga.start[i] = start;
         start += (ga.tiles[i] + 7) & ~7;
+        total += (ga.tiles[i] + 7) & ~7;
     }
     ga.start[n] = start;
-    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
+    ga.rounds = 0;
+    if (n0 < n) {
+        ga.units[1] = start >> 3;
+        ga.rounds = ga.units[0] < ga.units[1] ? ga.units[0] : ga.units[1];
+        ga.per_round[0] = ga.units[0] / ga.rounds;
+        ga.per_round[1] = ga.units[1] / ga.rounds;
+    }
+    start = total;
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = 0; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
     const size_t lds_bytes = 2 * (size_t)ws_stage_bytes(max_ns);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_group_ws_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_stage_bytes(96));
