@@ -849,7 +849,7 @@ int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* d) {
         g[i].Wp3 = d[i].w_packed;
         if (!capf::gemm_bf16_ws_ok(g[i])) return CAPF_ERR_UNSUPPORTED;
     }
-    return capf::launch_gemm_bf16_ws_level(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+    return capf::launch_gemm_bf16_ws_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
 int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* d, const void* const* w_rh, int32_t* variant) {

@@ -1480,7 +1480,7 @@ hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s, in
             else rest[nrest++] = list[i];
         }
         if (nws) {
-            const hipError_t e = launch_gemm_bf16_ws_level(wsl, nws, s);
+            const hipError_t e = launch_gemm_bf16_ws_group(wsl, nws, s);
             if (e != hipSuccess) return e;
             if (variant) *variant = 3;
             int v2 = -1;

@@ -60,39 +60,24 @@ bool gemm_bf16_ws_wanted(const GemmArgs& a) {
 // several channel slices, the pixel tile in L2).  Measured and rejected: dealing the grid out in rounds, every problem in
 // proportion to its size, so that memory-bound (48-channel) and matrix-bound (384-channel) tiles are co-resident throughout:
 // HRNet-48 level at batch 256 224 -> 247 us, cfg2 14.39k -> 13.9k frames/s.
-// Two-stream mix (rounds > 0): stream 0 = the matrix-bound problems, longest first as above; stream 1 = the memory-bound ones (two or
-// three chunks per tile: their blocks mostly wait for HBM).  The grid is dealt in rounds of per_round[0] + per_round[1] units of 8
-// blocks, so that for the whole launch a CU's two slots tend to hold one tile of each kind, while the long tiles still all start early.
+// Also measured and rejected: two streams -- the matrix-bound problems longest first, the memory-bound 48-channel one dealt evenly
+// between them so that a CU's two slots hold one tile of each kind: 226 -> 228 us.  The tiles are bound by their own serial issue /
+// wait chains (SQ_WAIT_INST_ANY 35-40 %, SQ_WAIT_ANY 30-36 % of the wave-cycles with two waves per SIMD), not by a shared roof.
 struct WsGroupArgs {
     WsProblem g[MAXG];
-    int start[MAXG + 1];   // first block of the problem inside its stream (stream 1's problems follow stream 0's in this array)
+    int start[MAXG + 1];
     int tiles[MAXG];
-    int n, n0;             // problems, problems of stream 0
-    int rounds, per_round[2], units[2];
+    int n;
 };
 
 __global__ __launch_bounds__(256, 2) void igemm_bf16_group_ws_kernel(WsGroupArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
-    int b = blockIdx.x, lo = 0, hi = ga.n;
-    if (ga.rounds > 0) {                                   // block -> (stream, index in the stream); indices keep b's residue mod 8
-        const int m0 = 8 * ga.per_round[0], m1 = 8 * ga.per_round[1], rb = m0 + m1, main_blocks = ga.rounds * rb;
-        int st;
-        if (b < main_blocks) {
-            const int r = b / rb, o = b - r * rb;
-            st = o >= m0;
-            b = st ? r * m1 + (o - m0) : r * m0 + o;
-        } else {
-            const int t = b - main_blocks, rem0 = 8 * ga.units[0] - ga.rounds * m0;
-            st = t >= rem0;
-            b = st ? ga.rounds * m1 + (t - rem0) : ga.rounds * m0 + t;
-        }
-        if (st) lo = ga.n0; else hi = ga.n0;
-    }
-    int pi = lo;
-    while (pi + 1 < hi && b >= ga.start[pi + 1]) ++pi;
+    const int b = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < ga.n && b >= ga.start[pi + 1]) ++pi;
     const int l = b - ga.start[pi];
-    const int per_xcd = (ga.tiles[pi] + 7) >> 3;
+    const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
     const WsProblem& p = ga.g[pi];
@@ -117,33 +102,17 @@ hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s)
     }
     for (int i = 1; i < n; ++i)
         for (int j = i; j > 0 && it[j].cost > it[j - 1].cost; --j) { Item t = it[j]; it[j] = it[j - 1]; it[j - 1] = t; }
-    static const int mix = [] { const char* e = diag_env("CAPF_BF16_WS_MIX"); return e ? atoi(e) : 0; }();   // A/B runs only
     WsGroupArgs ga;
     ga.n = n;
-    // (sorted by K length, descending: the memory-bound problems -- at most three chunks per tile -- are the tail of the list)
-    int n0 = n;
-    while (mix && n0 > 0 && it[n0 - 1].p.C <= 48) --n0;
-    if (n0 == 0 || n0 == n) n0 = n;                                  // one kind only: a single stream
-    ga.n0 = n0;
-    int start = 0, total = 0;
+    int start = 0;
     for (int i = 0; i < n; ++i) {
-        if (i == n0) { ga.units[0] = start >> 3; start = 0; }
         ga.g[i] = it[i].p;
         ga.tiles[i] = it[i].p.tiles_m * it[i].p.NSL;
         ga.start[i] = start;
         start += (ga.tiles[i] + 7) & ~7;
-        total += (ga.tiles[i] + 7) & ~7;
     }
     ga.start[n] = start;
-    ga.rounds = 0;
-    if (n0 < n) {
-        ga.units[1] = start >> 3;
-        ga.rounds = ga.units[0] < ga.units[1] ? ga.units[0] : ga.units[1];
-        ga.per_round[0] = ga.units[0] / ga.rounds;
-        ga.per_round[1] = ga.units[1] / ga.rounds;
-    }
-    start = total;
-    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = 0; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
+    for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
     const size_t lds_bytes = 2 * (size_t)ws_stage_bytes(max_ns);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_group_ws_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_stage_bytes(96));
@@ -152,67 +121,14 @@ hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s)
     return hipGetLastError();
 }
 
-// ---- persistent, weight-resident form for narrow inputs (igemm_bf16_wsp_block): Cin = 32 / 48, one channel slice, at least two
-// tiles per CU.  Same results bit for bit as the tile above, so which of the two a conv takes is free to depend on its size.
-template <int TN, int NCC>
-__global__ __launch_bounds__(256, 1) void igemm_bf16_wsp_kernel(WsProblem p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) unsigned char wsp_lds[];
-    igemm_bf16_wsp_block<TN, NCC>(p, wsp_lds);
-#endif
-}
-
-static bool wsp_from_args(const GemmArgs& a, WsProblem* p) {
-    static const int on = [] { const char* e = diag_env("CAPF_BF16_WSP"); return e ? atoi(e) : 1; }();     // A/B runs only
-    if (!on || !a.Wp3 || !ws_from_args(a, p)) return false;
-    const int ncc = p->C / 16;
-    return p->NSL == 1 && (ncc == 2 || ncc == 3) && p->NS <= 64 && p->tiles_m >= 512;
-}
-
-bool gemm_bf16_wsp_wanted(const GemmArgs& a) {
-    WsProblem p;
-    return gemm_bf16_ws_wanted(a) && wsp_from_args(a, &p);
-}
-
-hipError_t launch_gemm_bf16_wsp(const GemmArgs& a, hipStream_t s) {
-    WsProblem p;
-    if (!wsp_from_args(a, &p)) return hipErrorInvalidValue;
-    const int tn = p.NS / 32, ncc = p.C / 16;
-    const int grid = p.tiles_m >= 256 ? 256 : ((p.tiles_m + 7) & ~7);
-    const size_t lds_bytes = (size_t)wsp_lds_bytes(p.NS, ncc);
-#define WSP_CASE(TN_, NCC_)                                                                                                            \
-    if (tn == TN_ && ncc == NCC_) {                                                                                                    \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_wsp_kernel<TN_, NCC_>),           \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, wsp_lds_bytes(32 * TN_, NCC_)); \
-        if (attr != hipSuccess) return attr;                                                                                           \
-        hipLaunchKernelGGL((igemm_bf16_wsp_kernel<TN_, NCC_>), dim3(grid), dim3(256), lds_bytes, s, p);                                \
-        return hipGetLastError();                                                                                                      \
-    }
-    WSP_CASE(2, 3) WSP_CASE(1, 2) WSP_CASE(2, 2) WSP_CASE(1, 3)
-#undef WSP_CASE
-    return hipErrorInvalidValue;
-}
-
-// what the engine issues for the 2-D halo problems of a level: the narrow ones on the persistent form, a launch each (one block per
-// CU: nothing else fits beside it), the others as one grouped launch
-hipError_t launch_gemm_bf16_ws_level(const GemmArgs* list, int n, hipStream_t s) {
-    if (n > MAXG) return hipErrorInvalidValue;
-    GemmArgs grp[MAXG];
-    int ng = 0;
-    for (int i = 0; i < n; ++i) {
-        if (gemm_bf16_wsp_wanted(list[i])) {
-            const hipError_t e = launch_gemm_bf16_wsp(list[i], s);
-            if (e != hipSuccess) return e;
-        } else grp[ng++] = list[i];
-    }
-    return launch_gemm_bf16_ws_group(grp, ng, s);
-}
-
-hipError_t launch_gemm_bf16_ws(const GemmArgs& a, hipStream_t s) { return launch_gemm_bf16_ws_level(&a, 1, s); }
+// Measured and not adopted (commit 899a361 "persistent weight-resident form", profiles/r04_pmc_bf16_ws_level.txt): a persistent block per CU
+// for the narrow branch (Cin 48: whole filter staged once, the next tile's pixels in flight under the current tile, one barrier per
+// tile) -- bit-identical, 92 -> 83 us alone, but nothing end to end (cfg2 14.23k vs 14.19k frames/s): with one wave per SIMD its K
+// loop, its VALU-heavy epilogue and its waits are strictly serial.
+hipError_t launch_gemm_bf16_ws(const GemmArgs& a, hipStream_t s) { return launch_gemm_bf16_ws_group(&a, 1, s); }
 
 const char* gemm_bf16_ws_kernel_name(const GemmArgs& a) {
     const int ns = ws_ns(a.N);
-    if (gemm_bf16_wsp_wanted(a)) return ns == 64 ? "igemm_bf16_wsp<w4,256x64,conv>" : "igemm_bf16_wsp<w4,256x32,conv>";
     return ns == 96 ? "igemm_bf16_ws<w4,256x96,conv>" : (ns == 64 ? "igemm_bf16_ws<w4,256x64,conv>" : "igemm_bf16_ws<w4,256x32,conv>");
 }
 

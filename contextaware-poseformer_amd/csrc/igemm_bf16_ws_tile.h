@@ -41,9 +41,6 @@ static constexpr int WS_A_BYTES = 13312;        // staged pixels x 32 B: at most
 static constexpr int WS_MAX_PP = WS_A_BYTES / 32;
 static constexpr int WS_MAX_P = 256;            // output pixels per tile (8 MFMA pixel blocks, two per wave)
 inline constexpr int ws_stage_bytes(int NS) { return WS_A_BYTES + 9 * NS * 32; }
-// persistent form (igemm_bf16_wsp_block): the whole filter + two pixel buffers of NCC chunks + 4.5 KiB of epilogue scratch per wave
-static constexpr int WSP_SCRATCH = 4 * 32 * 36 * 4;
-inline constexpr int wsp_lds_bytes(int NS, int NCC) { return NCC * 9 * NS * 32 + 2 * NCC * WS_A_BYTES + WSP_SCRATCH; }
 
 struct WsProblem {
     const unsigned short* x;      // [B][H][W][C] bf16
@@ -316,200 +313,6 @@ __device__ __forceinline__ void igemm_bf16_ws_tile(const WsProblem& p, const int
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Persistent, weight-resident form of the tile for NARROW inputs (Cin <= 48: HRNet-48's 48-channel, HRNet-32's 32-channel branch).
-// With two or three 16-channel chunks per tile the block above is a chain of DMA latencies: a chunk's 36 MFMAs per wave last 0.55 us,
-// its operands take ~2 us to arrive, and only one chunk is ever in flight (measured alone, HRNet-48 branch 0 at batch 256 with
-// residual: 93 us = 3.2 TB/s of a conv that is HBM-bound at ~50).  Here a block stays on its CU and walks tiles:
-//   * the WHOLE filter (NCC x 9 x NS x 32 B: 54 KiB at 48 -> 48) is staged once per block, not once per chunk and tile;
-//   * all NCC chunks of the NEXT tile's pixels (39 KiB) are requested behind the MFMAs of the current tile, one LDS-DMA
-//     instruction every second tap, into the other of two pixel buffers -- a whole tile of prefetch distance, 39 KiB per CU in flight;
-//   * ONE barrier per tile (after the counted wait for the next tile's pixels; the tile's own stores may still fly: vmcnt retires
-//     in order and they are the youngest eight), no barrier between chunks;
-//   * the residual rows of a tile are requested when its K loop starts.
-// One block per CU (136 - 154 KiB of LDS), grid = min(tiles, 256) rounded to a multiple of 8; block b serves XCD b % 8's contiguous
-// eighth of the tiles.  Same arithmetic, in the same order, as igemm_bf16_ws_tile: bit-identical results.
-
-template <int TN, int NCC>
-__device__ __forceinline__ void igemm_bf16_wsp_block(const WsProblem& p, unsigned char* __restrict__ lds) {
-    constexpr int NS = 32 * TN;
-    constexpr int W_BYTES = 9 * NS * 32;
-    constexpr int W_ALL = NCC * W_BYTES;
-    constexpr int A_ALL = NCC * WS_A_BYTES;
-    constexpr int NWI = W_ALL / 1024;
-    constexpr int NAS = 4;
-    constexpr int NSTORE = 2 * TN * 2;
-    constexpr unsigned OOB = 0x80000000u;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frow = lane & 31, fhalf = lane >> 5;
-    // this block's tiles: XCD x = blockIdx.x % 8 owns tiles [x * per_xcd, (x + 1) * per_xcd), its blocks stride through them
-    const int ntiles = p.tiles_m;
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = (int)gridDim.x >> 3;
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int t_end = min((xcd + 1) * per_xcd, ntiles);
-    int tile = xcd * per_xcd + lb;
-    if (tile >= t_end) return;
-
-    const ws_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFF00u, 0x00020000);
-    const ws_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)W_ALL, 0x00020000);
-    // ---- the filter, once
-#pragma unroll
-    for (int i = 0; i < (NWI + 3) / 4; ++i) {
-        const int k = min(i * 4 + wave, NWI - 1);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (ws_lptr_t)(lds + k * 1024), 16, (unsigned)lane * 16u, (unsigned)k * 1024u, 0, 0);
-    }
-    // ---- pixel DMA geometry of a tile (the lane's four quad slots; only the tile's first segment q0 changes from tile to tile)
-    const int NAI = (2 * p.PP + 63) >> 6;
-    int a_k[NAS];
-#pragma unroll
-    for (int j = 0; j < NAS; ++j) a_k[j] = min(j * 4 + wave, NAI - 1);
-    unsigned a_voff[NAS];
-    auto setup_tile = [&](int t, bool live) {
-        const int q0 = t * p.G;
-#pragma unroll
-        for (int j = 0; j < NAS; ++j) {
-            const int qi = a_k[j] * 64 + lane;
-            const int px = qi >> 1;
-            const int half = (qi & 1) ^ ((px >> 3) & 1);
-            const int g = ws_div(px, p.d_segp), rem = px - g * p.SEGP;
-            const int rr = ws_div(rem, p.d_pw), ww = rem - rr * p.PW;
-            const int q = q0 + g;
-            const int b = ws_div(q, p.d_rgpi);
-            const int h = (q - b * p.RGPI) * p.RH + rr - 1, col = ww - 1;
-            const bool ok = live && px < p.PP && q < p.RG && h >= 0 && h < p.H && col >= 0 && col < p.W;
-            a_voff[j] = ok ? (unsigned)((((b * p.H + h) * p.W + col) * p.C + half * 8) * 2) : OOB;
-        }
-    };
-    auto fire_piece = [&](int idx, int buf) {              // DMA instruction idx (0 .. NCC * NAS - 1) of the tile set up last
-        const int cc = idx / NAS, j = idx - cc * NAS;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (ws_lptr_t)(lds + W_ALL + buf * A_ALL + cc * WS_A_BYTES + a_k[j] * 1024), 16, a_voff[j],
-                                                 (unsigned)cc * 32u, 0, 0);
-    };
-    setup_tile(tile, true);
-#pragma unroll
-    for (int i = 0; i < NCC * NAS; ++i) fire_piece(i, 0);
-
-    // ---- bias, fragment addresses (tile independent)
-    const ws_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? (void*)p.bias : (void*)p.y, 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
-    ws_f32x4 bias_r[TN][4];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bias_r[j][g] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (unsigned)(j * 32 + 8 * g + 4 * fhalf) * 4u, 0, 0));
-    unsigned a_addr[2][9];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int pl = (2 * wave + i) * 32 + frow;
-        if (pl >= p.P) pl = 0;
-        const int g = ws_div(pl, p.d_rhw), rem = pl - g * p.RHW;
-        const int r = ws_div(rem, p.d_w), w = rem - r * p.W;
-        const int pix0 = (g * (p.RH + 2) + r) * p.PW + w;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int pix = pix0 + (t / 3) * p.PW + (t % 3);
-            a_addr[i][t] = (unsigned)(W_ALL + pix * 32 + ((fhalf ^ ((pix >> 3) & 1)) << 4));
-        }
-    }
-    const unsigned b_addr = (unsigned)(frow * 32 + ((fhalf ^ ((frow >> 3) & 1)) << 4));
-    const int er = lane >> 2, ec = (lane & 3) * 8;
-    const int Mi = (int)p.M;
-    const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(p.res ? (void*)p.res : (void*)p.y, 0, p.res ? 0x7FFFFF00u : 0u, 0x00020000);
-    const ws_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFF00u, 0x00020000);
-    float* ep = reinterpret_cast<float*>(lds + W_ALL + 2 * A_ALL) + wave * (32 * 36);
-    auto finish = [&](float t) { return p.relu ? fmaxf(t, 0.f) : t; };
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // the filter and the first tile's pixels have landed
-
-    auto one_tile = [&](auto BUFC) {
-        constexpr int BUF = decltype(BUFC)::value;
-        const int gp0 = tile * p.G * p.RHW;
-        auto piece_off = [&](int i, int j, int h, int ld) -> unsigned {
-            const int pl = (2 * wave + i) * 32 + h * 16 + er, n = j * 32 + ec;
-            const int gp = gp0 + pl;
-            return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(gp * ld + n) * 2u : OOB;
-        };
-        ws_u32x4 rr[2][TN][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) rr[i][j][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, h, p.ldr), 0, 0);
-        const int next = tile + nbx;
-        setup_tile(next, next < t_end);                    // (no next tile: the pieces still go out, as hardware zero fills)
-        ws_f32x16 acc[2][TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = bias_r[j][g][e];
-        ws_bf16x8 af[2][2], bfr[2][TN];
-        auto read_frags = [&](int u, int buf) {            // u = chunk * 9 + tap
-            const int cc = u / 9, t = u - cc * 9;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[buf][i] = __builtin_bit_cast(ws_bf16x8, *reinterpret_cast<const ws_f32x4*>(lds + BUF * A_ALL + cc * WS_A_BYTES + a_addr[i][t]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[buf][j] = __builtin_bit_cast(ws_bf16x8, *reinterpret_cast<const ws_f32x4*>(lds + cc * W_BYTES + b_addr + (t * NS + j * 32) * 32));
-        };
-        read_frags(0, 0);
-        constexpr int NU = NCC * 9, NP = NCC * NAS;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            if (u + 1 < NU) read_frags(u + 1, (u + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u & 1][j], af[u & 1][i], acc[i][j], 0, 0, 0);
-            if ((u * NP) / NU != ((u + 1) * NP) / NU) fire_piece((u * NP) / NU, BUF ^ 1);      // NP pieces spread evenly over the NU taps
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<ws_f32x4*>(&ep[frow * 36 + 8 * g + 4 * fhalf]) =
-                        ws_f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = h * 16 + er;
-                    const ws_f32x4 x0 = *reinterpret_cast<const ws_f32x4*>(&ep[row * 36 + ec]);
-                    const ws_f32x4 x1 = *reinterpret_cast<const ws_f32x4*>(&ep[row * 36 + ec + 4]);
-                    ws_u32x4 o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned rw = rr[i][j][h][q];
-                        const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
-                        o[q] = ws_pack2(finish(xa + __uint_as_float(rw << 16)), finish(xb + __uint_as_float(rw & 0xFFFF0000u)));
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, piece_off(i, j, h, p.ldy), 0, 0);
-                }
-            }
-        // the next tile's pixels have landed (everything but this tile's NSTORE stores has retired) and every wave is done with this
-        // tile's buffer
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NSTORE) : "memory");
-        __builtin_amdgcn_s_barrier();
-        tile = next;
-    };
-    while (true) {
-        one_tile(std::integral_constant<int, 0>{});
-        if (tile >= t_end) break;
-        one_tile(std::integral_constant<int, 1>{});
-        if (tile >= t_end) break;
-    }
-}
 #endif
 
 }  // namespace capf

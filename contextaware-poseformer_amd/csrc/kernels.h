@@ -174,12 +174,9 @@ hipError_t launch_pack_conv_bf16_rh(const float* w, const float* gamma, const fl
 bool gemm_bf16_ws_ok(const GemmArgs& a);
 int gemm_bf16_ws_tiles(const GemmArgs& a);              // blocks the problem needs (0 = not eligible)
 bool gemm_bf16_ws_wanted(const GemmArgs& a);            // eligible, carries Wp3, and large enough for this tile (a function of the conv alone)
-bool gemm_bf16_wsp_wanted(const GemmArgs& a);           // ... and narrow enough (Cin 32 / 48, >= 512 tiles) for the persistent, weight-resident form
-hipError_t launch_gemm_bf16_wsp(const GemmArgs& a, hipStream_t s);
 long bf16_ws_pack_elems(int Cout, int Cin);
 hipError_t launch_gemm_bf16_ws(const GemmArgs& a, hipStream_t s);
-hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s);      // one grid, the general tile for every problem
-hipError_t launch_gemm_bf16_ws_level(const GemmArgs* list, int n, hipStream_t s);      // the product's choice per problem (see igemm_bf16_ws.hip)
+hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_bf16_ws_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_bf16_ws(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                                     float eps, void* Wp_bf16, float* bias, int Cout, int Cin, hipStream_t s);

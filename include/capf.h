@@ -278,9 +278,8 @@ int capf_op_conv_bf16_rh(void* stream, const void* x_nhwc_bf16, const void* w_pa
  * 16-channel chunk of its pixels (with halo) once for all nine taps.  Cin % 16 == 0, Cout % 8 == 0, (rows + 2) x (W + 2) <= 416
  * for some row count dividing H.  w_packed holds capf_op_conv_bf16_ws_pack_elems(Cout, Cin) bf16 elements written by
  * capf_op_pack_conv_bf16_ws (BatchNorm folded as in capf_op_pack_conv_bf16; bias fp32 [Cout], may be NULL).
- * capf_op_conv_bf16_ws_group: up to 8 such convs the way capf_forward issues a level -- ONE grid, except that a conv with Cin of 32 /
- * 48 and >= 512 tiles takes the persistent, weight-resident form of the tile in a launch of its own (bit-identical results);
- * capf_conv_desc with bf16 x / residual / y and w_packed in this layout (ks = 3, stride = 1).                                                                                              */
+ * capf_op_conv_bf16_ws_group: up to 8 such convs in ONE grid, the way capf_forward issues a level; capf_conv_desc with bf16 x /
+ * residual / y and w_packed in this layout (ks = 3, stride = 1).                                                                                              */
 int64_t capf_op_conv_bf16_ws_pack_elems(int Cout, int Cin);
 int capf_op_pack_conv_bf16_ws(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
                               const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);

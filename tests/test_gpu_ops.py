@@ -811,25 +811,3 @@ def test_ws_engine_path_agrees_with_the_row_halo_kernels():
         print(f"2-D halo vs row-halo: relative L2 {rel:.2e}")
         assert rel < 1.5e-2
 
-
-@pytest.mark.parametrize("c,r,B", [(48, 64, 36), (32, 64, 40)])
-def test_persistent_ws_form_is_bit_identical_to_the_tile_and_matches_torch(c, r, B):
-    """A narrow conv (Cin 48 / 32) with >= 512 tiles runs the persistent, weight-resident form of the 2-D halo tile (igemm_bf16_wsp_block:
-    filter staged once per block, the next tile's pixels in flight under the current one).  The same frames as two half batches stay
-    below 512 tiles and run the plain tile: the results must be the same bits; and both match fp32 F.conv2d on the bf16-rounded operands."""
-    from capf import lib as capf
-    g = torch.Generator().manual_seed(c + B)
-    x = torch.randn(B, c, r, r, generator=g).bfloat16()
-    w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
-    bnp = (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) * 0.4 + 0.8)
-    res = torch.randn(B, c, r, r, generator=g).bfloat16()
-    wp, bias = capf.pack_conv_bf16_ws(w.cuda(), tuple(t.cuda() for t in bnp))
-    xd, rd = x.permute(0, 2, 3, 1).contiguous().cuda(), res.permute(0, 2, 3, 1).contiguous().cuda()
-    full, = capf.conv_nhwc_bf16_ws_group([(xd, wp, bias, 1, rd, c)])
-    h = B // 2
-    lo, = capf.conv_nhwc_bf16_ws_group([(xd[:h].contiguous(), wp, bias, 1, rd[:h].contiguous(), c)])
-    hi, = capf.conv_nhwc_bf16_ws_group([(xd[h:].contiguous(), wp, bias, 1, rd[h:].contiguous(), c)])
-    assert torch.equal(full, torch.cat([lo, hi]))
-    want = F.relu(F.conv2d(x.float(), _ws_fold(wp, c, c), bias.cpu(), 1, 1) + res.float())
-    got = full.float().cpu().permute(0, 3, 1, 2)
-    assert (got - want).abs().max().item() <= 2.0 ** -8 * max(1.0, want.abs().max().item()) * 1.5
