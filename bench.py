@@ -20,9 +20,12 @@ Rank 0 prints ONE JSON line: whole-job frames/s plus
                  the dense MFMA peak for the dtype and the 8 TB/s HBM peak (MI355X_MICROARCH.md); `bound` names the
                  roof the kernel sits closer to, `other_roof` carries the second one; `traffic` = measured HBM bytes
                  per launch from the offline rocprofv3 FETCH_SIZE / WRITE_SIZE passes of the same command
-                 (profiles/r02_hbm_traffic.json, keyed by configuration), null if not collected;
+                 (profiles/r04_hbm_traffic.json, keyed by configuration), null if not collected;
   cpu_baseline — the CPU oracle (a port of the reference forward to functional PyTorch-CPU) timed on this box's host
-                 cores on bounded samples of the same workload (rank 0, N=1 only): batch 1 and batch 16.
+                 cores on bounded samples of the same workload (rank 0, N=1 only): batch 1 and batch 16;
+  vs_fp32_oracle — accuracy beside the speed (same leg as cpu_baseline, inference): max |joint coordinate difference| and mean
+                 per-joint distance (metres) between the timed step's output and the fp32 CPU oracle on four of the run's own
+                 frames; --lifter-fp32 (plan flag CAPF_PLAN_LIFTER_FP32) keeps the lifter's projections fp32 under --dtype bf16.
 """
 import argparse
 import copy
@@ -75,6 +78,7 @@ def parse(argv=None):
     ap.add_argument("--embed", type=int, default=128, help="poseformer.embed_dim_ratio (128 = the reference default; 256 = the "
                     "labelled extra point for BASELINE's 'dim=256')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lifter-fp32", action="store_true", help="bf16 runs: lifter projections on the fp32 kernels (CAPF_PLAN_LIFTER_FP32)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
@@ -108,7 +112,9 @@ def config_tag(a):
 
 def workload_string(a, tag):
     head = f"configs[{tag}]" if tag is not None else "custom (not a BASELINE.json configuration)"
-    arith = "fp32 MFMA" if a.dtype == "f32" else "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)"
+    arith = ("fp32 MFMA" if a.dtype == "f32" else
+             "bf16 MFMA operands, fp32 accumulate (backbone convs; lifter GEMMs fp32: --lifter-fp32)" if getattr(a, "lifter_fp32", False) else
+             "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)")
     if a.train:
         return (f"{head}: TRAINING step, batch {a.batch}/GPU {a.backbone} {a.height}x{a.width} (frozen backbone forward, lifter "
                 f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), lifter embed {a.embed} levels 4, {arith}")
@@ -126,6 +132,22 @@ def respawn_under_torchrun(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def vs_fp32_oracle(backbone, sd_cpu, img, k2d, kc, got):
+    """The timed step's output against the fp32 CPU oracle on four of the run's own frames (the oracle is the checker here, as in
+    smoke(); part of the cpu_baseline leg)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import capf_oracle as oracle
+    B = img.shape[0]
+    idx = sorted({0, B // 3, (2 * B) // 3, B - 1})
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        want = oracle.ca_pf_forward(sd_cpu, img[idx].cpu(), k2d[idx].cpu(), kc[idx].cpu().clone(), backbone=backbone)
+    d = got[idx].cpu().float() - want
+    return {"frames": idx, "max_abs": float(d.abs().max()), "mean_joint_dist": float(d.norm(dim=-1).mean()), "unit": "m",
+            "reference": "oracle/capf_oracle.py, fp32 (pinned to the reference's outputs, tests/golden)"}
 
 
 def cpu_baseline(backbone, H, W, sd_cpu, budget_s=24.0):
@@ -237,7 +259,9 @@ def main():
     cfg.model.poseformer.embed_dim_ratio = a.embed
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32").eval()
+        from capf.lib import PLAN_LIFTER_FP32
+        pflags = PLAN_LIFTER_FP32 if (a.lifter_fp32 and a.dtype == "bf16") else 0
+        model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
 
@@ -302,7 +326,7 @@ def main():
             lanes = [(model, kc_work, torch.cuda.Stream(dev))]
             for _ in range(a.overlap - 1):
                 with contextlib.redirect_stdout(io.StringIO()):
-                    m2 = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32").eval()
+                    m2 = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
                 m2.load_state_dict(sd_cpu)
                 lanes.append((m2.to(dev), kc0.clone(), torch.cuda.Stream(dev)))
             if a.lanes >= 0:
@@ -398,7 +422,8 @@ def main():
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
         # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
         traffic, tsrc = None, None
-        for tfile, key in ((os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"), f"cfg{tag}"),
+        for tfile, key in ((os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), f"cfg{tag}"),
+                           (os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"), f"cfg{tag}"),
                            (os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"), f"cfg{tag}"),
                            (os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"), None)):
             if traffic is None and tag is not None and os.path.exists(tfile):
@@ -453,6 +478,8 @@ def main():
         if overlapped is not None:
             result["overlapped_steps"] = overlapped
         if world == 1 and not a.no_cpu_baseline:
+            if not a.train:
+                result["vs_fp32_oracle"] = vs_fp32_oracle(a.backbone, sd_cpu, img, k2d, kc0, out)
             result["cpu_baseline"] = cpu_baseline(a.backbone, H, W, sd_cpu)
             result["gpu_over_cpu"] = round(fps / result["cpu_baseline"]["value"], 1)
     if world > 1:

@@ -8,7 +8,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
-PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS = 1, 2, 4, 8, 16, 32     # capf_plan_flag
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32 = 1, 2, 4, 8, 16, 32, 64     # capf_plan_flag
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
@@ -41,7 +41,8 @@ class OpDesc(ctypes.Structure):
     """mirrors include/capf.h :: capf_op_desc"""
     _fields_ = [(k, c_int32) for k in ("kind", "backbone", "conv", "Cin", "H", "W", "Cout", "Ho", "Wo", "ks", "stride", "pad", "act",
                                        "in_dtype", "out_dtype", "mfma_bf16", "n_in")] + [("shift", c_int32 * 4)] + \
-               [(k, c_int32) for k in ("relu", "p_weight", "p_bn_weight", "has_residual", "checkpoint")]
+               [(k, c_int32) for k in ("relu", "p_weight", "p_bn_weight", "has_residual", "checkpoint", "rows_per_frame", "p_bias",
+                                       "p_ln_weight", "p_ln_bias")] + [("eps", c_float), ("attn", c_int32 * 4), ("maps", (c_int64 * 4) * 3)]
 
 
 _lib = None

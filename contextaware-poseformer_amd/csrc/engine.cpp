@@ -113,7 +113,8 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.out_bf16 = op.out_bf16;
     static const bool splitk_on = [] { const char* e = diag_env("CAPF_SPLITK"); return !e || atoi(e) != 0; }();   // A/B runs only
     if (op.conv && !op.bf16 && split_ws && lanes != 1 && splitk_on) {      // one stream: launches use the scratch one after the other
-        a.split_ws = split_ws; a.split_cnt = split_cnt;
+        a.split_ws = on_side_chain ? split_ws_side : split_ws;
+        a.split_cnt = on_side_chain ? split_cnt_side : split_cnt;
         a.split_ws_elems = SPLIT_WS_ELEMS; a.split_cnt_elems = SPLIT_CNT_ELEMS;
     }
     if (op.ln_w >= 0) {
@@ -349,7 +350,9 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                     if (two) {
                         HIP_TRY(hipEventRecord(events[op.i1], main_stream));
                         HIP_TRY(hipStreamWaitEvent(side[0], events[op.i1], 0));
+                        on_side_chain = true;
                         int rc = run_region_grouped(side[0], batch, op.region, nullptr, 0x6u);
+                        on_side_chain = false;
                         if (rc) return rc;
                         rc = run_region_grouped(main_stream, batch, op.region, nullptr, ~0x6u);
                         if (rc) return rc;
@@ -426,7 +429,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~63) {
+    if (cfg->plan_flags & ~127) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -447,6 +450,9 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&e.split_ws), Engine::SPLIT_WS_ELEMS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&e.split_cnt), Engine::SPLIT_CNT_ELEMS * sizeof(int));
         if (r == hipSuccess) r = hipMemset(e.split_cnt, 0, Engine::SPLIT_CNT_ELEMS * sizeof(int));
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&e.split_ws_side), Engine::SPLIT_WS_ELEMS * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&e.split_cnt_side), Engine::SPLIT_CNT_ELEMS * sizeof(int));
+        if (r == hipSuccess) r = hipMemset(e.split_cnt_side, 0, Engine::SPLIT_CNT_ELEMS * sizeof(int));
         for (int i = 0; i < 3 && r == hipSuccess; ++i) r = hipStreamCreateWithFlags(&e.side[i], hipStreamNonBlocking);
         e.events.resize(e.n_events);
         for (auto& x : e.events)
@@ -466,6 +472,8 @@ void capf_destroy(capf_handle* h) {
     if (h->e.pack_arena) (void)hipFree(h->e.pack_arena);
     if (h->e.split_ws) (void)hipFree(h->e.split_ws);
     if (h->e.split_cnt) (void)hipFree(h->e.split_cnt);
+    if (h->e.split_ws_side) (void)hipFree(h->e.split_ws_side);
+    if (h->e.split_cnt_side) (void)hipFree(h->e.split_cnt_side);
     for (auto& x : h->e.events)
         if (x) (void)hipEventDestroy(x);
     for (auto& st : h->e.side)
@@ -1088,10 +1096,16 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
     const capf::Op& op = e.ops[index];
     memset(d, 0, sizeof(*d));
     d->kind = op.kind == capf::OP_GEMM ? 0 : op.kind == capf::OP_FUSE ? 1 : op.kind == capf::OP_MAXPOOL ? 2
-              : op.kind == capf::OP_RESIZE ? 3 : -1;
+              : op.kind == capf::OP_RESIZE ? 3 : op.kind == capf::OP_LAYERNORM ? 4 : op.kind == capf::OP_ATTENTION ? 5 : -1;
     if (op.kind == capf::OP_FUSE && op.i0 == 1) d->kind = -1;          // debug copy
     d->backbone = index < e.n_backbone_ops;
-    d->p_weight = d->p_bn_weight = -1;
+    d->p_weight = d->p_bn_weight = d->p_bias = d->p_ln_weight = d->p_ln_bias = -1;
+    d->rows_per_frame = (int)op.rows_per_frame;
+    d->eps = op.eps;
+    {
+        const capf::RowMap* m[3] = {&op.amap, &op.omap, &op.rmap};
+        for (int k = 0; k < 3; ++k) { d->maps[k][0] = m[k]->G; d->maps[k][1] = m[k]->S1; d->maps[k][2] = m[k]->S2; d->maps[k][3] = m[k]->off; }
+    }
     const int act_dt = e.bf16() ? 2 : 0;
     d->in_dtype = d->out_dtype = (d->backbone ? act_dt : 0);
     d->H = op.H; d->W = op.W; d->Ho = op.Ho; d->Wo = op.Wo;
@@ -1109,7 +1123,21 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
             d->in_dtype = op.bf16 == 2 ? 2 : 0;
             d->out_dtype = op.out_bf16 ? 2 : 0;
             d->p_weight = pk.n_lin == 1 ? pk.w[0] : -1;
+            d->p_bias = pk.n_lin == 1 ? pk.b[0] : -1;
+            d->p_ln_weight = op.ln_w; d->p_ln_bias = op.ln_b;
         }
+    } else if (op.kind == capf::OP_LAYERNORM) {
+        d->Cin = d->Cout = op.C;
+        d->in_dtype = 0; d->out_dtype = op.out_bf16 ? 2 : 0;
+        d->has_residual = op.aux >= 0;
+        d->p_ln_weight = op.p0; d->p_ln_bias = op.p1;
+        d->maps[1][0] = 1; d->maps[1][1] = op.C; d->maps[1][2] = 0; d->maps[1][3] = 0;        // normalised rows are written densely
+    } else if (op.kind == capf::OP_ATTENTION) {
+        d->attn[0] = op.i0; d->attn[1] = op.i1; d->attn[2] = op.i2; d->attn[3] = op.i3;
+        d->rows_per_frame = op.i0 * op.i1;
+        d->Cin = 3 * op.i2 * op.i3; d->Cout = op.i2 * op.i3;
+        d->in_dtype = 0; d->out_dtype = op.out_bf16 ? 2 : 0;
+        d->maps[0][0] = 1; d->maps[0][1] = d->Cin; d->maps[1][0] = 1; d->maps[1][1] = d->Cout;
     } else {
         d->Cin = d->Cout = op.C;
         d->n_in = op.n_in; d->relu = op.relu;

@@ -164,6 +164,11 @@ struct Engine {
     float* pack_arena = nullptr;   // device, owned
     float* split_ws = nullptr;     // device, owned: split-K slabs + per-tile counters of the small-batch conv launches
     int* split_cnt = nullptr;
+    // the two-chain schedule (lanes == 3) runs two grouped chains CONCURRENTLY: the side chain's split-K convs get slabs and
+    // counters of their own (a conv splits or not by its shape alone, so both chains may hold splitting convs at once)
+    float* split_ws_side = nullptr;
+    int* split_cnt_side = nullptr;
+    bool on_side_chain = false;    // set around run_region_grouped(side[0], ...)
     static constexpr long SPLIT_WS_ELEMS = 4L << 20;
     static constexpr int SPLIT_CNT_ELEMS = 16384;
     float* ws = nullptr;           // device, borrowed

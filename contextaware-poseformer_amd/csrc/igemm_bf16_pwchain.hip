@@ -228,6 +228,14 @@ bool gemm_bf16_pwchain_ok(const GemmArgs& a, const GemmArgs& b) {
     if (a.K != 64 || a.Kpad != 64 || a.N != 256 || b.K != 256 || b.Kpad != 256 || b.N != 64 || b.res || a.M != b.M || !a.res) return false;
     if (reinterpret_cast<const unsigned short*>(b.A) != reinterpret_cast<const unsigned short*>(a.out) + a.omap.off || a.omap.S1 != b.K) return false;
     if (a.rmap.G != 1 || (a.rmap.S1 & 7) || (a.rmap.off & 7)) return false;
+    {   // b.out must not alias a.res / a.A: see gemm_f32_pwchain_ok
+        typedef const unsigned short* hp;
+        auto overlaps = [](hp p0, long n0, hp p1, long n1) { return p0 < p1 + n1 && p1 < p0 + n0; };
+        const hp bo = reinterpret_cast<hp>(b.out) + b.omap.off;
+        const long bn = (long)(b.M - 1) * b.omap.S1 + b.N;
+        if (overlaps(bo, bn, reinterpret_cast<hp>(a.res) + a.rmap.off, (long)(a.M - 1) * a.rmap.S1 + a.N)) return false;
+        if (overlaps(bo, bn, reinterpret_cast<hp>(a.A), (long)a.M * a.K)) return false;
+    }
     return a.M >= 32 * 1024 * 4;
 }
 

@@ -240,6 +240,15 @@ bool gemm_f32_pwchain_ok(const GemmArgs& a, const GemmArgs& b) {
     if (b.A != a.out + a.omap.off || a.omap.S1 != b.K) return false;          // b reads exactly what a writes, rows dense
     if (a.rmap.G != 1 || (a.rmap.S1 & 3) || (a.rmap.off & 3)) return false;
     if ((long)a.omap.S1 * 32 * 4 >= (1L << 31) || (long)a.rmap.S1 * 32 * 4 >= (1L << 31)) return false;
+    {   // As two launches the second conv's output may alias the first one's residual or input (both are dead by then and the plan's
+        // allocator reuses their memory); in ONE persistent kernel a wave stores t' rows while other waves still read those operands
+        // for later tiles.  Reject the chain unless b.out is disjoint from a.res and a.A.
+        auto overlaps = [](const float* p0, long n0, const float* p1, long n1) { return p0 < p1 + n1 && p1 < p0 + n0; };
+        const float* bo = b.out + b.omap.off;
+        const long bn = (long)(b.M - 1) * b.omap.S1 + b.N;
+        if (overlaps(bo, bn, a.res + a.rmap.off, (long)(a.M - 1) * a.rmap.S1 + a.N)) return false;
+        if (overlaps(bo, bn, a.A, (long)a.M * a.K)) return false;
+    }
     return a.M >= 32 * 1024 * 4;                                               // >= 4 tiles per wave of a full grid
 }
 

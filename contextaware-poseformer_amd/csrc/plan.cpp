@@ -570,7 +570,8 @@ void Engine::build_lifter(const Tensor feats[4]) {
     // a loss at K = 640, where 30 column tiles would each re-read 160 KB of rows (29 + 9.5 -> 44 us): the joint
     // blocks keep their LayerNorm launch
     // (compute_dtype = bf16: the projections take bf16 A rows, which the LayerNorm kernel writes directly)
-    const bool lb = bf16();                   // lifter projections (qkv / proj / fc1 / fc2) on the bf16 MFMA path
+    // lifter projections (qkv / proj / fc1 / fc2) on the bf16 MFMA path; CAPF_PLAN_LIFTER_FP32 keeps them (and their LayerNorm folding) fp32
+    const bool lb = bf16() && !(cfg.plan_flags & CAPF_PLAN_LIFTER_FP32);
     auto ln_fold_ok = [&](int dim) { return fused_lifter && dim <= 256 && !lb; };
     const bool ln_fold = ln_fold_ok(C);
     if (fused_lifter) {

@@ -54,16 +54,18 @@ class _MPJPEFn(torch.autograd.Function):
 
 class MPJPE(nn.Module):
     """loss.py:16-22: mean over every leading axis of ||pred - gt||_2 along the last one (any width: 3-D joints, 2-D keypoints).
-    CUDA tensors only — there is no CPU fallback; other float dtypes are computed in fp32."""
+    CUDA tensors only — there is no CPU fallback; other float dtypes are computed in fp32 and the loss is cast back to the inputs' dtype."""
 
     def forward(self, keypoints_pred, keypoints_gt):
         assert keypoints_pred.shape == keypoints_gt.shape
         if not (keypoints_pred.is_cuda and keypoints_gt.is_cuda):
             from capf.lib import CapfError
             raise CapfError("MPJPE runs on the MI355X only: got a CPU tensor (no CPU fallback)")
+        dt = torch.promote_types(keypoints_pred.dtype, keypoints_gt.dtype)
         if keypoints_pred.dtype != torch.float32 or keypoints_gt.dtype != torch.float32:
             keypoints_pred, keypoints_gt = keypoints_pred.float(), keypoints_gt.float()
-        return _MPJPEFn.apply(keypoints_pred, keypoints_gt)
+        loss = _MPJPEFn.apply(keypoints_pred, keypoints_gt)
+        return loss if dt == torch.float32 else loss.to(dt)        # the reference returns the inputs' dtype (torch.norm / mean)
 
 
 def _set_mean(pred, gt, column, per_pair=False):

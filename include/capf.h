@@ -83,7 +83,9 @@ enum capf_plan_flag {
     CAPF_PLAN_NO_ROW_HALO = 4,      /* bf16 3x3 stride-1 convs on the direct bf16 kernel */
     CAPF_PLAN_WINOGRAD_F23_ONLY = 8, /* F(2,3) where F(4,3) would be chosen */
     CAPF_PLAN_NO_PWCHAIN = 16,      /* layer1's conv3 -> next conv1 pairs as two pointwise launches instead of one chained kernel */
-    CAPF_PLAN_NO_WS = 32            /* bf16 3x3 stride-1 convs without the 2-D halo tile (row-halo / direct kernels as in round 3) */
+    CAPF_PLAN_NO_WS = 32,           /* bf16 3x3 stride-1 convs without the 2-D halo tile (row-halo / direct kernels as in round 3) */
+    CAPF_PLAN_LIFTER_FP32 = 64      /* compute_dtype = CAPF_BF16: keep the lifter's qkv / proj / fc1 / fc2 on the fp32 kernels (bf16 backbone only);
+                                     * the accuracy / speed trade bench.py reports as `vs_fp32_oracle`                                    */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -383,7 +385,8 @@ int capf_op_schedule(const capf_handle* h, int index, int32_t* region, int32_t* 
  *                         5 output; the external image for the stem's input).
  * tests/test_gpu_layerwise.py recomputes every backbone op on the CPU from the engine's inputs and compares outputs.   */
 typedef struct capf_op_desc {
-    int32_t kind;              /* 0 conv / linear on the MFMA kernels, 1 fuse-sum, 2 max-pool 3x3 s2, 3 bilinear resize, -1 other */
+    int32_t kind;              /* 0 conv / linear on the MFMA kernels, 1 fuse-sum, 2 max-pool 3x3 s2, 3 bilinear resize, 4 LayerNorm over rows,
+                                * 5 multi-head self-attention over the tokens of a group, -1 other */
     int32_t backbone;          /* 1: the op belongs to the backbone plan */
     int32_t conv;              /* kind 0: 1 = convolution (NHWC), 0 = rows-mode linear */
     int32_t Cin, H, W, Cout, Ho, Wo, ks, stride, pad, act;   /* act: 0 none, 1 ReLU, 2 GELU */
@@ -393,6 +396,18 @@ typedef struct capf_op_desc {
     int32_t p_weight, p_bn_weight;                           /* capf_param_info indices of <conv>.weight and <bn>.weight; -1 */
     int32_t has_residual;
     int32_t checkpoint;
+    /* rows-mode ops of the lifter (kind 0 with conv == 0, kinds 4 and 5; pose_dformer.py:15-79): row m of an operand lives at element
+     * (m / G) * S1 + (m % G) * S2 + off of its buffer, maps[k] = {G, S1, S2, off} for k = 0 input rows, 1 output rows, 2 residual rows
+     * (kind 4: the rows ADDED to the input before normalising).  kind 0: Cin = K, Cout = N, p_weight / p_bias [N,K] / [N]; an
+     * in-place update (proj, fc2: output rows == residual rows) reads its residual from the state BEFORE the op, i.e. after
+     * capf_forward_prefix(index), its result after capf_forward_prefix(index + 1).  kind 4: Cin = width, p_ln_weight / p_ln_bias, eps.
+     * kind 5: input rows [groups * tokens, 3 * heads * head_dim] ordered (q | k | v) x heads x head_dim (pose_dformer.py:49), output
+     * rows [groups * tokens, heads * head_dim]; groups per frame / tokens / heads / head_dim in attn[4].                            */
+    int32_t rows_per_frame;
+    int32_t p_bias, p_ln_weight, p_ln_bias;
+    float eps;
+    int32_t attn[4];
+    int64_t maps[3][4];
 } capf_op_desc;
 int capf_forward_prefix(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
                         int batch, float* out, int n_ops);

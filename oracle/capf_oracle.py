@@ -217,7 +217,7 @@ def _res_bottleneck(P, pre, x, stride, nm=FP32):
     return _cbr(P, pre + ".conv3", pre + ".bn3", y, res=x, nm=nm)
 
 
-def cpn_forward(P, x, pre="backbone", out_hw=(64, 48), nm=FP32):
+def cpn_forward(P, x, pre="backbone", out_hw=(64, 48), nm=FP32, taps=None):
     """CPN.forward networks/network.py:16-22 -> 4 maps [B,256,64,48].
 
     The `predict` heads of globalNet (globalNet.py:71) and refineNet.final_predict are computed and
@@ -238,14 +238,22 @@ def cpn_forward(P, x, pre="backbone", out_hw=(64, 48), nm=FP32):
     fms, u = [], None
     for i in range(4):                                                       # globalNet.py:61-83
         f = _cbr(P, f"{g}.laterals.{i}.0", f"{g}.laterals.{i}.1", res_out[i], nm=nm)
-        if i > 0:
-            # feature_i = lateral_i + BN(conv1x1(bilinear x2(feature_{i-1})))   (:66-70; the engine adds the lateral in the
-            # upsample conv's epilogue: one rounding in bf16 mode)
-            up = _cbr(P, f"{g}.upsamples.{i - 1}.1", f"{g}.upsamples.{i - 1}.2", u, relu=False, nm=_NOROUND if nm.bf16 else FP32)
-            f = nm.r(f + up)
+        if i > 0 and not nm.bf16:
+            # feature_i = lateral_i + BN(conv1x1(bilinear x2(feature_{i-1})))   (:66-70), in the reference's order
+            u = F.interpolate(fms[i - 1], scale_factor=2, mode="bilinear", align_corners=True)
+            f = f + _cbr(P, f"{g}.upsamples.{i - 1}.1", f"{g}.upsamples.{i - 1}.2", u, relu=False)
+        elif i > 0:
+            # bf16 emulation follows the ENGINE's order (csrc/plan.cpp build_cpn): a bias-free 1x1 conv + eval BatchNorm is a per-pixel
+            # affine map and commutes with the interpolation, so the engine convolves the LOW-resolution map, stores THAT in bf16,
+            # then interpolates, adds the lateral in fp32 and rounds once
+            low = _cbr(P, f"{g}.upsamples.{i - 1}.1", f"{g}.upsamples.{i - 1}.2", fms[i - 1], relu=False, nm=nm)
+            if taps is not None:
+                taps.setdefault("cpn_lateral", []).append(f)
+                taps.setdefault("cpn_up_low", []).append(low)
+            f = nm.r(F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True) + f)
         fms.append(f)
-        if i != 3:
-            u = nm.r(F.interpolate(f, scale_factor=2, mode="bilinear", align_corners=True))
+    if taps is not None:
+        taps["cpn_fms"] = fms
 
     rn = pre + ".refine_net"
     outs = []
@@ -475,7 +483,7 @@ def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit
     nm = BF16 if emulate_bf16 else FP32
     x = images.permute(0, 3, 1, 2).contiguous()
     ref = normalise_crop_keypoints_(kcrop)
-    feats = cpn_forward(P, x, nm=nm) if backbone == "cpn" else hrnet_forward(P, x, nm=nm)
+    feats = cpn_forward(P, x, nm=nm, taps=taps) if backbone == "cpn" else hrnet_forward(P, x, nm=nm)
     if taps is not None:
         taps["ref"] = ref.clone()
         taps["features"] = feats

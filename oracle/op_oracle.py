@@ -14,6 +14,8 @@ The ops follow the reference's modules exactly as capf_oracle does:
     fuse sum (nearest upsample + add + ReLU)      pose_hrnet.py:294-301
     max-pool 3x3 s2 p1                            networks/resnet.py:140
     bilinear resize, align_corners=True           globalNet.py:40, refineNet.py:61
+    nn.Linear (+ residual) (+ GELU), LayerNorm,
+    multi-head self-attention of the lifter       pose_dformer.py:15-79 (Mlp :15-31, Attention :34-59, Block :62-79)
 """
 import torch
 import torch.nn.functional as F
@@ -75,6 +77,37 @@ def resize(x_nhwc, Ho, Wo, bf16, add_nhwc=None):
     if add_nhwc is not None:
         y = y + _nchw(add_nhwc)
     return _nhwc(nm.r(y))
+
+
+def linear_rows(a_rows, w, b, res_rows, gelu, bf16_operands, out_bf16):
+    """One nn.Linear of the lifter on the engine's own rows: a_rows [M, K] (bf16 rows if the op runs on the bf16 MFMA path), w [N, K],
+    b [N], optional fp32 residual rows -> (what the engine must store, mass = sum |a| |w| + |b| + |residual|)."""
+    a = a_rows.float()
+    w = oracle.bf16_round(w) if bf16_operands else w
+    y = a @ w.t() + b
+    mass = a.abs() @ w.abs().t() + b.abs()
+    if res_rows is not None:
+        y = y + res_rows.float()
+        mass = mass + res_rows.float().abs()
+    if gelu:
+        y = F.gelu(y)                                        # exact erf form (pose_dformer.py:17 nn.GELU)
+        mass = mass * 1.2                                    # |gelu'| <= 1.13
+    return (oracle.bf16_round(y) if out_bf16 else y), mass
+
+
+def layernorm_rows(x_rows, add_rows, g, b, eps, out_bf16):
+    x = x_rows.float() if add_rows is None else x_rows.float() + add_rows.float()
+    y = F.layer_norm(x, (x.shape[-1],), g, b, eps)
+    return oracle.bf16_round(y) if out_bf16 else y
+
+
+def attention_rows(qkv_rows, groups, tokens, heads, hd, out_bf16):
+    """qkv rows [groups * tokens, 3 * heads * hd] ordered (q | k | v) x heads x hd (pose_dformer.py:49) -> [groups * tokens, heads * hd]"""
+    qkv = qkv_rows.float().view(groups, tokens, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)
+    y = (att @ v).transpose(1, 2).reshape(groups * tokens, heads * hd)
+    return oracle.bf16_round(y) if out_bf16 else y
 
 
 def compare(got, want, bf16, mass=None, term=None):

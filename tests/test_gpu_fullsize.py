@@ -105,6 +105,52 @@ def test_batch64_fp32_slice_of_the_other_backbones_vs_oracle(backbone, H, W):
     assert err <= 1e-3
 
 
+def check_cells_against_index_rule(eng, B, tag):
+    """At a PRODUCTION batch: the NW corners the deformable sampler gathered from (cidx{i}) == oracle.bilinear_corners(the positions the
+    kernel itself computed (cpos{i}), 'border') bit for bit, for all 4 blocks x 4 levels x B x 17 x 16 samples; prints how many samples
+    sit within 4 ulp of a cell boundary (where grid_sample's one-sided derivative makes the choice of cell matter)."""
+    n, near = 0, 0
+    for i in range(4):
+        pos = eng.tensor(f"cpos{i}")[:B].cpu().view(B, 17, 4, 16, 2).numpy()
+        idx = eng.tensor(f"cidx{i}")[:B].cpu().view(B, 17, 4, 16, 2).numpy()
+        for l in range(4):
+            f = eng.tensor(f"feat{l}")
+            H, W = f.shape[1], f.shape[2]
+            want = oracle.bilinear_corners(pos[:, :, l], H, W, "border")
+            np.testing.assert_array_equal(idx[:, :, l, :, 0], want["ix0"])
+            np.testing.assert_array_equal(idx[:, :, l, :, 1], want["iy0"])
+            for g, size in ((pos[:, :, l, :, 0], W), (pos[:, :, l, :, 1], H)):
+                x = np.clip(((g + np.float32(1)) / np.float32(2)) * np.float32(size - 1), 0, size - 1).astype(np.float32)
+                near += int((np.abs(x - np.rint(x)) <= 4 * np.spacing(np.maximum(np.abs(x), np.float32(1)))).sum())
+            n += want["ix0"].size
+    print(f"  {tag}: {n} deformable samples, corner indices == ATen's rule on the kernel's own positions bit for bit; "
+          f"{near} coordinates within 4 ulp of a cell boundary")
+    assert n == 4 * 4 * B * 17 * 16
+    return near
+
+
+# parameters whose gradient contains NO derivative of a sample w.r.t. its position (everything behind the last deformable sampler, and
+# the last context block's value / weight path): grid_sample's one-sided position derivative cannot touch them, so they are compared
+# against the oracle with its OWN floor() cells
+def _independent_of_cells(k):
+    return (k.startswith(("volume_net.res_blocks.", "volume_net.joint_blocks.", "volume_net.head.")) or
+            k.startswith(("volume_net.context_blocks.3.embed_proj.", "volume_net.context_blocks.3.attention_weights.",
+                          "volume_net.context_blocks.3.mlp.", "volume_net.context_blocks.3.norm2.")))
+
+
+def test_cfg1_batch64_inference_corner_indices_bit_exact():
+    """The fused inference kernel (ctx_attn_kernel) at configs[1]'s batch."""
+    B = 64
+    model, sd = _model("hrnet_32", "fp32", 41)
+    img, k2d, kc = synth.synth_inputs(B, 256, 256, seed=42, crop_range=(256, 256))
+    eng = model.engine_for(img.cuda())
+    eng.set_debug(True)
+    with torch.no_grad():
+        model(img.cuda(), k2d.cuda(), kc.cuda())
+    torch.cuda.synchronize()
+    check_cells_against_index_rule(eng, B, "cfg1 B=64 inference (ctx_attn_kernel)")
+
+
 def _train_model(B, drop):
     from mvn.models.loss import MPJPE
     model, sd = _model("hrnet_32", "fp32", 47)
@@ -133,6 +179,7 @@ def test_cfg3_training_step_batch64_all_191_gradients_vs_oracle_autograd(drop):
     loss = crit(pred, gt.cuda())
     loss.backward()
     torch.cuda.synchronize()
+    check_cells_against_index_rule(eng, B, f"cfg3 B=64 train (deform_sample_kernel, DropPath {'on' if drop else 'off'})")
     # the oracle differentiates the deformable samplers in the cells the engine used (see the batch-512 test below)
     cells = [eng.tensor(f"cidx{i}")[:B].cpu().view(B, 17, 4, 16, 2).long() for i in range(4)]
     P = {k: (v.clone().requires_grad_(True) if k.startswith("volume_net.") else v) for k, v in sd.items()}
@@ -152,6 +199,19 @@ def test_cfg3_training_step_batch64_all_191_gradients_vs_oracle_autograd(drop):
         assert rel < 1e-4, (k, rel)                            # (fp32 against fp32: measured 4e-6)
     print(f"  {n} gradients, worst max-abs error relative to the gradient's own max: {worst:.2e}")
     assert n == 191
+    # ... and an INDEPENDENT yardstick: the oracle differentiated in its own floor() cells, for every gradient that contains no
+    # derivative of a sample w.r.t. its position
+    P2 = {k: (v.clone().requires_grad_(True) if k.startswith("volume_net.") else v) for k, v in sd.items()}
+    w2 = oracle.ca_pf_forward(P2, img, k2d, kc.clone(), backbone="hrnet_32", drop_masks=masks.cpu() if drop else None)
+    oracle.mpjpe(w2, gt).backward()
+    worst2, n2 = 0.0, 0
+    for k, p in P2.items():
+        if k.startswith("volume_net.") and _independent_of_cells(k):
+            rel = ((named[k].grad.cpu() - p.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)).item()
+            worst2 = max(worst2, rel); n2 += 1
+            assert rel < 1e-4, (k, rel)
+    print(f"  {n2} gradients without a position derivative vs the oracle in its OWN floor() cells: worst {worst2:.2e}")
+    assert n2 == 116
 
 
 def test_cfg3_training_step_batch512_vs_oracle_autograd():
@@ -196,7 +256,18 @@ def test_cfg3_training_step_batch512_vs_oracle_autograd():
     # With the cells shared, (a) disappears from the comparison as well (both sides sum the same rows; measured: every one of the
     # 191 gradients within 1.4e-6 relative L2 and 3.1e-6 of its max per entry, where the fp32 oracle with its own floor() cells
     # sits up to 2.3e-4 from the fp64 yardstick).  Bound: 2e-5 for both.
+    check_cells_against_index_rule(eng, B, "cfg3 B=512 train (deform_sample_kernel)")
     cells = [eng.tensor(f"cidx{i}")[:B].cpu().view(B, 17, 4, 16, 2).long() for i in range(4)]
+    # independent yardstick (the fp32 oracle above differentiated in its OWN floor() cells): every gradient that contains no derivative
+    # of a sample w.r.t. its position
+    worst2, n2 = 0.0, 0
+    for k, p in P.items():
+        if k.startswith("volume_net.") and _independent_of_cells(k):
+            rel = ((grads[k] - p.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)).item()
+            worst2 = max(worst2, rel); n2 += 1
+            assert rel < 1e-4, (k, rel)
+    print(f"  {n2} gradients without a position derivative vs the fp32 oracle in its OWN floor() cells: worst {worst2:.2e}")
+    assert n2 == 116
 
     def lifter64(fs, cells=None):
         Q = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("volume_net.")}

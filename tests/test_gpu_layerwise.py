@@ -101,3 +101,77 @@ def test_layerwise_small_batches_take_the_other_kernels():
     layerwise("hrnet_32", "fp32", 1, 256, 256, [0])
     layerwise("hrnet_48", "bf16", 2, 256, 256, [0, 1])
     layerwise("cpn", "fp32", 2, 384, 288, [0, 1])
+
+
+def lifter_layerwise(backbone, B, H, W, frames, wseed=73, iseed=74):
+    """The lifter half of the tight check under compute_dtype = bf16: every LayerNorm (bf16 writer), attention (bf16 writer) and qkv / proj /
+    fc1 + GELU / fc2 launch of the three block groups (pose_dformer.py:15-79) recomputed on the CPU from the rows the ENGINE produced.
+    proj and fc2 update the token stream in place, so an op's operands are read after capf_forward_prefix(i) and its result after
+    capf_forward_prefix(i + 1) (the schedule is deterministic).  fp32 results: 2e-5 of each output's sum of |terms|; bf16 results: the
+    same or the adjacent bf16 number."""
+    model, sd = _model(backbone, "bf16", wseed)
+    img, k2d, kc = synth.synth_inputs(B, H, W, seed=iseed, crop_range=(W, H))
+    img_d, k2d_d, kc_d = img.cuda(), k2d.cuda(), kc.cuda()
+    out = torch.empty(B, 1, 17, 3, device="cuda")
+    eng = model.engine_for(img_d)
+    names = [n for n, _, _ in eng.schema()]
+    n_ops = eng.lib.capf_num_ops(eng.h)
+    descs = [eng.op_describe(i) for i in range(n_ops)]
+    table = eng.op_table(B)
+    stream = torch.cuda.current_stream().cuda_stream
+    todo = [i for i, d in enumerate(descs) if not d.backbone and ((d.kind == 0 and not d.conv) or d.kind in (4, 5))]
+    fr = torch.tensor(frames)
+
+    def rows_of(i, slot, k, width, dt):
+        d = descs[i]
+        G, S1, S2, off = (int(v) for v in d.maps[k])
+        m = (fr[:, None] * d.rows_per_frame + torch.arange(d.rows_per_frame)[None, :]).reshape(-1)
+        addr = (m // G) * S1 + (m % G) * S2 + off
+        mb = torch.arange(B * d.rows_per_frame)
+        n = int(((mb // G) * S1 + (mb % G) * S2 + off).max()) + width
+        flat = eng.op_tensor(i, slot, (n,), dt)
+        return flat[(addr[:, None] + torch.arange(width)[None, :]).cuda()].cpu()
+
+    counts, worst = {}, {}
+    for i in todo:
+        d = descs[i]
+        eng.forward_prefix(img_d, i, stream, k2d_d, kc_d.clone(), out)
+        torch.cuda.synchronize()
+        a = rows_of(i, 0, 0, d.Cin, d.in_dtype)
+        res = rows_of(i, 4, 2, d.Cout if d.kind == 0 else d.Cin, 0) if d.has_residual else None
+        eng.forward_prefix(img_d, i + 1, stream, k2d_d, kc_d.clone(), out)
+        torch.cuda.synchronize()
+        got = rows_of(i, 5, 1, d.Cout, d.out_dtype)
+        out_bf = d.out_dtype == 2
+        mass = None
+        with torch.no_grad():
+            if d.kind == 0:
+                assert d.p_weight >= 0 and d.p_ln_weight < 0
+                want, mass = op_oracle.linear_rows(a, sd[names[d.p_weight]], sd[names[d.p_bias]], res, d.act == 2, d.in_dtype == 2, out_bf)
+                kind = ("fc1+gelu" if d.act == 2 else table[i][0].split(".")[-1]) + (" bf16" if d.in_dtype == 2 else " fp32")
+            elif d.kind == 4:
+                want = op_oracle.layernorm_rows(a, res, sd[names[d.p_ln_weight]], sd[names[d.p_ln_bias]], d.eps, out_bf)
+                kind = "layernorm"
+            else:
+                g, t, h, hd = (int(v) for v in d.attn)
+                want = op_oracle.attention_rows(a, g * len(frames), t, h, hd, out_bf)
+                kind = "attention"
+        r = op_oracle.compare(got, want, out_bf, mass)
+        assert r["ok"], (table[i][0], table[i][1], r)
+        counts[kind] = counts.get(kind, 0) + 1
+        worst[kind] = max(worst.get(kind, 0.0), r["max_err"])
+    print(f"{backbone} bf16 B={B}: {len(todo)} lifter ops recomputed from the engine's own rows on {len(frames)} frames")
+    for k in sorted(counts):
+        print(f"    {k:18s} x {counts[k]:2d}   worst error {worst[k]:9.2e} of the allowance")
+    return counts
+
+
+def test_cfg2_lifter_layerwise_hrnet48_bf16_batch256():
+    c = lifter_layerwise("hrnet_48", 256, 256, 256, [0, 85, 170, 255])
+    assert c.get("qkv bf16") == 8 and c.get("proj bf16") == 8 and c.get("fc1+gelu bf16") == 12 and c.get("fc2 bf16") == 12
+    assert c.get("layernorm") == 20 and c.get("attention") == 8
+
+
+def test_cfg4_lifter_layerwise_cpn_bf16_batch128():
+    c = lifter_layerwise("cpn", 128, 384, 288, [0, 42, 85, 127])
+    assert c.get("qkv bf16") == 8 and c.get("fc2 bf16") == 12 and c.get("layernorm") == 20 and c.get("attention") == 8

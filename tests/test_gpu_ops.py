@@ -338,12 +338,15 @@ def test_engine_modes_are_bit_identical(dtype, backbone):
     assert (outs[0] - outs[1]).abs().max().item() <= (2e-6 if dtype == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("dtype,backbone", [("fp32", "hrnet_32"), ("bf16", "hrnet_48"), ("bf16", "cpn")])
-def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone):
+@pytest.mark.parametrize("dtype,backbone,B,H,W,flags", [("fp32", "hrnet_32", 24, 256, 192, 0), ("bf16", "hrnet_48", 24, 256, 192, 0),
+                                                         ("bf16", "cpn", 24, 256, 192, 0), ("fp32", "hrnet_32", 16, 64, 64, 2)])
+def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone, B, H, W, flags):
     """capf_set_lanes 3 (the default at batch 16..256: a region's lanes as two grouped chains on two streams, fork / join with
     events) against mode 2 (one chain on the caller's stream) at batch 24: same kernels on the same operands, only their
     grouping and their stream differ -> the same bits, call after call (a missing event dependency would show up as a
-    run-to-run difference)."""
+    run-to-run difference).  The 64 x 64 / batch 16 case runs with CAPF_PLAN_NO_WINOGRAD: its 16 x 16 ... 2 x 2 maps are a handful of
+    tiles per conv, so the 3x3 convs of BOTH concurrent chains take the split-K path (a conv splits by its shape alone) and must not
+    share slabs and counters (each chain has its own)."""
     import copy, contextlib, io
     from capf import synth
     from mvn.models.conpose import CA_PF
@@ -351,10 +354,10 @@ def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone):
     cfg = backbone_preset(copy.deepcopy(config), backbone)
     cfg.model.backbone.fix_weights = True
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg, compute_dtype=dtype).eval()
+        model = CA_PF(cfg, compute_dtype=dtype, plan_flags=flags).eval()
     synth.load_synthetic(model, seed=3, bn_mode="random")
     model = model.cuda()
-    img, k2d, kc = synth.synth_inputs(24, 256, 192, seed=5, crop_range=(192, 256))
+    img, k2d, kc = synth.synth_inputs(B, H, W, seed=5, crop_range=(W, H))
     img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
     eng_out = {}
     with torch.no_grad():
@@ -401,6 +404,38 @@ def test_pointwise_chain_is_bit_identical_to_its_two_launches():
         assert torch.equal(res[0][0], res[1][0])
         for a, b in zip(res[0][1], res[1][1]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("backbone,B,H,W", [("hrnet_48", 64, 256, 256), ("cpn", 32, 384, 288)])
+def test_bf16_pointwise_chain_agrees_with_its_two_launches(backbone, B, H, W):
+    """The bf16 twin (igemm_bf16_pwchain: y rounded once in registers, the second conv's 16-product groups summed in a permuted slot
+    order) against CAPF_PLAN_NO_PWCHAIN.  The first conv is bit-identical; the second differs by fp32 summation order inside an MFMA,
+    i.e. by at most one bf16 rounding of its output -- which a deep bf16 network amplifies to its rounding-noise floor (bf16_report.py),
+    so the context maps are held to that floor (the layer-wise test checks the chained ops themselves one by one)."""
+    import copy, contextlib, io
+    from capf import synth
+    from capf.lib import PLAN_NO_PWCHAIN
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), backbone)
+    cfg.model.backbone.fix_weights = True
+    img, k2d, kc = synth.synth_inputs(B, H, W, seed=21, crop_range=(W, H))
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    res = []
+    for flags in (0, PLAN_NO_PWCHAIN):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = CA_PF(cfg, compute_dtype="bf16", plan_flags=flags).eval()
+        synth.load_synthetic(m, seed=3, bn_mode="random")
+        m = m.cuda()
+        with torch.no_grad():
+            m(img, k2d, kc.clone())
+        eng = m.engine_for(img)
+        res.append(([eng.tensor(f"feat{l}")[:B].float().clone() for l in range(4)], [k for _, k, _ in eng.op_table(B)]))
+    assert any(k.startswith("igemm_bf16_pwchain") for k in res[0][1]) and not any(k.startswith("igemm_bf16_pwchain") for k in res[1][1])
+    for a, b in zip(res[0][0], res[1][0]):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"bf16 chain vs two launches ({backbone}): relative L2 {rel:.2e}")
+        assert rel < 1.5e-2
 
 
 def test_grouped_bf16_conv_launch_is_bit_identical_to_single_launches():
