@@ -199,6 +199,11 @@ def cpu_baseline(backbone, H, W, sd_cpu, budget_s=24.0):
                       f"(functional PyTorch-CPU/oneDNN; value = median batch-16 rate at {best_threads} threads, the best of the sweep in `points`)"}
 
 
+def input_seed(rank):
+    """Every rank draws its OWN shard of synthetic frames (data parallel: different frames per GPU)."""
+    return 1000 + rank
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -228,8 +233,11 @@ def main():
             mine = torch.tensor([B * a.steps / own_s], dtype=torch.float64)
             rates = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(rates, mine)
+            seed = torch.tensor([input_seed(rank)], dtype=torch.int64)
+            seeds = [torch.empty_like(seed) for _ in range(world)]
+            dist.all_gather(seeds, seed)
             dry_dist = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()), "devices_visible": torch.cuda.device_count(),
-                        "per_rank_frames_per_s": [round(r.item(), 2) for r in rates]}
+                        "per_rank_frames_per_s": [round(r.item(), 2) for r in rates], "input_seeds": [int(x.item()) for x in seeds]}
         elapsed = cdist.max_over_ranks(mine_s, torch.device("cpu"))
         if rank == 0:
             print(json.dumps({"metric": "frames/sec", "value": round(B * world * a.steps / elapsed, 2), "unit": "frames/s",
@@ -265,7 +273,7 @@ def main():
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
 
-    img, k2d, kc, gt = synth.synth_inputs(B, H, W, seed=1000 + rank, crop_range=(192, 256), with_gt=True)
+    img, k2d, kc, gt = synth.synth_inputs(B, H, W, seed=input_seed(rank), crop_range=(192, 256), with_gt=True)
     img, k2d, kc0, gt = img.to(dev), k2d.to(dev), kc.to(dev), gt.to(dev)
     kc_work = kc0.clone()
     stream = torch.cuda.current_stream(dev)

@@ -145,6 +145,26 @@ def test_bench_self_spawns_two_ranks_dry_run():
     assert d["per_rank_frames_per_s"][0] > d["per_rank_frames_per_s"][1] > 0     # rank 1 sleeps twice as long
 
 
+def test_bench_eight_rank_dry_run_of_the_cpn_configuration():
+    """The flow the driver's 8-GPU scaling run takes for configs[4] (`--gpus 8 --config 4`), as a dry run on CPU: eight ranks
+    rendezvous on 127.0.0.1, a collective on the backend sees all eight, every rank reports its own rate and draws its own input seed,
+    rank 0 prints one line whose frames_per_step is the whole job's (weak scaling: 128 frames per rank)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run",
+                        "--backend", "gloo", "--config", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    d = j["distributed"]
+    assert j["n_gpus"] == 8 and j["config"]["frames_per_step"] == 8 * 128 and j["scaling"] == "weak" and j["dtype"] == "bf16"
+    assert d["ranks_seen"] == 8 and len(d["per_rank_frames_per_s"]) == 8
+    assert len(set(d["input_seeds"])) == 8
+    assert j["config"]["workload"].startswith("configs[4]")
+
+
 def test_bench_labels_follow_the_arguments():
     import importlib.util, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
