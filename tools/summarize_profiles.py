@@ -40,7 +40,7 @@ def short(name):
     m = re.match(r"(?:void )?capf::igemm_f32_group_kernel", name)
     if m:
         return "igemm_f32_group"
-    m = re.match(r"(?:void )?capf::igemm_bf16_group_(pp|rh)_kernel", name)
+    m = re.match(r"(?:void )?capf::igemm_bf16_group_(pp|rh|ws)_kernel", name)
     if m:
         return "igemm_bf16_group_" + m.group(1)
     m = re.match(r"(?:void )?capf::igemm_bf16_rh_kernel", name)
