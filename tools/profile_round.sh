@@ -3,7 +3,8 @@
 #   bash tools/profile_round.sh r2_cfg2 cfg2 --config 2
 # leaves raw CSVs under gpurun_out/<tag>/ ; reduce them (again, in the build container) with
 #   python tools/summarize_profiles.py gpurun_out/r3_cfg2 r03 cfg2
-# Counters are collected in their own passes (no trace domains next to --pmc).  The traffic file is reduced on the box
+# The trace pass runs with --overlap 0: two batches in flight on two streams (bench.py's extra overlapped_steps measurement) stretch
+# every kernel's duration in a trace.  Counters are collected in their own passes (no trace domains next to --pmc).  The traffic file is reduced on the box
 # BEFORE the final bench run, so that the bench line of the same build carries `roofline.traffic`.
 TAG=${1:-r2}; KEY=${2:-cfg1}; shift; shift
 OUT=$PWD/gpurun_out/$TAG
@@ -11,7 +12,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python $PWD/bench.py --no-cpu-baseline $*"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH --steps 10 > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH --steps 10 --overlap 0 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH --steps 2 --warmup 1 --profile-steps 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $BENCH --steps 2 --warmup 1 --profile-steps 1 > $OUT/pmc_write.log 2>&1
 cd - > /dev/null
