@@ -290,16 +290,24 @@ def main():
         model.flat_grad_only = True                                          # gradient -> all-reduce -> AdamW on the flat buffer
         crit = MPJPE()
 
+        phase_ev = None                                                       # (after the timed region: event pairs around the phases)
+
         def step():
+            mark = (lambda: None) if phase_ev is None else (lambda: (phase_ev.append(torch.cuda.Event(enable_timing=True)), phase_ev[-1].record()))
+            mark()
             kc_work.copy_(kc0)
             pred = model(img, k2d, kc_work)                                  # DropPath active (dpr 0..0.2)
             loss = crit(pred, gt)
+            mark()
             model.zero_grad(set_to_none=True)
             loss.backward()
+            mark()
             flat_g = model.last_flat_grad
             flat_g, gscale = cdist.allreduce_sum_(flat_g)                    # ONE RCCL all-reduce of 56.4 MB (C3) ...
+            mark()
             opt.step(flat_g, grad_scale=gscale)                              # ... its 1 / world folded into the AdamW kernel
             model.lifter_params_changed()
+            mark()
             return pred.detach()
     else:
         def step():
@@ -324,6 +332,21 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0                     # bracketed by barrier + synchronize on both sides
     assert torch.isfinite(out).all()
+    train_phases = None
+    if a.train:                                            # untimed extra steps: where a training step's time goes (HIP events on the stream)
+        acc_ms = [0.0, 0.0, 0.0, 0.0]
+        nrep = 3
+        with torch.enable_grad():
+            for _ in range(nrep):
+                phase_ev = []
+                step()
+                torch.cuda.synchronize(dev)
+                for k in range(4):
+                    acc_ms[k] += phase_ev[k].elapsed_time(phase_ev[k + 1])
+        phase_ev = None
+        train_phases = {"forward_loss_ms": round(acc_ms[0] / nrep, 3), "backward_ms": round(acc_ms[1] / nrep, 3),
+                        "allreduce_ms": round(acc_ms[2] / nrep, 3), "optimizer_ms": round(acc_ms[3] / nrep, 3),
+                        "note": "HIP events on the step's stream over 3 untimed extra steps; optimizer = fused AdamW + the lifter repack"}
 
     # ---- consecutive batches in flight on separate HIP streams (a serving loop's option, NOT the contract's step: two batches
     # of B frames are resident at once, so this never becomes `value`).  The lifter's 17-token kernels, the low-resolution
@@ -485,6 +508,8 @@ def main():
             result["distributed"] = dist_info
         if overlapped is not None:
             result["overlapped_steps"] = overlapped
+        if train_phases is not None:
+            result["train_phases"] = train_phases
         if world == 1 and not a.no_cpu_baseline:
             if not a.train:
                 result["vs_fp32_oracle"] = vs_fp32_oracle(a.backbone, sd_cpu, img, k2d, kc0, out)

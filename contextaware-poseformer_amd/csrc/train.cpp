@@ -70,7 +70,7 @@ void Engine::train_layout(int B, TrainLayout& L) const {
     L.tA = take(maxNR, (size_t)3 * D * 32);
     L.tB = take(maxNR, (size_t)3 * D * 32);
     L.wT = take(0, (size_t)3 * D * D + 64 * 2 * D);            // largest transposed weight [K][Npad]
-    L.slabs = take(0, (size_t)16 * 3 * D * D);                 // split-K slabs of the largest weight gradient
+    L.slabs = take(0, (size_t)16 * (3 * D * D + 3 * D));       // split-K slabs of the largest weight gradient (+ its bias gradient)
     L.red = take(0, (size_t)64 * 3 * D);
     L.total = cur;
 }
@@ -102,6 +102,22 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
                          float* gW, float* gb) {
     float* red = tw + L.red;
     const size_t red_elems = (size_t)64 * 3 * cfg.embed_dim_ratio * (cfg.levels + 1);
+    // dW (and db, when it sits right behind dW in the flat gradient -- every nn.Linear's weight / bias pair does) straight from the
+    // row-major dY and X: no transposes, no column-reduction launches (wgrad_tn_kernel; 64-multiples and plain row pitches only)
+    if (gW && N % 64 == 0 && K % 64 == 0 && dymap.G == 1 && xmap.G == 1 && (double)rows * (double)std::max(dymap.S1, xmap.S1) * 4.0 < 2.0e9) {
+        const bool bias_here = gb && gb == gW + (long)N * K;
+        if (gb && !bias_here) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
+        const int tiles = (N / 64) * (K / 64), chunks = (rows + 31) / 32;
+        int splits = std::min(16, std::max(1, 512 / std::max(1, tiles)));
+        splits = std::min(splits, chunks);
+        const int cps = (chunks + splits - 1) / splits, slices = (chunks + cps - 1) / cps;
+        const long slab = (long)N * K + (bias_here ? N : 0);
+        HIP_TRY(launch_wgrad_tn(dY + dymap.off, dymap.S1, Xin + xmap.off, xmap.S1, rows, N, K, slices > 1 ? tw + L.slabs : gW, slab, splits,
+                                bias_here ? 1 : 0, s));
+        if (slices > 1) HIP_TRY(launch_slab_sum(tw + L.slabs, slices, slab, gW, s));
+        gW = nullptr;
+        gb = nullptr;
+    }
     if (gb) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
     if (gW) {
         const int Mp = r32(rows);

@@ -371,6 +371,110 @@ hipError_t launch_transpose_pad(const float* in, RowMap imap, int M, int C, floa
     return hipGetLastError();
 }
 
+// ---- weight gradient of an nn.Linear WITHOUT transposes:  dW[n][k] = sum_m dY[m][n] X[m][k],  db[n] = sum_m dY[m][n] ---------------
+// Both operands are contiguous along their OUTPUT index, not along the contraction index m, which is why t_linear_bwd used to transpose
+// them (two transpose_pad launches + two column-reduction launches per linear: 153 + 156 tiny launches per step).  Here
+// 32-row tiles [32 m][64 n] of dY and [32 m][64 k] of X go to LDS as they lie in memory (LDS-DMA, 256 contiguous bytes per row) and the
+// MFMA fragments are read across them: lane (i, h) of v_mfma_f32_32x32x2_f32 needs element (m + h, i) = one ds_read2st64_b32 for two
+// k-steps (row stride = 64 dwords), 32 consecutive lanes = 32 consecutive dwords: conflict-free.  64 x 64 output tile per block (four
+// waves, 32 x 32 each), three-stage ring, split over m in grid.y (each slice writes a raw slab, summed by slab_sum like before); the blocks
+// of the first k tile also sum their dY tile's columns: the bias gradient, as N more floats behind the slice's N * K slab.
+// Requires N % 64 == 0, K % 64 == 0, plain row pitches (the ctx blocks' strided token maps and the 32 / 48-wide linears keep the old path).
+struct WgradArgs {
+    const float* dY; long ldy;      // [M][ldy], columns 0 .. N - 1
+    const float* X; long ldx;       // [M][ldx], columns 0 .. K - 1
+    float* out;                     // slice s writes N * K (+ N) floats at out + s * slab
+    long slab;
+    int M, N, K, cps, want_bias;    // cps = 32-row chunks per slice
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int S = 3, TILE = 32 * 64;                   // floats per operand tile
+    __shared__ __attribute__((aligned(16))) float lds[S * 2 * TILE + 4 * 64];
+    typedef __attribute__((address_space(3))) void* lptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tk = a.K >> 6;
+    const int tile_n = blockIdx.x / tk, tile_k = blockIdx.x - tile_n * tk;
+    const int n0 = tile_n * 64, k0 = tile_k * 64;
+    const int c_begin = blockIdx.y * a.cps;
+    const int chunks_total = (a.M + 31) >> 5;
+    const int c_end = min(chunks_total, c_begin + a.cps);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + n0), 0, 0x7FFFFF00u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + k0), 0, 0x7FFFFF00u, 0x00020000);
+    // DMA: instruction i (0..7) of a tile covers rows 4 i .. 4 i + 3 (16 lanes x 16 B per row); a wave issues i = wave and wave + 4
+    const int drow = lane >> 4, dq = lane & 15;
+    auto fire = [&](int c, int stage) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = wave + 4 * h;
+            const long m = (long)c * 32 + 4 * i + drow;
+            const bool ok = c < c_end && m < a.M;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lptr)(lds + (stage * 2) * TILE + i * 256), 16, ok ? (unsigned)((m * a.ldy + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr)(lds + (stage * 2 + 1) * TILE + i * 256), 16, ok ? (unsigned)((m * a.ldx + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
+        }
+    };
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    const int fi = lane & 31, fh = lane >> 5;
+    float bsum = 0.f;                                      // (tile_k == 0) this thread's column n0 + (tid & 63), rows (tid >> 6) * 8 .. + 7 of every chunk
+    fire(c_begin, 0);
+    fire(c_begin + 1, 1);
+    int st = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this chunk's four instructions of mine have landed (the next chunk's four may fly)
+        __builtin_amdgcn_s_barrier();
+        fire(c + 2, st == 0 ? 2 : st - 1);                 // (into the stage everybody finished reading before this barrier)
+        const float* ys = lds + (st * 2) * TILE;
+        const float* xs = ys + TILE;
+#pragma unroll
+        for (int mm = 0; mm < 32; mm += 4) {               // lane half fh takes rows mm + fh and mm + 2 + fh: two MFMA k-steps per read pair
+            const float a0 = ys[(mm + fh) * 64 + wn + fi], a1 = ys[(mm + 2 + fh) * 64 + wn + fi];
+            const float b0 = xs[(mm + fh) * 64 + wk + fi], b1 = xs[(mm + 2 + fh) * 64 + wk + fi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+        }
+        if (a.want_bias && tile_k == 0) {
+            const int col = tid & 63, r0 = (tid >> 6) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bsum += ys[(r0 + r) * 64 + col];
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // D[i][j]: lane holds column j = k0 + wk + fi, register 4 g + e = row n0 + wn + 8 g + 4 fh + e
+    float* o = a.out + (long)blockIdx.y * a.slab;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(long)(n0 + wn + 8 * g + 4 * fh + e) * a.K + k0 + wk + fi] = acc[4 * g + e];
+    if (a.want_bias && tile_k == 0) {
+        float* red = lds + S * 2 * TILE;
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) o[(long)a.N * a.K + n0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    }
+#endif
+}
+
+// slabs: at least splits * (N * K + N) floats; *splits_out slices were written (1: straight into out = dW, bias at out + N * K)
+hipError_t launch_wgrad_tn(const float* dY, long ldy, const float* X, long ldx, int M, int N, int K, float* out, long slab, int splits,
+                           int want_bias, hipStream_t s) {
+    if (N % 64 || K % 64 || M <= 0 || splits < 1 || (double)M * (double)ldy * 4.0 >= 2.0e9 || (double)M * (double)ldx * 4.0 >= 2.0e9)
+        return hipErrorInvalidValue;
+    WgradArgs a{dY, ldy, X, ldx, out, slab, M, N, K, 0, want_bias};
+    const int chunks = (M + 31) / 32;
+    a.cps = (chunks + splits - 1) / splits;
+    const int slices = (chunks + a.cps - 1) / a.cps;
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((N / 64) * (K / 64), slices), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ---- backward of the tiny attention (Attention.forward pose_dformer.py:46-59) -----------------------
 // One block (256 threads for 17 tokens, one wave for 5) per (group, head): q, k, v and dO of the N <= 17 tokens are staged in LDS (coalesced reads of the
 // d contiguous floats of each token), the N x N probabilities are recomputed from the saved qkv exactly as
