@@ -47,6 +47,9 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s, pk.Kpad == 18 * pk.Cin ? 43 : 23));
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                      params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w2_off, B, pk.N, pk.Cin, pk.ks, pk.Kpad2, s));
+            if (pk.x3)
+                HIP_TRY(launch_pack_conv_f32x3(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
+                                               params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w3_off, B, pk.N, pk.Cin, s));
         } else if (pk.kind == 0) {
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
                                      params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks,
@@ -100,7 +103,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.M = (int)(op.rows_per_frame * batch);
     a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
     if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
-    if (pk.ws) a.Wp3 = pack_arena + pk.w3_off;
+    if (pk.ws || pk.x3) a.Wp3 = pack_arena + pk.w3_off;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
@@ -429,7 +432,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~127) {
+    if (cfg->plan_flags & ~255) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -858,6 +861,39 @@ int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* d) {
         if (!capf::gemm_bf16_ws_ok(g[i])) return CAPF_ERR_UNSUPPORTED;
     }
     return capf::launch_gemm_bf16_ws_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int64_t capf_op_conv_f32x3_pack_elems(int Cout, int Cin) { return Cin % 16 == 0 && Cout > 0 ? capf::f32x3_pack_elems(Cout, Cin) : 0; }
+
+int capf_op_pack_conv_f32x3(void* stream, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                            float eps, void* wp, float* bias, int Cout, int Cin) {
+    if (!w || !wp || Cin % 16 != 0 || Cout % 4 != 0) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_pack_conv_f32x3(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_f32x3_group(void* stream, int n, const capf_conv_desc* d) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i) {
+        if (d[i].ks != 3 || d[i].stride != 1) return CAPF_ERR_UNSUPPORTED;
+        g[i] = capf::GemmArgs{};
+        g[i].A = static_cast<const float*>(d[i].x);
+        g[i].Wp3 = static_cast<const float*>(d[i].w_packed);
+        g[i].bias = d[i].bias;
+        g[i].res = static_cast<const float*>(d[i].residual);
+        g[i].out = static_cast<float*>(d[i].y);
+        g[i].M = d[i].B * d[i].H * d[i].W;
+        g[i].N = d[i].Cout; g[i].K = 9 * d[i].Cin;
+        g[i].conv = 1;
+        g[i].Cin = d[i].Cin; g[i].H = d[i].H; g[i].W = d[i].W; g[i].Ho = d[i].H; g[i].Wo = d[i].W;
+        g[i].ks = 3; g[i].stride = 1; g[i].pad = 1;
+        g[i].omap = capf::row_ld(d[i].Cout);
+        g[i].rmap = capf::row_ld(d[i].Cout);
+        g[i].act = d[i].act;
+        if (!capf::gemm_f32x3_ok(g[i])) return CAPF_ERR_UNSUPPORTED;
+    }
+    return capf::launch_gemm_f32x3_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
 int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* d, const void* const* w_rh, int32_t* variant) {

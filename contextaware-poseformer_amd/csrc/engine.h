@@ -56,6 +56,7 @@ struct Pack {
     bool bf16 = false;             // conv weights packed as bf16 (Kpad % 64 == 0)
     bool rh = false;               // bf16 3x3 stride-1 conv: a second copy in the row-halo layout ([N][9 * Cin] bf16) at w2_off
     bool ws = false;               // bf16 3x3 stride-1 conv: a copy in the 2-D halo tile's layout (igemm_bf16_ws.hip) at w3_off
+    bool x3 = false;               // fp32 3x3 stride-1 conv: a copy as three bf16 pieces (igemm_f32x3_ws.hip) at w3_off
     size_t w3_off = 0;
     bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
 };
@@ -182,6 +183,7 @@ struct Engine {
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)
     std::vector<int> last_variants;   // capf_forward_profile_launches: grouped-bf16 kernel variant per leader op
     bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
+    bool use_x3 = true;            // plan: split-fp32 tile for the Winograd-eligible fp32 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_F32X3 clears it)
     bool use_ws = true;            // plan: 2-D halo layout + kernel for the bf16 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_WS clears it)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)
     bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)

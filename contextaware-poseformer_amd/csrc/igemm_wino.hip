@@ -1470,6 +1470,7 @@ static hipError_t launch_wino43_group(const GemmArgs* prep, const int* cfgs, int
 }
 
 hipError_t launch_gemm_wino(const GemmArgs& a_in, hipStream_t s) {
+    if (gemm_f32x3_wanted(a_in)) return launch_gemm_f32x3(a_in, s);       // (large launches: the split-fp32 tile, igemm_f32x3_ws.hip)
     GemmArgs a = a_in;
     if (!wino_prepare(a)) return hipErrorInvalidValue;
     hipError_t r = wino_attr();
@@ -1484,6 +1485,7 @@ hipError_t launch_gemm_wino(const GemmArgs& a_in, hipStream_t s) {
 
 // what rocprofv3 will call the launch: F(4,3) problems (alone or grouped) run igemm_wino43_group_kernel
 const char* gemm_wino_kernel_name(const GemmArgs& a) {
+    if (gemm_f32x3_wanted(a)) return gemm_f32x3_kernel_name(a);
     return (a.Kpad == 18 * a.Cin && wino43_short()) ? "igemm_wino43_group" : "igemm_wino<w4,F(2,3)>";
 }
 
@@ -1491,6 +1493,19 @@ hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (n == 1) return launch_gemm_wino(list[0], s);
     if (n > MAXG) return hipErrorInvalidValue;
+    {   // the problems the split-fp32 tile wants (a per-problem rule: igemm_f32x3_ws.hip) leave in one launch of their own
+        GemmArgs x3[MAXG], rest[MAXG];
+        int nx = 0, nrest = 0;
+        for (int i = 0; i < n; ++i) {
+            if (gemm_f32x3_wanted(list[i])) x3[nx++] = list[i];
+            else rest[nrest++] = list[i];
+        }
+        if (nx) {
+            const hipError_t rx = launch_gemm_f32x3_group(x3, nx, s);
+            if (rx != hipSuccess || nrest == 0) return rx;
+            return launch_gemm_wino_group(rest, nrest, s);
+        }
+    }
     hipError_t r = wino_attr();
     if (r != hipSuccess) return r;
     struct Item { int idx, cfg, tiles; double cost; };

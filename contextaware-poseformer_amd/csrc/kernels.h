@@ -85,7 +85,9 @@ struct GemmArgs {
     const float* Wp2;   // bf16 3x3 stride-1 convs: the same weights in the row-halo layout ([N][9 * Cin], igemm_bf16.hip), or
                         // nullptr; launch_gemm_bf16 / _group switch to that kernel for launches of >= 2048 tiles
     const float* Wp3;   // bf16 3x3 stride-1 convs: the same weights in the 2-D halo tile's layout (igemm_bf16_ws.hip), or nullptr;
-                        // launch_gemm_bf16 / _group run the problems gemm_bf16_ws_wanted() accepts on that kernel
+                        // launch_gemm_bf16 / _group run the problems gemm_bf16_ws_wanted() accepts on that kernel.
+                        // fp32 3x3 stride-1 convs: the weights as three bf16 pieces (igemm_f32x3_ws.hip), or nullptr;
+                        // launch_gemm_wino / _group run the problems gemm_f32x3_wanted() accepts on that kernel
     const float* bias;  // [N] or nullptr
     const float* res;   // residual, addressed by rmap, or nullptr
     float* out;         // addressed by omap
@@ -180,6 +182,19 @@ hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s)
 const char* gemm_bf16_ws_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_bf16_ws(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                                     float eps, void* Wp_bf16, float* bias, int Cout, int Cin, hipStream_t s);
+
+// fp32 3x3 / stride-1 conv on the bf16 matrix pipe (igemm_f32x3_ws.hip, igemm_f32x3_ws_tile.h): fp32 tensors in and out, every operand split
+// losslessly into three bf16 pieces, the six piece products of weight >= 2^-18 accumulated in fp32 -- results to fp32 accumulation
+// order.  Any width up to 256, Cin % 16 == 0, Cout % 4 == 0; weights packed by launch_pack_conv_f32x3 (f32x3_pack_elems(Cout, Cin)
+// bf16 elements), passed as GemmArgs::Wp3
+bool gemm_f32x3_ok(const GemmArgs& a);
+bool gemm_f32x3_wanted(const GemmArgs& a);             // eligible, carries Wp3, and large enough for this tile (a function of the conv alone)
+long f32x3_pack_elems(int Cout, int Cin);
+hipError_t launch_gemm_f32x3(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s);
+const char* gemm_f32x3_kernel_name(const GemmArgs& a);
+hipError_t launch_pack_conv_f32x3(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                  void* Wp_bf16, float* bias, int Cout, int Cin, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);

@@ -131,6 +131,9 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     if (use_bf16 && use_rh && ks == 3 && stride == 1 && bf16_rh_width(x.C) && Cout % 4 == 0) { pk.rh = true; pk.Kpad2 = 9 * x.C; }
     // ... and in the layout of the 2-D halo tile (igemm_bf16_ws.hip), which takes them from 512 tiles per launch
     if (use_bf16 && use_ws && ks == 3 && stride == 1 && x.C % 16 == 0 && Cout % 8 == 0) pk.ws = true;
+    // fp32: the Winograd-eligible convs also keep their weights as three bf16 pieces for the split-fp32 tile (igemm_f32x3_ws.hip), which
+    // takes them from 2 GFLOP per conv up (gemm_f32x3_wanted)
+    if (use_wino && use_x3 && x.W <= 256) pk.x3 = true;
     packs.push_back(pk);
 
     Op op;
@@ -902,6 +905,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;
     // tuning knobs of the diagnostic build only (diag_env is a constant nullptr in the product library)
     if (const char* fz = diag_env("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;
     if (const char* wz = diag_env("CAPF_WINO")) use_wino = atoi(wz) != 0;
@@ -982,6 +986,10 @@ bool Engine::build() {
         if (pk.ws) {
             pk.w3_off = off;
             off += round64(((size_t)bf16_ws_pack_elems(pk.N, pk.Cin) + 1) / 2);
+        }
+        if (pk.x3) {
+            pk.w3_off = off;
+            off += round64(((size_t)f32x3_pack_elems(pk.N, pk.Cin) + 1) / 2);
         }
         pk.b_off = off;
         off += round64((size_t)pk.N);

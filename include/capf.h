@@ -84,8 +84,10 @@ enum capf_plan_flag {
     CAPF_PLAN_WINOGRAD_F23_ONLY = 8, /* F(2,3) where F(4,3) would be chosen */
     CAPF_PLAN_NO_PWCHAIN = 16,      /* layer1's conv3 -> next conv1 pairs as two pointwise launches instead of one chained kernel */
     CAPF_PLAN_NO_WS = 32,           /* bf16 3x3 stride-1 convs without the 2-D halo tile (row-halo / direct kernels as in round 3) */
-    CAPF_PLAN_LIFTER_FP32 = 64      /* compute_dtype = CAPF_BF16: keep the lifter's qkv / proj / fc1 / fc2 on the fp32 kernels (bf16 backbone only);
+    CAPF_PLAN_LIFTER_FP32 = 64,     /* compute_dtype = CAPF_BF16: keep the lifter's qkv / proj / fc1 / fc2 on the fp32 kernels (bf16 backbone only);
                                      * the accuracy / speed trade bench.py reports as `vs_fp32_oracle`                                    */
+    CAPF_PLAN_NO_F32X3 = 128        /* fp32 3x3 stride-1 convs without the split-fp32 tile (three bf16 pieces per operand on the bf16
+                                     * matrix pipe, igemm_f32x3_ws.hip): the Winograd kernels at every batch, as in round 3            */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -286,6 +288,18 @@ int64_t capf_op_conv_bf16_ws_pack_elems(int Cout, int Cin);
 int capf_op_pack_conv_bf16_ws(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
                               const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);
 int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* convs);
+
+/* Split-fp32 tile of the 3x3 / stride-1 / pad-1 fp32 conv (csrc/igemm_f32x3_ws.hip; what capf_forward runs for the BasicBlock convs of
+ * an fp32 model, pose_hrnet.py:66-95, from 2 GFLOP per conv): fp32 tensors in and out; every operand is split, exactly, into three
+ * bf16 numbers and the six piece products of weight >= 2^-18 run on the bf16 matrix pipe with fp32 accumulation -- the dropped
+ * products are below the rounding of one fp32 multiply, so results agree with the direct fp32 kernel to accumulation order.
+ * Cin % 16 == 0, Cout % 4 == 0, W <= 256.  w_packed holds capf_op_conv_f32x3_pack_elems(Cout, Cin) bf16 elements written by
+ * capf_op_pack_conv_f32x3 (BatchNorm folded as in capf_op_pack_conv, then split; bias fp32 [Cout], may be NULL).
+ * capf_op_conv_f32x3_group: up to 8 such convs in ONE grid (capf_conv_desc with w_packed in this layout, ks = 3, stride = 1).       */
+int64_t capf_op_conv_f32x3_pack_elems(int Cout, int Cin);
+int capf_op_pack_conv_f32x3(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);
+int capf_op_conv_f32x3_group(void* stream, int n, const capf_conv_desc* convs);
 
 /* Up to 8 independent bf16 convs in one grid (what capf_forward issues per dependency level of the HRNet branches of a bf16 model):
  * capf_conv_desc with bf16 x / w_packed / residual / y.  w_row_halo[i] (optional array, entries may be NULL): the same weights
