@@ -431,7 +431,7 @@ def main():
                         kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh", "igemm_bf16_group_ws")[max(0, variants[l])] if kern.startswith("igemm_bf16")
                                 else ("igemm_wino43_group" if kern.startswith("igemm_wino43") else
                                       "igemm_wino_group" if kern.startswith("igemm_wino") else
-                                      kern if kern.startswith("igemm_f32_pwchain") else "igemm_f32_group"))
+                                      kern if kern.startswith(("igemm_f32_pwchain", "igemm_f32x3")) else "igemm_f32_group"))
                         if table[l][1].startswith("igemm_bf16_pwchain"):
                             kern = table[l][1]
                     if not kern or table[l][0].startswith("copy."):
@@ -450,6 +450,12 @@ def main():
         gemm_by = sum(e[3] for k, e in acc.items() if k.startswith("igemm"))
         gemm_ex = sum(e[4] for k, e in acc.items() if k.startswith("igemm"))
         peak = PEAK_TFLOPS[a.dtype]
+        # The split-fp32 tile (igemm_f32x3_ws.hip) computes fp32 results on the bf16 pipe with six piece products per fp32 product: its
+        # roof in ALGORITHMIC fp32 FLOP/s is the bf16 peak / 6, so that frac = executed bf16 FLOP/s / bf16 peak = the pipe's busy fraction
+        x3 = dname.startswith("igemm_f32x3")
+        dpeak = round(PEAK_TFLOPS["bf16"] / 6.0, 1) if x3 else peak
+        pipe_peak = lambda k: PEAK_TFLOPS["bf16"] if k.startswith(("igemm_f32x3", "igemm_bf16")) else peak     # executed FLOPs are priced on the pipe they ran on
+        gemm_busy = sum(e[4] / pipe_peak(k) for k, e in acc.items() if k.startswith("igemm")) / 1e12
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
         # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
         traffic, tsrc = None, None
@@ -462,7 +468,10 @@ def main():
                 data = data.get(key, {}) if key else (data if tag == 1 else {})
                 traffic = data.get(dname, {}).get("hbm_bytes_per_launch")
                 tsrc = os.path.relpath(tfile, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None
-        mfma = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)}
+        mfma = {"bound": "mfma", "achieved": round(tflops, 2), "peak": dpeak, "unit": "TFLOP/s", "frac": round(tflops / dpeak, 4)}
+        if x3:
+            mfma["peak_note"] = ("fp32 results on the bf16 matrix pipe: each fp32 operand = three bf16 pieces (exact), six piece products per fp32 product; "
+                                 "peak = 2500 TFLOP/s dense bf16 / 6")
         hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         first, second = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
         roofline = dict(first)
@@ -475,14 +484,14 @@ def main():
             "flops_convention": "algorithmic = 2*M*N*K of the direct convolution (SURVEY 8d); executed = MFMA MACs actually issued",
             "executed_flops_per_launch": round(dexec / dn, 1),
             "executed_tflops": round(dexec / (dms * 1e-3) / 1e12, 2) if dms > 0 else 0.0,
-            "mfma_busy_frac": round(dexec / (dms * 1e-3) / 1e12 / peak, 4) if dms > 0 else 0.0,
+            "mfma_busy_frac": round(dexec / (dms * 1e-3) / 1e12 / pipe_peak(dname), 4) if dms > 0 else 0.0,
             "algorithmic_flops_per_launch": round(dflops / dn, 1), "algorithmic_bytes_per_launch": round(dbytes / dn, 1),
             "launches_per_step": dn // nprof, "avg_launch_us": round(dms / dn * 1e3, 2),
             "share_of_forward": round(dms / total_ms, 4),
             "measured_hbm_gbs": round(traffic / (dms / dn * 1e-3) / 1e9, 1) if traffic else None,
             "all_mfma_kernels": {"tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
                                  "mfma_frac": round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, 4),
-                                 "mfma_busy_frac": round(gemm_ex / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                                 "mfma_busy_frac": round(gemm_busy / (gemm_ms * 1e-3), 4),
                                  "algorithmic_gbs": round(gemm_by / (gemm_ms * 1e-3) / 1e9, 1),
                                  "share_of_forward": round(gemm_ms / total_ms, 4)},
             "forward_ms_by_events": round(total_ms / nprof, 3)})

@@ -1000,7 +1000,8 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
 
 // FLOPs the MFMA pipe is asked to execute for one op at `batch` (2 x MACs issued, K padding included, tile-edge padding
 // not): the Winograd kernels issue 18 (F(4,3), per four outputs) or 12 (F(2,3), per two) MACs per (cin, cout) where the
-// direct conv issues 36 / 18, i.e. 1/2 or 2/3 of the algorithmic count capf_op_info reports.
+// direct conv issues 36 / 18, i.e. 1/2 or 2/3 of the algorithmic count capf_op_info reports; the split-fp32 tile (igemm_f32x3_ws.hip)
+// issues six bf16 MACs per fp32 MAC -- on the bf16 pipe, whose peak is 16 x the fp32 pipe's.
 int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* flops) {
     if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0 || !flops) return CAPF_ERR_INVALID;
     const capf::Engine& e = h->e;
@@ -1009,7 +1010,9 @@ int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* f
     if (op.kind != capf::OP_GEMM) return CAPF_OK;
     const capf::Pack& pk = e.packs[op.pack];
     const double MN = 2.0 * (double)op.rows_per_frame * batch * op.N;
-    if (op.conv && e.wino_now(op, batch)) *flops = MN * op.Cin * (pk.Kpad == 18 * pk.Cin ? 4.5 : 6.0);
+    if (op.conv && e.wino_now(op, batch) && pk.x3 && capf::gemm_f32x3_wanted(e.gemm_args(op, batch)))
+        *flops = 6.0 * MN * op.K;                                  // split-fp32 tile: six bf16 piece products per fp32 product, on the bf16 pipe
+    else if (op.conv && e.wino_now(op, batch)) *flops = MN * op.Cin * (pk.Kpad == 18 * pk.Cin ? 4.5 : 6.0);
     else if (op.wino) *flops = MN * pk.Kpad2;                      // small batch: the direct kernel on the direct layout
     else if (pk.rh && op.conv) *flops = MN * op.K;                 // row-halo layout has no K padding (decided per launch; lower bound)
     else *flops = MN * (pk.direct ? op.K : pk.Kpad);

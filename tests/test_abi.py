@@ -149,9 +149,11 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     table = {name: kern for name, kern, _ in eng.op_table(64)}
     assert table["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
     assert table["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
-    # the 3x3 stride-1 convs run the Winograd kernel from batch 8 up and the direct kernel (tall 256x32 tile for the
-    # 32-channel 64x64 branch launched on its own) below
-    assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"      # F(4,3): row length 64 is a multiple of 4
+    # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below
+    # batch 8, the Winograd kernel from there, and the split-fp32 tile from 2 GFLOP per conv (batch 27 for these branches)
+    assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
+    mid = {name: kern for name, kern, _ in eng.op_table(16)}
+    assert mid["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"        # F(4,3): row length 64 is a multiple of 4
     small = {name: kern for name, kern, _ in eng.op_table(4)}
     assert small["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
     # layer1's HBM-bound 1x1 bottleneck convs: the pointwise kernel from 2048 tiles per launch, the general tile below
@@ -237,7 +239,7 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
     """capf_config::plan_flags is the ONLY way to take a kernel family out of the plan: the A/B environment switches of
     earlier rounds are compiled out of the product library (kernels.h diag_env), unknown flag bits are rejected."""
     from capf import Engine
-    from capf.lib import PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
+    from capf.lib import PLAN_NO_F32X3, PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
     from mvn.models import _native
 
     def kernels(flags, embed=128):
@@ -247,13 +249,15 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
         return [(n, k) for n, k, _ in eng.op_table(64)]
 
     base = kernels(0)
-    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_wino") for _, k in base)
-    for var in ("CAPF_LIFTER_FUSED", "CAPF_WINO", "CAPF_BF16_RH", "CAPF_WINO_F43"):
+    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_f32x3") for _, k in base)
+    no_x3 = kernels(PLAN_NO_F32X3)                                          # the round-3 plan: Winograd kernels at every batch
+    assert any(k.startswith("igemm_wino") for _, k in no_x3) and not any(k.startswith("igemm_f32x3") for _, k in no_x3)
+    for var in ("CAPF_LIFTER_FUSED", "CAPF_WINO", "CAPF_BF16_RH", "CAPF_WINO_F43", "CAPF_F32X3_MIN_MFLOP"):
         monkeypatch.setenv(var, "0")
     assert kernels(0) == base                                               # the environment does not reach the product plan
     unfused = kernels(PLAN_NO_FUSED_LIFTER)
     assert not any(k in ("ctx_attn", "embed") for _, k in unfused) and any(k == "deform_sample" for _, k in unfused)
-    assert not any(k.startswith("igemm_wino") for _, k in kernels(PLAN_NO_WINOGRAD))
+    assert not any(k.startswith(("igemm_wino", "igemm_f32x3")) for _, k in kernels(PLAN_NO_WINOGRAD))
     with pytest.raises(CapfError):
         kernels(1 << 10)
     # embed_dim_ratio beyond the fused kernels' register / LDS budget: the plan falls back to one kernel per op
@@ -265,13 +269,19 @@ def test_executed_flops_of_winograd_ops_are_half_or_two_thirds_of_the_algorithmi
     from capf import Engine
     from mvn.models import _native
     eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
-    table, ex = eng.op_table(64), eng.op_executed_flops(64)
+    # batch 64: the branch convs run the split-fp32 tile -- six bf16 piece products per fp32 product, counted on the bf16 pipe
+    t64, e64 = eng.op_table(64), eng.op_executed_flops(64)
+    assert any(k.startswith("igemm_f32x3") for _, k, _ in t64)
+    assert all(abs(e / a - 6.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32x3"))
+    table, ex = eng.op_table(16), eng.op_executed_flops(16)
     seen = set()
     for (name, kern, alg), e in zip(table, ex):
         if kern.startswith("igemm_wino"):
             r = e / alg
             assert abs(r - 0.5) < 1e-9 or abs(r - 2.0 / 3.0) < 1e-9, (name, r)
             seen.add(round(r, 3))
+        elif kern.startswith("igemm_f32x3"):
+            assert abs(e / alg - 6.0) < 1e-9, (name, e / alg)
         elif kern.startswith("igemm") and alg > 0:
             assert 1.0 - 1e-9 <= e / alg <= 1.2, (name, kern, e / alg)       # K padded to the chunk width only
     assert 0.5 in seen

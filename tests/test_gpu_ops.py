@@ -339,14 +339,16 @@ def test_engine_modes_are_bit_identical(dtype, backbone):
 
 
 @pytest.mark.parametrize("dtype,backbone,B,H,W,flags", [("fp32", "hrnet_32", 24, 256, 192, 0), ("bf16", "hrnet_48", 24, 256, 192, 0),
-                                                         ("bf16", "cpn", 24, 256, 192, 0), ("fp32", "hrnet_32", 16, 64, 64, 2)])
+                                                         ("bf16", "cpn", 24, 256, 192, 0), ("fp32", "hrnet_32", 16, 64, 64, 2),
+                                                         ("fp32", "hrnet_32", 48, 256, 192, 0)])
 def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone, B, H, W, flags):
     """capf_set_lanes 3 (the default at batch 16..256: a region's lanes as two grouped chains on two streams, fork / join with
     events) against mode 2 (one chain on the caller's stream) at batch 24: same kernels on the same operands, only their
     grouping and their stream differ -> the same bits, call after call (a missing event dependency would show up as a
     run-to-run difference).  The 64 x 64 / batch 16 case runs with CAPF_PLAN_NO_WINOGRAD: its 16 x 16 ... 2 x 2 maps are a handful of
     tiles per conv, so the 3x3 convs of BOTH concurrent chains take the split-K path (a conv splits by its shape alone) and must not
-    share slabs and counters (each chain has its own)."""
+    share slabs and counters (each chain has its own).  Batch 48 fp32: the branch convs are past 2 GFLOP each and run on the
+    split-fp32 tile (igemm_f32x3_ws.hip) in both schedules."""
     import copy, contextlib, io
     from capf import synth
     from mvn.models.conpose import CA_PF
@@ -846,3 +848,130 @@ def test_ws_engine_path_agrees_with_the_row_halo_kernels():
         print(f"2-D halo vs row-halo: relative L2 {rel:.2e}")
         assert rel < 1.5e-2
 
+
+
+def _x3_fold(wp, co, ci):
+    """Undo capf_op_pack_conv_f32x3: packed [slice][Cin / 16][piece][tap][32][quad position][8] bf16 -> folded fp32 weights [co, ci, 3, 3]
+    (the three pieces of a weight add up to it exactly)."""
+    ns = 32
+    nsl = (co + ns - 1) // ns
+    t = wp.double().cpu().view(nsl, ci // 16, 3, 9, ns, 2, 8).sum(dim=2)
+    n = torch.arange(ns)
+    swap = ((n >> 3) & 1).bool()
+    t = torch.where(swap[None, None, None, :, None, None], t.flip(4), t)           # quad position -> channel half
+    w = t.permute(0, 3, 1, 4, 5, 2).reshape(nsl * ns, ci, 9)[:co]                  # [n, (cc, half, e), tap]
+    return w.reshape(co, ci, 3, 3).contiguous()
+
+
+def _x3_check(got_nhwc, x, w_fold, bias, res, act, what):
+    """fp32 result of the split-fp32 tile against an fp64 evaluation of the same fp32 operands: within 1e-6 of each output's sum of
+    |terms| (fp32 accumulation in another order: measured 2.6e-7 at worst; one dropped bf16 piece would be 4e-6 to 2e-3)."""
+    xd = x.double()
+    want = F.conv2d(xd, w_fold, bias.double().cpu(), 1, 1)
+    mass = F.conv2d(xd.abs(), w_fold.abs(), bias.double().abs().cpu(), 1, 1)
+    if res is not None:
+        want, mass = want + res.double(), mass + res.double().abs()
+    if act:
+        want = F.relu(want)
+    err = ((got_nhwc.double().cpu().permute(0, 3, 1, 2) - want).abs() / mass).max().item()
+    assert err <= 1e-6, f"{what}: {err:.3e} of the sum of |terms|"
+    return err
+
+
+def test_f32x3_fuzz_against_torch():
+    """Seeded random 3x3 / stride-1 fp32 problems through the split-fp32 tile (csrc/igemm_f32x3_ws.hip): Cin multiples of 16, Cout
+    multiples of 4 (ragged last channel slice), widths that are and are not multiples of 16 (closed-form and dealt-out pixel-to-column
+    assignment), part rows / whole images / several images per tile, ragged last tiles, with and without residual / ReLU -- against an
+    fp64 F.conv2d of the same fp32 operands with full-mantissa values.  The folded weights are read back from the packed pieces (which
+    checks the pack: the three pieces must add up to the fp32 fold) and compared with the CPU's own BatchNorm fold."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(20261001)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    worst = 0.0
+    for case in range(30):
+        ci = 16 * ri(1, 12)
+        co = 4 * ri(1, 48)
+        H, W, B = ri(1, 40), ri(1, 70), ri(1, 5)
+        if case == 5:
+            H, W, B = 8, 8, 9                     # several images per tile, ragged last tile, dealt-out columns
+        if case == 6:
+            H, W, B = 64, 64, 2                   # part rows of an image per tile
+        if case == 7:
+            H, W, B = 12, 9, 5                    # CPN's smallest map
+        if case == 8:
+            H, W, B, ci, co = 16, 16, 3, 128, 128
+        act, res = ri(0, 1), bool(ri(0, 1))
+        x = torch.randn(B, ci, H, W, generator=rng) * torch.rand(B, ci, H, W, generator=rng).pow(3)     # magnitudes over several binades
+        w = torch.randn(co, ci, 3, 3, generator=rng) / (ci * 9) ** 0.5
+        bnp = (torch.rand(co, generator=rng) + 0.5, torch.randn(co, generator=rng) * 0.1, torch.randn(co, generator=rng) * 0.1,
+               torch.rand(co, generator=rng) * 0.4 + 0.8)
+        wp, bias = capf.pack_conv_f32x3(w.cuda(), tuple(t.cuda() for t in bnp))
+        w_fold = _x3_fold(wp, co, ci)
+        sc = bnp[0].double() / torch.sqrt(bnp[3].double() + 1e-5)
+        assert torch.allclose(w_fold, w.double() * sc.view(-1, 1, 1, 1), rtol=1e-6, atol=1e-9)
+        assert torch.equal(w_fold.float().double(), w_fold)                    # an fp32 number: the pieces lose nothing
+        r = torch.randn(B, co, H, W, generator=rng) if res else None
+        got, = capf.conv_nhwc_f32x3_group([(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
+                                            r.permute(0, 2, 3, 1).contiguous().cuda() if res else None, co)])
+        worst = max(worst, _x3_check(got, x, w_fold, bias, r, act, f"case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}"))
+    print(f"split-fp32 tile, 30 random problems: worst |error| {worst:.2e} of the sum of |terms|")
+
+
+@pytest.mark.parametrize("chans,B", [((32, 64, 128, 256), 9), ((48, 96, 192, 384), 5), ((64, 128, 256, 512), 3)])
+def test_grouped_f32x3_launch_matches_torch_and_single_launches(chans, B):
+    """The four HRNet branch convs (3x3, stride 1, residual, ReLU) as ONE grouped launch of the split-fp32 tile -- problems of different
+    K and tile geometry in one grid, padded tile ids -- against fp64 F.conv2d, and bit-identical to the four single launches."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(sum(chans) + B)
+    probs, refs = [], []
+    for i, c in enumerate(chans):
+        r = 64 >> i
+        x = torch.randn(B, c, r, r, generator=g)
+        w = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+        bnp = (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+               torch.rand(c, generator=g) * 0.4 + 0.8)
+        res = torch.randn(B, c, r, r, generator=g)
+        wp, bias = capf.pack_conv_f32x3(w.cuda(), tuple(t.cuda() for t in bnp))
+        refs.append((x, _x3_fold(wp, c, c), bias, res))
+        probs.append((x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, 1, res.permute(0, 2, 3, 1).contiguous().cuda(), c))
+    outs = capf.conv_nhwc_f32x3_group(probs)
+    for y, (x, wf, bias, res), pr in zip(outs, refs, probs):
+        _x3_check(y, x, wf, bias, res, 1, f"{x.shape}")
+        single, = capf.conv_nhwc_f32x3_group([pr])
+        assert torch.equal(single, y)
+
+
+def test_f32x3_engine_path_agrees_with_the_winograd_kernels():
+    """Batch 32 HRNet-32 fp32: the product plan runs the branch levels on igemm_f32x3_group_ws_kernel, a plan with CAPF_PLAN_NO_F32X3 on
+    the Winograd kernels.  Same fp32 operands, two fp32-accurate evaluations: the context maps and the poses agree to fp32 roundoff
+    accumulated over the backbone (the F(4,3) side contributes most of it)."""
+    import copy, contextlib, io
+    from capf import synth
+    from capf.lib import PLAN_NO_F32X3
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    img, k2d, kc = synth.synth_inputs(32, 256, 256, seed=17)
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    maps, outs, kernels = [], [], []
+    for flags in (0, PLAN_NO_F32X3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = CA_PF(cfg, compute_dtype="fp32", plan_flags=flags).eval()
+        synth.load_synthetic(model, seed=4, bn_mode="random")
+        model = model.cuda()
+        with torch.no_grad():
+            outs.append(model(img, k2d, kc.clone()).clone())
+            eng = model.engine_for(img)
+        kernels.append(set(k for _, k, _ in eng.op_table(32) if k))
+        maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
+    assert any(k.startswith("igemm_f32x3") for k in kernels[0]) and not any(k.startswith("igemm_f32x3") for k in kernels[1])
+    assert any(k.startswith("igemm_wino") for k in kernels[1])
+    for a, b in zip(*maps):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"split-fp32 vs Winograd: relative L2 {rel:.2e}")
+        assert rel < 2e-5
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-4 * outs[1].abs().max().item()
