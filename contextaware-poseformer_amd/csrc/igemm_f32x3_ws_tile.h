@@ -53,7 +53,7 @@ inline bool x3_plan(int B, int H, int W, int C, int N, int NS, X3Problem* q) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef X3_DBG
-#define X3_DBG 0          // experiments (tools/f32x3_ws.hip): 1 = no MFMAs, 2 = no split, 4 = no weight DMA, 8 = no fragment reads
+#define X3_DBG 0          // experiments (tools/f32x3_ws.hip): 1 = no MFMAs, 2 = no split, 4 = no weight DMA, 8 = no fragment reads, 16 = residual after the K loop
 #endif
 
 // a pair of fp32 values -> the pair's three packed bf16 pieces
@@ -215,11 +215,37 @@ __device__ __forceinline__ void igemm_f32x3_ws_tile(const X3Problem& q, const in
     if (NCC > 1) load_a(1);
     __builtin_amdgcn_s_barrier();
 
+    // ---- epilogue addressing: lane = 4 consecutive channels (register group g) of its pixel; the residual rows are requested before the
+    // last chunk's MFMAs
+    const int gp0 = q0 * p.RHW;
+    const int Mi = (int)p.M;
+    const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(q.res ? (void*)q.res : (void*)q.y, 0, q.res ? 0x7FFFFF00u : 0u, 0x00020000);
+    const ws_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)q.y, 0, 0x7FFFFF00u, 0x00020000);
+    auto piece_off = [&](int i, int j, int g, int ld) -> unsigned {
+        const int pl = pl_i[i], n = slice * NS + j * 32 + 8 * g + 4 * fhalf;
+        const int gp = gp0 + pl;
+        return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(gp * ld + n) * 4u : OOB;
+    };
+    ws_f32x4 rr[2][TN][4];
+    auto prefetch_residual = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    rr[i][j][g] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, g, p.ldr), 0, 0));
+    };
     // (weight piece, pixel piece) of the six products, smallest first
     constexpr int PW_[6] = {0, 2, 1, 0, 1, 0};
     constexpr int PA_[6] = {2, 0, 1, 1, 0, 0};
+    // fragments of two taps in registers, a tap's reads issued one tap ahead, one behind every MFMA.  (Two taps ahead -- three register
+    // sets, 256 VGPRs -- changes nothing: 228 vs 232 us at batch 512, 128 ch 16^2.  The kernel runs against the board's power limit, not
+    // against an issue or LDS limit: tools/f32x3_ws.hip reads the shader clock inside the launch -- 1.60 GHz sustained at batch 512,
+    // 1.96 GHz in a 30 us launch at batch 64, nominal 2.4 -- so "0.40 of the nominal bf16 peak" is 0.60 of the pipe's actual cycles.)
     ws_bf16x8 af[2][3][2], bfr[2][3][TN];
     for (int cc = 0; cc < NCC; ++cc) {
+        if (cc == NCC - 1 && !(X3_DBG & 16)) prefetch_residual();
         auto read_frags = [&](int t, int buf) {            // (in the order the products below consume them)
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
@@ -266,24 +292,10 @@ __device__ __forceinline__ void igemm_f32x3_ws_tile(const X3Problem& q, const in
         }
     }
 
-    // ---- epilogue: lane = 4 consecutive channels (register group g) of pixel frow of a 32-pixel block
-    const int gp0 = q0 * p.RHW;
-    const int Mi = (int)p.M;
-    const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(q.res ? (void*)q.res : (void*)q.y, 0, q.res ? 0x7FFFFF00u : 0u, 0x00020000);
-    const ws_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)q.y, 0, 0x7FFFFF00u, 0x00020000);
-    auto piece_off = [&](int i, int j, int g, int ld) -> unsigned {
-        const int pl = pl_i[i], n = slice * NS + j * 32 + 8 * g + 4 * fhalf;
-        const int gp = gp0 + pl;
-        return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(gp * ld + n) * 4u : OOB;
-    };
+    // ---- epilogue
+    if (X3_DBG & 16) prefetch_residual();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        ws_f32x4 rr[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                rr[j][g] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, g, p.ldr), 0, 0));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -291,7 +303,7 @@ __device__ __forceinline__ void igemm_f32x3_ws_tile(const X3Problem& q, const in
                 ws_f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = acc[i][j][4 * g + e] + rr[j][g][e];
+                    const float t = acc[i][j][4 * g + e] + rr[i][j][g][e];
                     o[e] = p.relu ? fmaxf(t, 0.f) : t;
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), rs_out, piece_off(i, j, g, p.ldy), 0, 0);

@@ -41,14 +41,18 @@ __global__ void direct_ref(const float* x, const float* w, const float* bias, co
     y[i] = s; mass[i] = m;
 }
 
+__device__ unsigned long long g_clk[4];      // shader clock / 100 MHz wall clock at the start and end of block 0 (actual frequency under load)
+
 template <int TN>
 __global__ __launch_bounds__(256, TN == 1 ? 2 : 1) void x3_kernel(X3Problem p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (blockIdx.x == 8 && threadIdx.x == 0) { g_clk[0] = clock64(); g_clk[1] = wall_clock64(); }
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, x = b & 7;
     const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);      // XCD-contiguous tile order
     igemm_f32x3_ws_tile<TN>(p, bid, lds);
+    if (blockIdx.x == 8 && threadIdx.x == 0) { g_clk[2] = clock64(); g_clk[3] = wall_clock64(); }
 #endif
 }
 
@@ -131,6 +135,10 @@ static double run(int B, int H, int W, int C, int N, bool with_res, bool check, 
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         us = ms * 1e3 / reps;
+        unsigned long long hc[4];
+        hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc));
+        printf("   [block 8 of the last launch: %.0f shader cycles in %.2f us = %.0f MHz]\n", (double)(hc[2] - hc[0]), (hc[3] - hc[1]) / 100.0,
+               (double)(hc[2] - hc[0]) / ((hc[3] - hc[1]) / 100.0));
         const double gf = 2.0 * B * H * W * (double)N * 9 * C / 1e9, mb = ((double)nx + ny * (with_res ? 2 : 1)) * 4 / 1e6;
         printf("B=%d %dx%d %d->%d res=%d f32x3 ws NS %d: %8.1f us  %7.1f TFLOP/s (fp32-equivalent; %.2f of the bf16 pipe)  %6.2f TB/s (alg)  grid %d\n", B, H, W, C, N,
                (int)with_res, NS, us, gf / us * 1e3, 6 * gf / us * 1e3 / 2500.0, mb / us, grid);
