@@ -44,19 +44,20 @@ __global__ void direct_ref(const float* x, const float* w, const float* bias, co
 __device__ unsigned long long g_clk[4];      // shader clock / 100 MHz wall clock at the start and end of block 0 (actual frequency under load)
 
 template <int TN>
-__global__ __launch_bounds__(256, TN == 1 ? 2 : 1) void x3_kernel(X3Problem p) {
+__global__ __launch_bounds__(256, TN == 1 ? 2 : 1) void x3_kernel(X3Problem p, int nt, int tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     if (blockIdx.x == 8 && threadIdx.x == 0) { g_clk[0] = clock64(); g_clk[1] = wall_clock64(); }
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, x = b & 7;
     const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);      // XCD-contiguous tile order
-    igemm_f32x3_ws_tile<TN>(p, bid, lds);
+    const int b0 = bid * nt;
+    if (b0 < tiles) igemm_f32x3_ws_tiles<TN>(p, b0, min(nt, tiles - b0), lds);
     if (blockIdx.x == 8 && threadIdx.x == 0) { g_clk[2] = clock64(); g_clk[3] = wall_clock64(); }
 #endif
 }
 
-static int g_ns = 32;
+static int g_ns = 32, g_nt = 1;
 
 static double run(int B, int H, int W, int C, int N, bool with_res, bool check, int reps = 20) {
     const long nx = (long)B * H * W * C, ny = (long)B * H * W * N, nw = 9L * C * N;
@@ -98,12 +99,13 @@ static double run(int B, int H, int W, int C, int N, bool with_res, bool check, 
     hipMemset(dy, 0, ny * 4);
     p.x = dx; p.g.wp = dp; p.g.bias = db; p.res = with_res ? dres : nullptr; p.y = dy; p.g.relu = 1;
     const size_t lds_bytes = x3_lds_bytes(NS);
-    const int grid = p.g.tiles_m * NSL;
+    const int tiles = p.g.tiles_m * NSL, grid = (tiles + g_nt - 1) / g_nt;
     auto launch = [&]() {
-        if (TN == 2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); hipLaunchKernelGGL(x3_kernel<2>, dim3(grid), dim3(256), lds_bytes, 0, p); }
-        else { hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); hipLaunchKernelGGL(x3_kernel<1>, dim3(grid), dim3(256), lds_bytes, 0, p); }
+        if (TN == 2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); hipLaunchKernelGGL(x3_kernel<2>, dim3(grid), dim3(256), lds_bytes, 0, p, g_nt, tiles); }
+        else { hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); hipLaunchKernelGGL(x3_kernel<1>, dim3(grid), dim3(256), lds_bytes, 0, p, g_nt, tiles); }
     };
     launch();
+    { int nb = -1; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&x3_kernel<1>), 256, lds_bytes); static int once = 0; if (!once++) printf("   [occupancy: %d blocks of 256 threads per CU with %zu B of LDS]\n", nb, lds_bytes); }
     { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) { printf("  kernel error: %s\n", hipGetErrorString(e)); exit(1); } }
     if (check) {
         hipMalloc(&dr, ny * 8); hipMalloc(&dm, ny * 8);
@@ -140,8 +142,8 @@ static double run(int B, int H, int W, int C, int N, bool with_res, bool check, 
         printf("   [block 8 of the last launch: %.0f shader cycles in %.2f us = %.0f MHz]\n", (double)(hc[2] - hc[0]), (hc[3] - hc[1]) / 100.0,
                (double)(hc[2] - hc[0]) / ((hc[3] - hc[1]) / 100.0));
         const double gf = 2.0 * B * H * W * (double)N * 9 * C / 1e9, mb = ((double)nx + ny * (with_res ? 2 : 1)) * 4 / 1e6;
-        printf("B=%d %dx%d %d->%d res=%d f32x3 ws NS %d: %8.1f us  %7.1f TFLOP/s (fp32-equivalent; %.2f of the bf16 pipe)  %6.2f TB/s (alg)  grid %d\n", B, H, W, C, N,
-               (int)with_res, NS, us, gf / us * 1e3, 6 * gf / us * 1e3 / 2500.0, mb / us, grid);
+        printf("B=%d %dx%d %d->%d res=%d f32x3 ws NS %d nt %d: %8.1f us  %7.1f TFLOP/s (fp32-equivalent; %.2f of the bf16 pipe)  %6.2f TB/s (alg)  grid %d\n", B, H, W, C, N,
+               (int)with_res, NS, g_nt, us, gf / us * 1e3, 6 * gf / us * 1e3 / 2500.0, mb / us, grid);
     }
     hipFree(dx); hipFree(dw); hipFree(dp); hipFree(dy); hipFree(dres); hipFree(db);
     return us;
@@ -149,6 +151,7 @@ static double run(int B, int H, int W, int C, int N, bool with_res, bool check, 
 
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "check");
+    if (getenv("X3_NT")) g_nt = atoi(getenv("X3_NT"));
     if (argc > 7 && !strcmp(argv[1], "one")) {            // one B H W C N NS [reps]: a single shape (PMC passes)
         g_ns = atoi(argv[7]);
         run(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), true, false, argc > 8 ? atoi(argv[8]) : 5);
