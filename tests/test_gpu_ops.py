@@ -863,7 +863,7 @@ def _x3_fold(wp, co, ci):
     return w.reshape(co, ci, 3, 3).contiguous()
 
 
-def _x3_check(got_nhwc, x, w_fold, bias, res, act, what):
+def _x3_check(got_nhwc, x, w_fold, bias, res, act, what, direct=None):
     """fp32 result of the split-fp32 tile against an fp64 evaluation of the same fp32 operands: within 1e-6 of each output's sum of
     |terms| (fp32 accumulation in another order: measured 2.6e-7 at worst; one dropped bf16 piece would be 4e-6 to 2e-3)."""
     xd = x.double()
@@ -875,7 +875,16 @@ def _x3_check(got_nhwc, x, w_fold, bias, res, act, what):
         want = F.relu(want)
     err = ((got_nhwc.double().cpu().permute(0, 3, 1, 2) - want).abs() / mass).max().item()
     assert err <= 1e-6, f"{what}: {err:.3e} of the sum of |terms|"
+    # the yardstick: the SAME convolution on this library's direct fp32 MFMA kernel (v_mfma_f32_32x32x2_f32, fp32 operands, fp32 accumulate)
+    # against the same fp64 evaluation: the split-fp32 tile must be as close (both are fp32 accumulations of exact products, in different orders)
+    if direct is not None:
+        err32 = ((direct.double().cpu().permute(0, 3, 1, 2) - want).abs() / mass).max().item()
+        assert err <= 2.0 * err32 + 5e-8, f"{what}: {err:.3e} vs {err32:.3e} for the direct fp32 kernel"
+        _x3_check.pairs.append((err, err32))
     return err
+
+
+_x3_check.pairs = []
 
 
 def test_f32x3_fuzz_against_torch():
@@ -916,8 +925,11 @@ def test_f32x3_fuzz_against_torch():
         r = torch.randn(B, co, H, W, generator=rng) if res else None
         got, = capf.conv_nhwc_f32x3_group([(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, bias, act,
                                             r.permute(0, 2, 3, 1).contiguous().cuda() if res else None, co)])
-        worst = max(worst, _x3_check(got, x, w_fold, bias, r, act, f"case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}"))
-    print(f"split-fp32 tile, 30 random problems: worst |error| {worst:.2e} of the sum of |terms|")
+        wd, bd = capf.pack_conv(w.cuda(), tuple(t.cuda() for t in bnp))
+        direct = capf.conv_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), wd, bd, 3, 1, act, r.permute(0, 2, 3, 1).contiguous().cuda() if res else None)
+        worst = max(worst, _x3_check(got, x, w_fold, bias, r, act, f"case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}", direct))
+    e32 = max(b for _, b in _x3_check.pairs)
+    print(f"split-fp32 tile, 30 random problems: worst |error| {worst:.2e} of the sum of |terms| (the direct fp32 MFMA kernel on the same problems: {e32:.2e})")
 
 
 @pytest.mark.parametrize("chans,B", [((32, 64, 128, 256), 9), ((48, 96, 192, 384), 5), ((64, 128, 256, 512), 3)])
