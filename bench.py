@@ -456,6 +456,8 @@ def main():
         dpeak = round(PEAK_TFLOPS["bf16"] / 6.0, 1) if x3 else peak
         pipe_peak = lambda k: PEAK_TFLOPS["bf16"] if k.startswith(("igemm_f32x3", "igemm_bf16")) else peak     # executed FLOPs are priced on the pipe they ran on
         gemm_busy = sum(e[4] / pipe_peak(k) for k, e in acc.items() if k.startswith("igemm")) / 1e12
+        alg_peak = lambda k: PEAK_TFLOPS["bf16"] / 6.0 if k.startswith("igemm_f32x3") else peak                 # roof of a kernel in algorithmic FLOP/s
+        gemm_alg = sum(e[1] / alg_peak(k) for k, e in acc.items() if k.startswith("igemm")) / 1e12
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
         # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
         traffic, tsrc = None, None
@@ -490,7 +492,7 @@ def main():
             "share_of_forward": round(dms / total_ms, 4),
             "measured_hbm_gbs": round(traffic / (dms / dn * 1e-3) / 1e9, 1) if traffic else None,
             "all_mfma_kernels": {"tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
-                                 "mfma_frac": round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                                 "mfma_frac": round(gemm_alg / (gemm_ms * 1e-3), 4),      # each kernel's algorithmic FLOPs over its own roof
                                  "mfma_busy_frac": round(gemm_busy / (gemm_ms * 1e-3), 4),
                                  "algorithmic_gbs": round(gemm_by / (gemm_ms * 1e-3) / 1e9, 1),
                                  "share_of_forward": round(gemm_ms / total_ms, 4)},

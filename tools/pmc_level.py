@@ -79,7 +79,7 @@ def main():
     busy = n_mfma * (32 if (bf or x3) else 64)
     peak = 2500.0 if (bf or x3) else 157.3
     print(f"{a.kind} batch {B} branches {sel}: {us:8.1f} us per grouped launch (variant {variant});  algorithmic {alg / 1e9:.2f} GFLOP = "
-          f"{alg / us / 1e6:7.1f} TFLOP/s ({alg / us / 1e6 / peak:.3f} of peak),  executed {ex / 1e9:.2f} GFLOP = {ex / us / 1e6:7.1f} TFLOP/s "
+          f"{alg / us / 1e6:7.1f} TFLOP/s ({alg / us / 1e6 / (peak / 6.0 if x3 else peak):.3f} of peak),  executed {ex / 1e9:.2f} GFLOP = {ex / us / 1e6:7.1f} TFLOP/s "
           f"({ex / us / 1e6 / peak:.3f});  {n_mfma / 1e6:.3f} M MFMAs = {busy / 1e6:.1f} M SQ_VALU_MFMA_BUSY_CYCLES expected")
 
 
