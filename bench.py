@@ -26,6 +26,9 @@ Rank 0 prints ONE JSON line: whole-job frames/s plus
   vs_fp32_oracle — accuracy beside the speed (same leg as cpu_baseline, inference): max |joint coordinate difference| and mean
                  per-joint distance (metres) between the timed step's output and the fp32 CPU oracle on four of the run's own
                  frames; --lifter-fp32 (plan flag CAPF_PLAN_LIFTER_FP32) keeps the lifter's projections fp32 under --dtype bf16.
+fp32 configurations: the 3x3 stride-1 convs run on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 numbers
+(csrc/igemm_f32x3_ws.hip: results as close to fp64 as the direct fp32 MFMA kernel's); --no-f32x3 (CAPF_PLAN_NO_F32X3) times
+round 3's plan (Winograd on the fp32 pipe) for comparison.  `dtype` stays "f32": that is the arithmetic the path computes in.
 """
 import argparse
 import copy
@@ -78,6 +81,7 @@ def parse(argv=None):
     ap.add_argument("--embed", type=int, default=128, help="poseformer.embed_dim_ratio (128 = the reference default; 256 = the "
                     "labelled extra point for BASELINE's 'dim=256')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32x3", action="store_true", help="fp32 runs: 3x3 convs on the Winograd kernels at every batch (CAPF_PLAN_NO_F32X3: round 3's plan) instead of the split-fp32 tile")
     ap.add_argument("--lifter-fp32", action="store_true", help="bf16 runs: lifter projections on the fp32 kernels (CAPF_PLAN_LIFTER_FP32)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
@@ -267,8 +271,10 @@ def main():
     cfg.model.poseformer.embed_dim_ratio = a.embed
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        from capf.lib import PLAN_LIFTER_FP32
+        from capf.lib import PLAN_LIFTER_FP32, PLAN_NO_F32X3
         pflags = PLAN_LIFTER_FP32 if (a.lifter_fp32 and a.dtype == "bf16") else 0
+        if a.no_f32x3:
+            pflags |= PLAN_NO_F32X3
         model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
@@ -511,7 +517,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload_string(a, tag), "baseline_config": tag, "frames_per_step": B * world,
-                       "parallelism": par, "launches_per_forward": n_launches, "forward_gflop_per_frame": round(flops / B / 1e9, 3)},
+                       "parallelism": par, "launches_per_forward": n_launches, "forward_gflop_per_frame": round(flops / B / 1e9, 3),
+                       "plan_flags": pflags},
             "end_to_end_forward_tflops": round(fps * flops / B / 1e12, 2),
             "roofline": roofline,
         }
