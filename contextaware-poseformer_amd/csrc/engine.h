@@ -176,8 +176,14 @@ struct Engine {
     size_t ws_bytes = 0;
     bool packed = false;
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
-    int wino_min_batch = 8;        // below this batch the Winograd-eligible convs run the direct kernel (B = 1: 305 vs 286 frames/s)
-    bool wino_now(const Op& op, int batch) const { return op.wino && batch >= wino_min_batch; }
+    int wino_min_batch = 24;       // below this batch the Winograd-eligible convs the split-fp32 tile does not take run the direct kernel (with
+                                   // split-K; batch 16: 4.75 vs 5.86 ms per forward, batch 24: 6.08 vs 6.37)
+    // does the conv leave the direct kernel (for the split-fp32 tile or a Winograd kernel: launch_gemm_wino decides which) at this batch?
+    bool wino_now(const Op& op, int batch) const {
+        if (!op.wino) return false;
+        if (packs[op.pack].x3 && f32x3_takes(batch, op.H, op.W, op.Cin, op.N)) return true;
+        return batch >= wino_min_batch;
+    }
     bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)

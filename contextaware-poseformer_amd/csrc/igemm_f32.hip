@@ -461,14 +461,27 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
                             f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 }
         }
-        __threadfence();                              // release: the slab is visible device-wide before the count moves
-        __shared__ int s_last;
+        // Hand-off (cdna_hip_programming.md, in-launch split-K reduction): ONE agent-scope release per slice and ONE agent-scope acquire per
+        // tile, both by lane 0 behind a block barrier -- not a __threadfence() (L2 write-back + invalidate) in every thread of every
+        // slice, which cost ~15 us per launch.  Order matters: every wave drains its stores, barrier, release fence, drained again (the
+        // compiler may drop the wait behind the write-back), THEN the ticket.  The "I am last" flag lives in the ring (its last stage
+        // was read before the barrier): a second __shared__ object would make the compiler drain the DMA pipeline at every k-step.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(p.split_cnt + bid, 1) == p.splits - 1;
+        int* s_last = reinterpret_cast<int*>(lds);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(p.split_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.splits - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (drops this CU's L1: the other slices' slabs are read from L2)
+                p.split_cnt[bid] = 0;                 // self-resetting: the next launch finds zeros
+            }
+            *s_last = last;
+        }
         __syncthreads();
-        if (!s_last) return;
-        __threadfence();                              // acquire: see every other slice's slab
-        if (tid == 0) p.split_cnt[bid] = 0;           // self-resetting: the next launch finds zeros
+        if (!*s_last) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1058,7 +1071,7 @@ static long group_tiles_small(const GemmArgs& a) {
 // does a lone conv gain from the split-K path of the grouped kernel? (few tiles, long K, scratch available)
 static bool worth_splitting(const GemmArgs& a) {
     // (a.N & 3) == 0: the slab stores / reloads are 16-byte accesses at slab + m * N + n
-    return a.conv && a.split_ws && a.split_cnt && gemm_f32_groupable(a) && (a.N & 3) == 0 && a.Kpad / BK >= 32 && group_tiles_small(a) <= 16 &&
+    return a.conv && a.split_ws && a.split_cnt && gemm_f32_groupable(a) && (a.N & 3) == 0 && a.Kpad / BK >= 16 && group_tiles_small(a) <= 16 &&
            (long)a.M * a.N * 2 <= a.split_ws_elems;
 }
 
@@ -1096,7 +1109,10 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     // along K; the slices of a tile meet through the scratch the caller lent (GemmArgs::split_ws / split_cnt), reduced in
     // fixed order by the last slice to finish (see igemm_tile).  The decision is a function of the problem ALONE
     // (worth_splitting), so a conv sums in the same order whether it is launched on its own or inside a group.
-    // Measured (HRNet-32 256x256, frames/s with / without): batch 1 362 / 302, batch 2 678 / 600, batch 4 1171 / 1172.  A
+    // Measured (HRNet-32 256x256, frames/s with / without): batch 1 362 / 302, batch 2 678 / 600, batch 4 1171 / 1172 -- with the
+    // __threadfence() hand-off of rounds 2-3; with the agent-scope release / acquire by lane 0 (igemm_tile) the same rule gives 430 / 840 /
+    // 1353, and splitting from 16 chunks into slices of >= 6 (was: from 32, >= 12) 442 / 856 / 1354; finer (slices of 4, or problems of up to
+    // 64 tiles) loses again (411 / 755 / 1306; 444 / 800 / 1202).  A
     // group-wide rule (split everything to the shortest problem's length whenever the level had < 192 tiles) lost 13 % /
     // 10 % at batch 2 / 4: the device-scope release / acquire around the counter (an L2 write-back on this multi-XCD
     // part) and the second pass over the slabs cost ~15 us, which only a long loop on a handful of tiles repays.
@@ -1111,7 +1127,7 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
         float* ws = a.split_ws; int* cnt = a.split_cnt;
         a.split_ws = nullptr; a.split_cnt = nullptr;
         if (ws && cnt && worth_splitting(list[it[i].idx])) {
-            int sp = std::min(8, chunks / 12);
+            int sp = std::min(8, chunks / 6);
             const long slab = (long)a.M * a.N;
             if ((ws_used + slab * sp) > list[it[i].idx].split_ws_elems || cnt_used + it[i].tiles > list[it[i].idx].split_cnt_elems) sp = 1;
             if (sp > 1) {

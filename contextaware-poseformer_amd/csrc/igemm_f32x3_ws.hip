@@ -39,11 +39,18 @@ bool gemm_f32x3_ok(const GemmArgs& a) {
 }
 
 // As for the bf16 tile (igemm_bf16_ws.hip): which kernel a conv runs on is a function of the conv ALONE, so that every schedule of
-// the engine produces the same bits.  From 2 GFLOP up (HRNet-32 from batch ~27): below that a level is too few 256-pixel tiles.
-// (diag builds: CAPF_F32X3_MIN_MFLOP)
+// the engine produces the same bits.  From 400 MFLOP and batch 6 up (the HRNet-32 branch convs from batch 6, measured in ms per forward
+// against the direct kernel with split-K / the Winograd kernels: batch 6 3.67 / 3.80 / -, 8 3.76 / 3.90 / 5.47, 16 4.27 / 4.75 / 5.86,
+// 24 4.90 / 6.08 / 6.37; below, the direct kernel wins: batch 4 3.49 / 2.92).  (diag builds: CAPF_F32X3_MIN_MFLOP)
+bool f32x3_takes(int B, int H, int W, int Cin, int Cout) {
+    static const double min_flop = [] { const char* e = diag_env("CAPF_F32X3_MIN_MFLOP"); return (e ? atof(e) : 400.0) * 1e6; }();
+    X3Problem q;
+    return B >= 6 && 2.0 * (double)B * H * W * Cout * 9.0 * Cin >= min_flop && x3_plan(B, H, W, Cin, Cout, X3_NS, &q);
+}
+
 bool gemm_f32x3_wanted(const GemmArgs& a) {
-    static const double min_flop = [] { const char* e = diag_env("CAPF_F32X3_MIN_MFLOP"); return (e ? atof(e) : 2000.0) * 1e6; }();
-    return a.Wp3 && !a.out_bf16 && 2.0 * (double)a.M * a.N * 9.0 * a.Cin >= min_flop && gemm_f32x3_ok(a);
+    return a.Wp3 && !a.out_bf16 && a.H > 0 && a.W > 0 && a.M % (a.H * a.W) == 0 && f32x3_takes(a.M / (a.H * a.W), a.H, a.W, a.Cin, a.N) &&
+           gemm_f32x3_ok(a);
 }
 
 struct X3GroupArgs {

@@ -189,6 +189,7 @@ hipError_t launch_pack_conv_bf16_ws(const float* w, const float* gamma, const fl
 // bf16 elements), passed as GemmArgs::Wp3
 bool gemm_f32x3_ok(const GemmArgs& a);
 bool gemm_f32x3_wanted(const GemmArgs& a);             // eligible, carries Wp3, and large enough for this tile (a function of the conv alone)
+bool f32x3_takes(int B, int H, int W, int Cin, int Cout);   // the shape half of that rule (what the engine asks before it picks a weight layout)
 long f32x3_pack_elems(int Cout, int Cin);
 hipError_t launch_gemm_f32x3(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s);

@@ -149,11 +149,15 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     table = {name: kern for name, kern, _ in eng.op_table(64)}
     assert table["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
     assert table["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
-    # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below
-    # batch 8, the Winograd kernel from there, and the split-fp32 tile from 2 GFLOP per conv (batch 27 for these branches)
+    # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below batch 6 and
+    # the split-fp32 tile from 400 MFLOP per conv (batch 6 for these branches); a plan without that tile (CAPF_PLAN_NO_F32X3) runs them on
+    # the Winograd kernel from batch 24
     assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
-    mid = {name: kern for name, kern, _ in eng.op_table(16)}
-    assert mid["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"        # F(4,3): row length 64 is a multiple of 4
+    assert {name: kern for name, kern, _ in eng.op_table(6)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
+    from capf.lib import PLAN_NO_F32X3
+    eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
+    assert {name: kern for name, kern, _ in eng_w.op_table(24)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"   # F(4,3): row length 64 is a multiple of 4
+    assert {name: kern for name, kern, _ in eng_w.op_table(16)}["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
     small = {name: kern for name, kern, _ in eng.op_table(4)}
     assert small["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
     # layer1's HBM-bound 1x1 bottleneck convs: the pointwise kernel from 2048 tiles per launch, the general tile below
@@ -273,15 +277,15 @@ def test_executed_flops_of_winograd_ops_are_half_or_two_thirds_of_the_algorithmi
     t64, e64 = eng.op_table(64), eng.op_executed_flops(64)
     assert any(k.startswith("igemm_f32x3") for _, k, _ in t64)
     assert all(abs(e / a - 6.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32x3"))
-    table, ex = eng.op_table(16), eng.op_executed_flops(16)
+    from capf.lib import PLAN_NO_F32X3
+    eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
+    table, ex = eng_w.op_table(32), eng_w.op_executed_flops(32)
     seen = set()
     for (name, kern, alg), e in zip(table, ex):
         if kern.startswith("igemm_wino"):
             r = e / alg
             assert abs(r - 0.5) < 1e-9 or abs(r - 2.0 / 3.0) < 1e-9, (name, r)
             seen.add(round(r, 3))
-        elif kern.startswith("igemm_f32x3"):
-            assert abs(e / alg - 6.0) < 1e-9, (name, e / alg)
         elif kern.startswith("igemm") and alg > 0:
             assert 1.0 - 1e-9 <= e / alg <= 1.2, (name, kern, e / alg)       # K padded to the chunk width only
     assert 0.5 in seen
