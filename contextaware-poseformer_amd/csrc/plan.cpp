@@ -132,7 +132,7 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     // ... and in the layout of the 2-D halo tile (igemm_bf16_ws.hip), which takes them from 512 tiles per launch
     if (use_bf16 && use_ws && ks == 3 && stride == 1 && x.C % 16 == 0 && Cout % 8 == 0) pk.ws = true;
     // fp32: the Winograd-eligible convs also keep their weights as three bf16 pieces for the split-fp32 tile (igemm_f32x3_ws.hip), which
-    // takes them from 2 GFLOP per conv up (gemm_f32x3_wanted)
+    // takes them from 400 MFLOP per conv and batch 6 up (f32x3_takes)
     if (use_wino && use_x3 && x.W <= 256) pk.x3 = true;
     packs.push_back(pk);
 

@@ -87,7 +87,7 @@ enum capf_plan_flag {
     CAPF_PLAN_LIFTER_FP32 = 64,     /* compute_dtype = CAPF_BF16: keep the lifter's qkv / proj / fc1 / fc2 on the fp32 kernels (bf16 backbone only);
                                      * the accuracy / speed trade bench.py reports as `vs_fp32_oracle`                                    */
     CAPF_PLAN_NO_F32X3 = 128        /* fp32 3x3 stride-1 convs without the split-fp32 tile (three bf16 pieces per operand on the bf16
-                                     * matrix pipe, igemm_f32x3_ws.hip): the Winograd kernels at every batch, as in round 3            */
+                                     * matrix pipe, igemm_f32x3_ws.hip): the Winograd kernels (from batch 24; the direct kernel below)    */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -290,7 +290,7 @@ int capf_op_pack_conv_bf16_ws(void* stream, const float* w_oihw, const float* ga
 int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* convs);
 
 /* Split-fp32 tile of the 3x3 / stride-1 / pad-1 fp32 conv (csrc/igemm_f32x3_ws.hip; what capf_forward runs for the BasicBlock convs of
- * an fp32 model, pose_hrnet.py:66-95, from 2 GFLOP per conv): fp32 tensors in and out; every operand is split, exactly, into three
+ * an fp32 model, pose_hrnet.py:66-95, from 400 MFLOP per conv and batch 6): fp32 tensors in and out; every operand is split, exactly, into three
  * bf16 numbers and the six piece products of weight >= 2^-18 run on the bf16 matrix pipe with fp32 accumulation -- the dropped
  * products are below the rounding of one fp32 multiply, so results agree with the direct fp32 kernel to accumulation order.
  * Cin % 16 == 0, Cout % 4 == 0, W <= 256.  w_packed holds capf_op_conv_f32x3_pack_elems(Cout, Cin) bf16 elements written by

@@ -347,7 +347,7 @@ def test_two_chain_schedule_is_bit_identical_to_one_chain(dtype, backbone, B, H,
     grouping and their stream differ -> the same bits, call after call (a missing event dependency would show up as a
     run-to-run difference).  The 64 x 64 / batch 16 case runs with CAPF_PLAN_NO_WINOGRAD: its 16 x 16 ... 2 x 2 maps are a handful of
     tiles per conv, so the 3x3 convs of BOTH concurrent chains take the split-K path (a conv splits by its shape alone) and must not
-    share slabs and counters (each chain has its own).  Batch 48 fp32: the branch convs are past 2 GFLOP each and run on the
+    share slabs and counters (each chain has its own).  Batch 48 fp32: the branch convs run on the
     split-fp32 tile (igemm_f32x3_ws.hip) in both schedules."""
     import copy, contextlib, io
     from capf import synth
