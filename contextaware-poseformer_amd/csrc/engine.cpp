@@ -115,7 +115,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.act = op.act;
     a.out_bf16 = op.out_bf16;
     static const bool splitk_on = [] { const char* e = diag_env("CAPF_SPLITK"); return !e || atoi(e) != 0; }();   // A/B runs only
-    if (op.conv && !op.bf16 && split_ws && lanes != 1 && splitk_on) {      // one stream: launches use the scratch one after the other
+    if ((op.conv || (op.kind == OP_GEMM && op.ln_w < 0 && op.res_param < 0)) && !op.bf16 && split_ws && lanes != 1 && splitk_on) {   // one stream: launches use the scratch one after the other
         a.split_ws = on_side_chain ? split_ws_side : split_ws;
         a.split_cnt = on_side_chain ? split_cnt_side : split_cnt;
         a.split_ws_elems = SPLIT_WS_ELEMS; a.split_cnt_elems = SPLIT_CNT_ELEMS;

@@ -445,8 +445,9 @@ __device__ __forceinline__ void igemm_tile(const GemmArgs& p, const int bid, con
     if (ABL == 5 && p.M > 0) return;     // (ablation) no epilogue; the condition is opaque to the compiler, the MFMAs stay
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     const bool vec_ok = (p.N & 3) == 0;
-    if (SPLITK && AMODE == AMODE_CONV && PLAIN && p.split_cnt) {
-        // ---- conv split-K: park the raw partial tile, count, and let the last slice of the tile reduce + finish
+    if (SPLITK && PLAIN && p.split_cnt) {
+        // ---- split-K with an in-launch reduction (small-batch convs; rows-mode GEMMs of the batch-1 lifter): park the raw partial tile,
+        // count, and let the last slice of the tile reduce + finish
         float* slab = p.split_ws + (long)ky * p.split_stride;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -607,6 +608,17 @@ __global__ __launch_bounds__(64 * NW) void igemm_f32_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[S * (BM + BN) * BK + (LNA ? 2 * LNK + 2 * BM : 0)];
     igemm_tile<NW, BM, BN, WM, WN, S, AMODE, GELU, PLAIN, ABL, LNA>(p, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y, lds,
                                                                      blockIdx.x);
+#endif
+}
+
+// Rows-mode GEMM split along K with the in-launch reduction of igemm_tile (batch 1-2: the joint blocks' 17- / 34-row GEMMs are 10-30 tiles
+// with a 20- / 40-chunk K loop each -- pose_dformer.py:15-59 at B p (l c) -- on 256 CUs): block b = slice b % splits of tile b / splits.
+template <bool GELU>
+__global__ __launch_bounds__(256) void igemm_f32_rows_splitk_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float lds[3 * (64 + 64) * BK];
+    const int tile = blockIdx.x / p.splits, ky = blockIdx.x - tile * p.splits;
+    igemm_tile<4, 64, 64, 32, 32, 3, AMODE_ROWS, GELU, true, 0, false, true>(p, tile, ky, lds, blockIdx.x);
 #endif
 }
 
@@ -999,6 +1011,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
     if (a.conv && a.Cin % 4 != 0)
         return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : (stem_stream_f32_ok(a) ? "igemm_f32_stem_stream<w4,64x64>" : "igemm_f32_smallc<w4,128x64>");
     if (gemm_f32_pw_ok(a)) return gemm_f32_pw_kernel_name();
+    if (gemm_f32_rows_splitk(a)) return "igemm_f32_rows_splitk";
     return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
 
@@ -1073,6 +1086,19 @@ static bool worth_splitting(const GemmArgs& a) {
     // (a.N & 3) == 0: the slab stores / reloads are 16-byte accesses at slab + m * N + n
     return a.conv && a.split_ws && a.split_cnt && gemm_f32_groupable(a) && (a.N & 3) == 0 && a.Kpad / BK >= 16 && group_tiles_small(a) <= 16 &&
            (long)a.M * a.N * 2 <= a.split_ws_elems;
+}
+
+// the same question for a rows-mode GEMM (the lifter's projections at batch 1-2): at most 32 tiles of 64 x 64, at least 16 chunks, plain row
+// pitches, no LayerNorm fold, scratch lent by the caller.  Measured (ms per forward at batch 1 / 2 / 4): without 2.26 / 2.37 / 2.92; this
+// rule 2.17 / 2.26 / 2.88; up to 64 tiles 2.22 / 2.26 / 2.89; from 8 chunks in slices of 4 2.20 / 2.29 / 2.88
+bool gemm_f32_rows_splitk(const GemmArgs& a) {
+    if (a.conv || a.ln_g || a.splits > 1 || !a.split_ws || !a.split_cnt || a.rscale || (a.N & 3) || a.Kpad % BK != 0) return false;
+    if (a.amap.G != 1 || a.omap.G != 1 || (a.res && a.rmap.G != 1)) return false;
+    const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    const int chunks = a.Kpad / BK;
+    if (tiles > 32 || chunks < 16) return false;
+    const int sp = std::min(8, chunks / 6);
+    return sp > 1 && (long)a.M * a.N * sp <= a.split_ws_elems && tiles <= a.split_cnt_elems && (double)a.M * (double)a.omap.S1 < 4.0e9;
 }
 
 hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
@@ -1174,7 +1200,18 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (gemm_f32_pw_ok(a_in)) return launch_gemm_f32_pw(a_in, s);
     if (a_in.splits <= 1 && worth_splitting(a_in)) return launch_gemm_f32_group(&a_in, 1, s);
     GemmArgs a = a_in;
-    a.split_ws = nullptr; a.split_cnt = nullptr;                           // (the in-kernel reduction belongs to the grouped kernel)
+    if (gemm_f32_rows_splitk(a_in)) {                                      // a handful of tiles with a long K loop: slices + in-launch reduction
+        const int chunks = a.Kpad / BK, tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+        int sp = std::min(8, chunks / 6);
+        a.cps = (chunks + sp - 1) / sp;
+        a.splits = (chunks + a.cps - 1) / a.cps;
+        a.split_stride = (long)a.M * a.N;
+        if (a.rs_div <= 0) a.rs_div = 1;
+        if (a.act == ACT_GELU) hipLaunchKernelGGL(igemm_f32_rows_splitk_kernel<true>, dim3(tiles * a.splits), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(igemm_f32_rows_splitk_kernel<false>, dim3(tiles * a.splits), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    a.split_ws = nullptr; a.split_cnt = nullptr;                           // (the in-kernel reduction belongs to the grouped / split kernels)
     if (a.splits <= 1) { a.splits = 1; a.cps = a.Kpad / BK; a.split_stride = 0; }
     else if (a.conv || a.bias || a.res) return hipErrorInvalidValue;     // split-K slabs are raw partial sums
     if (a.rs_div <= 0) a.rs_div = 1;

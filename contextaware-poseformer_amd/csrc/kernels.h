@@ -120,6 +120,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 // must satisfy gemm_f32_groupable()
 static constexpr int MAXG = 8;
 bool gemm_f32_groupable(const GemmArgs& a);
+bool gemm_f32_rows_splitk(const GemmArgs& a);        // rows-mode GEMM that launch_gemm_f32 splits along K (few tiles, long K, scratch lent)
 hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_f32_kernel_name(const GemmArgs& a);   // which template instantiation launch_gemm_f32 picks
 // fp32 pointwise (1x1 / stride 1) conv for the HBM-bound bottleneck convs of layer1 (igemm_f32_pw.hip): ping-pong schedule,
