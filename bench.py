@@ -68,8 +68,8 @@ CONFIGS = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json configs[i]; explicit flags override")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 64; 512 with --train)")
     ap.add_argument("--train", action="store_true", default=None, help="configs[3]: training step (frozen backbone forward, "
