@@ -293,7 +293,8 @@ int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* convs)
  * an fp32 model, pose_hrnet.py:66-95, from 400 MFLOP per conv and batch 6): fp32 tensors in and out; every operand is split, exactly, into three
  * bf16 numbers and the six piece products of weight >= 2^-18 run on the bf16 matrix pipe with fp32 accumulation -- the dropped
  * products are below the rounding of one fp32 multiply, so results agree with the direct fp32 kernel to accumulation order.
- * Cin % 16 == 0, Cout % 4 == 0, W <= 256.  w_packed holds capf_op_conv_f32x3_pack_elems(Cout, Cin) bf16 elements written by
+ * (Non-finite / denormal operands: an infinite input gives NaN -- Inf - Inf in the split -- where the fp32 pipe gives +-Inf; fp32 denormals are
+ * flushed.)  Cin % 16 == 0, Cout % 4 == 0, W <= 256.  w_packed holds capf_op_conv_f32x3_pack_elems(Cout, Cin) bf16 elements written by
  * capf_op_pack_conv_f32x3 (BatchNorm folded as in capf_op_pack_conv, then split; bias fp32 [Cout], may be NULL).
  * capf_op_conv_f32x3_group: up to 8 such convs in ONE grid (capf_conv_desc with w_packed in this layout, ks = 3, stride = 1).       */
 int64_t capf_op_conv_f32x3_pack_elems(int Cout, int Cin);
