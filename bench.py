@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line: whole-job frames/s plus
                  frames; --lifter-fp32 (plan flag CAPF_PLAN_LIFTER_FP32) keeps the lifter's projections fp32 under --dtype bf16.
 fp32 configurations: the 3x3 stride-1 convs run on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 numbers
 (csrc/igemm_f32x3_ws.hip: results as close to fp64 as the direct fp32 MFMA kernel's); --no-f32x3 (CAPF_PLAN_NO_F32X3) times
-round 3's plan (Winograd on the fp32 pipe) for comparison.  `dtype` stays "f32": that is the arithmetic the path computes in.
+round 3's plan (Winograd on the fp32 pipe) for comparison, and every fp32 inference line carries that plan's rate for the same K steps as
+`fp32_pipe_plan` (never `value`).  `dtype` stays "f32": that is the arithmetic the path computes in.
 """
 import argparse
 import copy
@@ -81,6 +82,7 @@ def parse(argv=None):
     ap.add_argument("--embed", type=int, default=128, help="poseformer.embed_dim_ratio (128 = the reference default; 256 = the "
                     "labelled extra point for BASELINE's 'dim=256')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-plan", action="store_true", help="skip the extra measurement of the fp32-pipe plan (`fp32_pipe_plan` in the line)")
     ap.add_argument("--no-f32x3", action="store_true", help="fp32 runs: 3x3 convs on the Winograd kernels at every batch (CAPF_PLAN_NO_F32X3: round 3's plan) instead of the split-fp32 tile")
     ap.add_argument("--lifter-fp32", action="store_true", help="bf16 runs: lifter projections on the fp32 kernels (CAPF_PLAN_LIFTER_FP32)")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -393,6 +395,37 @@ def main():
         except Exception as e:                                 # an extra measurement must never cost the contract's line
             overlapped = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.synchronize(dev)
+    # ---- fp32 configurations: the same K steps on round 3's plan (CAPF_PLAN_NO_F32X3: the 3x3 convs on the fp32 matrix pipe -- Winograd /
+    # direct kernels -- instead of the split-fp32 tile on the bf16 pipe), so that both arithmetic routes are on one line; never `value`
+    fp32_pipe_plan = None
+    if not a.train and world == 1 and a.dtype != "bf16" and not a.no_f32x3 and not a.no_alt_plan:
+        try:
+            from capf.lib import PLAN_NO_F32X3 as _NOX3
+            with contextlib.redirect_stdout(io.StringIO()):
+                m3 = CA_PF(cfg, compute_dtype="fp32", plan_flags=pflags | _NOX3).eval()
+            m3.load_state_dict(sd_cpu)
+            m3 = m3.to(dev)
+            if a.lanes >= 0:
+                m3.engine_for(img).set_lanes(a.lanes)
+            kc3 = kc0.clone()
+            with torch.no_grad():
+                for _ in range(max(a.warmup, 2)):
+                    kc3.copy_(kc0)
+                    o3 = m3(img, k2d, kc3)
+                torch.cuda.synchronize(dev)
+                t3 = time.perf_counter()
+                for _ in range(a.steps):
+                    kc3.copy_(kc0)
+                    o3 = m3(img, k2d, kc3)
+                torch.cuda.synchronize(dev)
+                el3 = time.perf_counter() - t3
+            fp32_pipe_plan = {"value": round(B * a.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / a.steps * 1e3, 4), "steps": a.steps,
+                              "max_abs_diff_to_contract_step": float((o3 - out).abs().max()),
+                              "note": "plan_flags |= CAPF_PLAN_NO_F32X3: 3x3 convs on the fp32 matrix pipe (Winograd from batch 24, direct below); not the headline"}
+            del m3, o3
+        except Exception as e:
+            fp32_pipe_plan = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize(dev)
     dist_info = None
     if world > 1:
         # evidence that the job really ran on `world` ranks of the named backend: a SUM all-reduce of ones on the device
@@ -526,6 +559,8 @@ def main():
             result["distributed"] = dist_info
         if overlapped is not None:
             result["overlapped_steps"] = overlapped
+        if fp32_pipe_plan is not None:
+            result["fp32_pipe_plan"] = fp32_pipe_plan
         if train_phases is not None:
             result["train_phases"] = train_phases
         if world == 1 and not a.no_cpu_baseline:

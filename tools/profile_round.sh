@@ -10,7 +10,7 @@ TAG=${1:-r2}; KEY=${2:-cfg1}; shift; shift
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --no-cpu-baseline $*"
+BENCH="python $PWD/bench.py --no-cpu-baseline --no-alt-plan $*"     # (the traced passes time the product plan only)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH --steps 10 --overlap 0 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH --steps 2 --warmup 1 --profile-steps 1 > $OUT/pmc_fetch.log 2>&1
