@@ -356,76 +356,82 @@ def main():
                         "allreduce_ms": round(acc_ms[2] / nrep, 3), "optimizer_ms": round(acc_ms[3] / nrep, 3),
                         "note": "HIP events on the step's stream over 3 untimed extra steps; optimizer = fused AdamW + the lifter repack"}
 
-    # ---- consecutive batches in flight on separate HIP streams (a serving loop's option, NOT the contract's step: two batches
-    # of B frames are resident at once, so this never becomes `value`).  The lifter's 17-token kernels, the low-resolution
-    # branches and every launch's tail leave CUs idle that the other batch's convolutions fill.
-    overlapped = None
-    if not a.train and world == 1 and a.overlap > 1:
-        try:
-            lanes = [(model, kc_work, torch.cuda.Stream(dev))]
-            for _ in range(a.overlap - 1):
+    def measure_overlapped():
+        # ---- consecutive batches in flight on separate HIP streams (a serving loop's option, NOT the contract's step: two batches
+        # of B frames are resident at once, so this never becomes `value`).  The lifter's 17-token kernels, the low-resolution
+        # branches and every launch's tail leave CUs idle that the other batch's convolutions fill.
+        overlapped = None
+        if not a.train and world == 1 and a.overlap > 1:
+            try:
+                lanes = [(model, kc_work, torch.cuda.Stream(dev))]
+                for _ in range(a.overlap - 1):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        m2 = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
+                    m2.load_state_dict(sd_cpu)
+                    lanes.append((m2.to(dev), kc0.clone(), torch.cuda.Stream(dev)))
+                if a.lanes >= 0:
+                    for m, _, _ in lanes[1:]:
+                        m.engine_for(img).set_lanes(a.lanes)
+
+                def lane_step(i):
+                    m, kcw, st = lanes[i % len(lanes)]
+                    with torch.cuda.stream(st):
+                        kcw.copy_(kc0)
+                        return m(img, k2d, kcw)
+
+                with torch.no_grad():
+                    outs = [lane_step(i) for i in range(max(a.warmup, len(lanes)))]
+                    fence()
+                    same = all(torch.equal(o, out) for o in outs[-len(lanes):])       # every engine reproduces the contract step's output
+                    t1 = time.perf_counter()
+                    for i in range(a.steps):
+                        lane_step(i)
+                    fence()
+                    el2 = time.perf_counter() - t1
+                overlapped = {"streams": len(lanes), "value": round(B * a.steps / el2, 2), "unit": "frames/s", "steps": a.steps,
+                              "ms_per_step": round(el2 / a.steps * 1e3, 4), "frames_in_flight": B * len(lanes),
+                              "outputs_bit_identical_to_contract_step": bool(same),
+                              "note": "same K steps, issued round-robin on separate engines / HIP streams; not the headline"}
+                del lanes, outs
+            except Exception as e:                                 # an extra measurement must never cost the contract's line
+                overlapped = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.synchronize(dev)
+        return overlapped
+
+    def measure_fp32_pipe_plan():
+        # ---- fp32 configurations: the same K steps on round 3's plan (CAPF_PLAN_NO_F32X3: the 3x3 convs on the fp32 matrix pipe -- Winograd /
+        # direct kernels -- instead of the split-fp32 tile on the bf16 pipe), so that both arithmetic routes are on one line; never `value`
+        fp32_pipe_plan = None
+        if not a.train and world == 1 and a.dtype != "bf16" and not a.no_f32x3 and not a.no_alt_plan:
+            try:
+                from capf.lib import PLAN_NO_F32X3 as _NOX3
                 with contextlib.redirect_stdout(io.StringIO()):
-                    m2 = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
-                m2.load_state_dict(sd_cpu)
-                lanes.append((m2.to(dev), kc0.clone(), torch.cuda.Stream(dev)))
-            if a.lanes >= 0:
-                for m, _, _ in lanes[1:]:
-                    m.engine_for(img).set_lanes(a.lanes)
-
-            def lane_step(i):
-                m, kcw, st = lanes[i % len(lanes)]
-                with torch.cuda.stream(st):
-                    kcw.copy_(kc0)
-                    return m(img, k2d, kcw)
-
-            with torch.no_grad():
-                outs = [lane_step(i) for i in range(max(a.warmup, len(lanes)))]
-                fence()
-                same = all(torch.equal(o, out) for o in outs[-len(lanes):])       # every engine reproduces the contract step's output
-                t1 = time.perf_counter()
-                for i in range(a.steps):
-                    lane_step(i)
-                fence()
-                el2 = time.perf_counter() - t1
-            overlapped = {"streams": len(lanes), "value": round(B * a.steps / el2, 2), "unit": "frames/s", "steps": a.steps,
-                          "ms_per_step": round(el2 / a.steps * 1e3, 4), "frames_in_flight": B * len(lanes),
-                          "outputs_bit_identical_to_contract_step": bool(same),
-                          "note": "same K steps, issued round-robin on separate engines / HIP streams; not the headline"}
-            del lanes, outs
-        except Exception as e:                                 # an extra measurement must never cost the contract's line
-            overlapped = {"error": f"{type(e).__name__}: {e}"[:300]}
-            torch.cuda.synchronize(dev)
-    # ---- fp32 configurations: the same K steps on round 3's plan (CAPF_PLAN_NO_F32X3: the 3x3 convs on the fp32 matrix pipe -- Winograd /
-    # direct kernels -- instead of the split-fp32 tile on the bf16 pipe), so that both arithmetic routes are on one line; never `value`
-    fp32_pipe_plan = None
-    if not a.train and world == 1 and a.dtype != "bf16" and not a.no_f32x3 and not a.no_alt_plan:
-        try:
-            from capf.lib import PLAN_NO_F32X3 as _NOX3
-            with contextlib.redirect_stdout(io.StringIO()):
-                m3 = CA_PF(cfg, compute_dtype="fp32", plan_flags=pflags | _NOX3).eval()
-            m3.load_state_dict(sd_cpu)
-            m3 = m3.to(dev)
-            if a.lanes >= 0:
-                m3.engine_for(img).set_lanes(a.lanes)
-            kc3 = kc0.clone()
-            with torch.no_grad():
-                for _ in range(max(a.warmup, 2)):
-                    kc3.copy_(kc0)
-                    o3 = m3(img, k2d, kc3)
+                    m3 = CA_PF(cfg, compute_dtype="fp32", plan_flags=pflags | _NOX3).eval()
+                m3.load_state_dict(sd_cpu)
+                m3 = m3.to(dev)
+                if a.lanes >= 0:
+                    m3.engine_for(img).set_lanes(a.lanes)
+                kc3 = kc0.clone()
+                with torch.no_grad():
+                    for _ in range(max(a.warmup, 2)):
+                        kc3.copy_(kc0)
+                        o3 = m3(img, k2d, kc3)
+                    torch.cuda.synchronize(dev)
+                    t3 = time.perf_counter()
+                    for _ in range(a.steps):
+                        kc3.copy_(kc0)
+                        o3 = m3(img, k2d, kc3)
+                    torch.cuda.synchronize(dev)
+                    el3 = time.perf_counter() - t3
+                fp32_pipe_plan = {"value": round(B * a.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / a.steps * 1e3, 4), "steps": a.steps,
+                                  "max_abs_diff_to_contract_step": float((o3 - out).abs().max()),
+                                  "note": "plan_flags |= CAPF_PLAN_NO_F32X3: 3x3 convs on the fp32 matrix pipe (Winograd from batch 24, direct below); not the headline"}
+                del m3, o3
+            except Exception as e:
+                fp32_pipe_plan = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.synchronize(dev)
-                t3 = time.perf_counter()
-                for _ in range(a.steps):
-                    kc3.copy_(kc0)
-                    o3 = m3(img, k2d, kc3)
-                torch.cuda.synchronize(dev)
-                el3 = time.perf_counter() - t3
-            fp32_pipe_plan = {"value": round(B * a.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / a.steps * 1e3, 4), "steps": a.steps,
-                              "max_abs_diff_to_contract_step": float((o3 - out).abs().max()),
-                              "note": "plan_flags |= CAPF_PLAN_NO_F32X3: 3x3 convs on the fp32 matrix pipe (Winograd from batch 24, direct below); not the headline"}
-            del m3, o3
-        except Exception as e:
-            fp32_pipe_plan = {"error": f"{type(e).__name__}: {e}"[:300]}
-            torch.cuda.synchronize(dev)
+        return fp32_pipe_plan
+
     dist_info = None
     if world > 1:
         # evidence that the job really ran on `world` ranks of the named backend: a SUM all-reduce of ones on the device
@@ -453,6 +459,15 @@ def main():
         oexec = eng.op_executed_flops(B)
         acc = {}
         out_buf = torch.empty_like(out)
+        # A launch's duration is the difference of the event markers in front of it and in front of the next one: it contains one
+        # marker's own cost on the GPU's command processor, which is not the kernel's.  Calibrated here (markers back to back on the
+        # same stream, nothing between them) and subtracted from every launch: with it the per-kernel averages agree with rocprofv3's
+        # kernel durations (profiles/), without it they sit 5-9 us above them.
+        cal_ev = [torch.cuda.Event(enable_timing=True) for _ in range(129)]
+        for e in cal_ev:
+            e.record(stream)
+        torch.cuda.synchronize(dev)
+        marker_ms = sorted(cal_ev[i].elapsed_time(cal_ev[i + 1]) for i in range(128))[64]
         with torch.no_grad():
             for _ in range(max(1, a.profile_steps)):
                 kc_work.copy_(kc0)
@@ -476,7 +491,7 @@ def main():
                     if not kern or table[l][0].startswith("copy."):
                         continue
                     e = acc.setdefault(kern, [0.0, 0.0, 0, 0.0, 0.0])
-                    e[0] += ms[l]; e[1] += sum(table[i][2] for i in ops_); e[2] += 1; e[3] += sum(obytes[i] for i in ops_)
+                    e[0] += max(ms[l] - marker_ms, 0.0); e[1] += sum(table[i][2] for i in ops_); e[2] += 1; e[3] += sum(obytes[i] for i in ops_)
                     e[4] += sum(oexec[i] for i in ops_)
                 n_launches = len(members)
         nprof = max(1, a.profile_steps)
@@ -535,7 +550,7 @@ def main():
                                  "mfma_busy_frac": round(gemm_busy / (gemm_ms * 1e-3), 4),
                                  "algorithmic_gbs": round(gemm_by / (gemm_ms * 1e-3) / 1e9, 1),
                                  "share_of_forward": round(gemm_ms / total_ms, 4)},
-            "forward_ms_by_events": round(total_ms / nprof, 3)})
+            "forward_ms_by_events": round(total_ms / nprof, 3), "event_marker_us": round(marker_ms * 1e3, 2)})
         if a.kernel_table:
             for k, e in sorted(acc.items(), key=lambda kv: -kv[1][0]):
                 tf = e[1] / (e[0] * 1e-3) / 1e12 if e[0] > 0 else 0
@@ -543,6 +558,8 @@ def main():
                 ex = e[4] / (e[0] * 1e-3) / 1e12 if e[0] > 0 else 0
                 print(f"  {k:34s} {e[2] // nprof:4d} launches/step {e[0] / nprof:9.3f} ms/step {tf:8.2f} TFLOP/s(alg) {ex:8.2f} TFLOP/s(exec) "
                       f"{gb:8.1f} GB/s(alg)", file=sys.stderr)
+        overlapped = measure_overlapped()                     # (extra measurements run after the per-launch timing passes: they leave the chip warm)
+        fp32_pipe_plan = measure_fp32_pipe_plan()
         launches, flops = eng.stats(B)
         par = f"dp{world} (independent frames, " + ("one flat-gradient all-reduce per step)" if a.train else "no collective)")
         result = {

@@ -179,11 +179,18 @@ struct Engine {
     int wino_min_batch = 24;       // below this batch the Winograd-eligible convs the split-fp32 tile does not take run the direct kernel (with
                                    // split-K; batch 16: 4.75 vs 5.86 ms per forward, batch 24: 6.08 vs 6.37)
     // does the conv leave the direct kernel (for the split-fp32 tile or a Winograd kernel: launch_gemm_wino decides which) at this batch?
+    // (asked several times per conv and launch: the answer for the current batch is kept per op)
     bool wino_now(const Op& op, int batch) const {
         if (!op.wino) return false;
-        if (packs[op.pack].x3 && f32x3_takes(batch, op.H, op.W, op.Cin, op.N)) return true;
-        return batch >= wino_min_batch;
+        const size_t i = (size_t)(&op - ops.data());
+        if (batch != wn_batch || wn_cache.size() != ops.size()) { wn_cache.assign(ops.size(), (signed char)-1); wn_batch = batch; }
+        if (i < wn_cache.size() && wn_cache[i] >= 0) return wn_cache[i] != 0;
+        const bool yes = (packs[op.pack].x3 && f32x3_takes(batch, op.H, op.W, op.Cin, op.N)) || batch >= wino_min_batch;
+        if (i < wn_cache.size()) wn_cache[i] = yes ? 1 : 0;
+        return yes;
     }
+    mutable std::vector<signed char> wn_cache;
+    mutable int wn_batch = -1;
     bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)

@@ -42,15 +42,18 @@ bool gemm_f32x3_ok(const GemmArgs& a) {
 // the engine produces the same bits.  From 400 MFLOP and batch 6 up (the HRNet-32 branch convs from batch 6, measured in ms per forward
 // against the direct kernel with split-K / the Winograd kernels: batch 6 3.67 / 3.80 / -, 8 3.76 / 3.90 / 5.47, 16 4.27 / 4.75 / 5.86,
 // 24 4.90 / 6.08 / 6.37; below, the direct kernel wins: batch 4 3.49 / 2.92).  (diag builds: CAPF_F32X3_MIN_MFLOP)
-bool f32x3_takes(int B, int H, int W, int Cin, int Cout) {
+static bool x3_big_enough(int B, int H, int W, int Cin, int Cout) {
     static const double min_flop = [] { const char* e = diag_env("CAPF_F32X3_MIN_MFLOP"); return (e ? atof(e) : 400.0) * 1e6; }();
-    X3Problem q;
-    return B >= 6 && 2.0 * (double)B * H * W * Cout * 9.0 * Cin >= min_flop && x3_plan(B, H, W, Cin, Cout, X3_NS, &q);
+    return B >= 6 && 2.0 * (double)B * H * W * Cout * 9.0 * Cin >= min_flop;
 }
 
-bool gemm_f32x3_wanted(const GemmArgs& a) {
-    return a.Wp3 && !a.out_bf16 && a.H > 0 && a.W > 0 && a.M % (a.H * a.W) == 0 && f32x3_takes(a.M / (a.H * a.W), a.H, a.W, a.Cin, a.N) &&
-           gemm_f32x3_ok(a);
+bool f32x3_takes(int B, int H, int W, int Cin, int Cout) {
+    X3Problem q;
+    return x3_big_enough(B, H, W, Cin, Cout) && x3_plan(B, H, W, Cin, Cout, X3_NS, &q);
+}
+
+bool gemm_f32x3_wanted(const GemmArgs& a) {            // (one geometry computation: this runs on the launch path)
+    return a.Wp3 && a.H > 0 && a.W > 0 && a.M % (a.H * a.W) == 0 && x3_big_enough(a.M / (a.H * a.W), a.H, a.W, a.Cin, a.N) && gemm_f32x3_ok(a);
 }
 
 struct X3GroupArgs {
