@@ -84,6 +84,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-plan", action="store_true", help="skip the extra measurement of the fp32-pipe plan (`fp32_pipe_plan` in the line)")
     ap.add_argument("--no-f32x3", action="store_true", help="fp32 runs: 3x3 convs on the Winograd kernels at every batch (CAPF_PLAN_NO_F32X3: round 3's plan) instead of the split-fp32 tile")
+    ap.add_argument("--x3-exact", action="store_true", help="fp32 runs: round 4's exact three-bf16-piece tile (six piece products, CAPF_PLAN_F32X3_EXACT) instead of the "
+                    "two-fp16-piece tile (three)")
     ap.add_argument("--lifter-fp32", action="store_true", help="bf16 runs: lifter projections on the fp32 kernels (CAPF_PLAN_LIFTER_FP32)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
@@ -118,7 +120,13 @@ def config_tag(a):
 
 def workload_string(a, tag):
     head = f"configs[{tag}]" if tag is not None else "custom (not a BASELINE.json configuration)"
-    arith = ("fp32 MFMA" if a.dtype == "f32" else
+    arith = (("fp32 tensors, fp32 accumulation; 3x3 stride-1 convs from batch 6: " +
+              ("fp32 matrix pipe (Winograd / direct; CAPF_PLAN_NO_F32X3)" if getattr(a, "no_f32x3", False) else
+               "each operand split exactly into three bf16 pieces, six piece products on the bf16 matrix pipe (CAPF_PLAN_F32X3_EXACT)" if getattr(a, "x3_exact", False) else
+               "each operand as two fp16 pieces under exact power-of-two block scales (to 2^-23), three piece products on the 16-bit matrix pipe -- same "
+               "measured distance to fp64 as the direct fp32 MFMA kernel; Inf / NaN / |x| >= 1.5e23 give NaN (igemm_f32h2_ws); the exact-operand and "
+               "fp32-pipe plans are timed on the same line (exact_split_plan, fp32_pipe_plan)") +
+              "; every other conv / GEMM: fp32 MFMA") if a.dtype == "f32" else
              "bf16 MFMA operands, fp32 accumulate (backbone convs; lifter GEMMs fp32: --lifter-fp32)" if getattr(a, "lifter_fp32", False) else
              "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)")
     if a.train:
@@ -140,9 +148,9 @@ def respawn_under_torchrun(a):
     return subprocess.call(cmd, env=env)
 
 
-def vs_fp32_oracle(backbone, sd_cpu, img, k2d, kc, got):
+def vs_fp32_oracle(backbone, sd_cpu, img, k2d, kc, got, others=None):
     """The timed step's output against the fp32 CPU oracle on four of the run's own frames (the oracle is the checker here, as in
-    smoke(); part of the cpu_baseline leg)."""
+    smoke(); part of the cpu_baseline leg).  `others`: outputs of the same step on the alternative plans, held to the same frames."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import capf_oracle as oracle
@@ -152,8 +160,12 @@ def vs_fp32_oracle(backbone, sd_cpu, img, k2d, kc, got):
     with torch.no_grad():
         want = oracle.ca_pf_forward(sd_cpu, img[idx].cpu(), k2d[idx].cpu(), kc[idx].cpu().clone(), backbone=backbone)
     d = got[idx].cpu().float() - want
-    return {"frames": idx, "max_abs": float(d.abs().max()), "mean_joint_dist": float(d.norm(dim=-1).mean()), "unit": "m",
-            "reference": "oracle/capf_oracle.py, fp32 (pinned to the reference's outputs, tests/golden)"}
+    res = {"frames": idx, "max_abs": float(d.abs().max()), "mean_joint_dist": float(d.norm(dim=-1).mean()), "unit": "m",
+           "reference": "oracle/capf_oracle.py, fp32 (pinned to the reference's outputs, tests/golden)"}
+    for key, o in (others or {}).items():
+        dd = o[idx].cpu().float() - want
+        res[key] = {"max_abs": float(dd.abs().max()), "mean_joint_dist": float(dd.norm(dim=-1).mean())}
+    return res
 
 
 def cpu_baseline(backbone, H, W, sd_cpu, budget_s=24.0):
@@ -273,10 +285,12 @@ def main():
     cfg.model.poseformer.embed_dim_ratio = a.embed
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        from capf.lib import PLAN_LIFTER_FP32, PLAN_NO_F32X3
+        from capf.lib import PLAN_F32X3_EXACT, PLAN_LIFTER_FP32, PLAN_NO_F32X3
         pflags = PLAN_LIFTER_FP32 if (a.lifter_fp32 and a.dtype == "bf16") else 0
         if a.no_f32x3:
             pflags |= PLAN_NO_F32X3
+        if a.x3_exact and a.dtype != "bf16":
+            pflags |= PLAN_F32X3_EXACT
         model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
     sd_cpu = synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.to(dev)
@@ -398,39 +412,41 @@ def main():
                 torch.cuda.synchronize(dev)
         return overlapped
 
-    def measure_fp32_pipe_plan():
-        # ---- fp32 configurations: the same K steps on round 3's plan (CAPF_PLAN_NO_F32X3: the 3x3 convs on the fp32 matrix pipe -- Winograd /
-        # direct kernels -- instead of the split-fp32 tile on the bf16 pipe), so that both arithmetic routes are on one line; never `value`
-        fp32_pipe_plan = None
-        if not a.train and world == 1 and a.dtype != "bf16" and not a.no_f32x3 and not a.no_alt_plan:
-            try:
-                from capf.lib import PLAN_NO_F32X3 as _NOX3
-                with contextlib.redirect_stdout(io.StringIO()):
-                    m3 = CA_PF(cfg, compute_dtype="fp32", plan_flags=pflags | _NOX3).eval()
-                m3.load_state_dict(sd_cpu)
-                m3 = m3.to(dev)
-                if a.lanes >= 0:
-                    m3.engine_for(img).set_lanes(a.lanes)
-                kc3 = kc0.clone()
-                with torch.no_grad():
-                    for _ in range(max(a.warmup, 2)):
-                        kc3.copy_(kc0)
-                        o3 = m3(img, k2d, kc3)
-                    torch.cuda.synchronize(dev)
-                    t3 = time.perf_counter()
-                    for _ in range(a.steps):
-                        kc3.copy_(kc0)
-                        o3 = m3(img, k2d, kc3)
-                    torch.cuda.synchronize(dev)
-                    el3 = time.perf_counter() - t3
-                fp32_pipe_plan = {"value": round(B * a.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / a.steps * 1e3, 4), "steps": a.steps,
-                                  "max_abs_diff_to_contract_step": float((o3 - out).abs().max()),
-                                  "note": "plan_flags |= CAPF_PLAN_NO_F32X3: 3x3 convs on the fp32 matrix pipe (Winograd from batch 24, direct below); not the headline"}
-                del m3, o3
-            except Exception as e:
-                fp32_pipe_plan = {"error": f"{type(e).__name__}: {e}"[:300]}
+    alt_outputs = {}
+
+    def measure_alt_plan(flag, key, note):
+        # ---- fp32 configurations: the same K steps on another arithmetic route for the 3x3 convs, so that all of them are on one line (never `value`):
+        # CAPF_PLAN_NO_F32X3 = round 3's plan, the fp32 matrix pipe (Winograd / direct kernels); CAPF_PLAN_F32X3_EXACT = round 4's plan, the
+        # exact three-bf16-piece tile (six piece products per fp32 product where the product plan issues three)
+        if a.train or world != 1 or a.dtype == "bf16" or a.no_f32x3 or a.no_alt_plan or (pflags & flag):
+            return None
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                m3 = CA_PF(cfg, compute_dtype="fp32", plan_flags=(pflags & ~PLAN_F32X3_EXACT) | flag).eval()
+            m3.load_state_dict(sd_cpu)
+            m3 = m3.to(dev)
+            if a.lanes >= 0:
+                m3.engine_for(img).set_lanes(a.lanes)
+            kc3 = kc0.clone()
+            with torch.no_grad():
+                for _ in range(max(a.warmup, 2)):
+                    kc3.copy_(kc0)
+                    o3 = m3(img, k2d, kc3)
                 torch.cuda.synchronize(dev)
-        return fp32_pipe_plan
+                t3 = time.perf_counter()
+                for _ in range(a.steps):
+                    kc3.copy_(kc0)
+                    o3 = m3(img, k2d, kc3)
+                torch.cuda.synchronize(dev)
+                el3 = time.perf_counter() - t3
+            alt_outputs[key] = o3.clone()
+            res = {"value": round(B * a.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / a.steps * 1e3, 4), "steps": a.steps,
+                   "max_abs_diff_to_contract_step": float((o3 - out).abs().max()), "note": note}
+            del m3, o3
+            return res
+        except Exception as e:                                 # an extra measurement must never cost the contract's line
+            torch.cuda.synchronize(dev)
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
 
     dist_info = None
     if world > 1:
@@ -485,7 +501,7 @@ def main():
                         kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh", "igemm_bf16_group_ws")[max(0, variants[l])] if kern.startswith("igemm_bf16")
                                 else ("igemm_wino43_group" if kern.startswith("igemm_wino43") else
                                       "igemm_wino_group" if kern.startswith("igemm_wino") else
-                                      kern if kern.startswith(("igemm_f32_pwchain", "igemm_f32x3")) else "igemm_f32_group"))
+                                      kern if kern.startswith(("igemm_f32_pwchain", "igemm_f32x3", "igemm_f32h2")) else "igemm_f32_group"))
                         if table[l][1].startswith("igemm_bf16_pwchain"):
                             kern = table[l][1]
                     if not kern or table[l][0].startswith("copy."):
@@ -506,11 +522,13 @@ def main():
         peak = PEAK_TFLOPS[a.dtype]
         # The split-fp32 tile (igemm_f32x3_ws.hip) computes fp32 results on the bf16 pipe with six piece products per fp32 product: its
         # roof in ALGORITHMIC fp32 FLOP/s is the bf16 peak / 6, so that frac = executed bf16 FLOP/s / bf16 peak = the pipe's busy fraction
-        x3 = dname.startswith("igemm_f32x3")
-        dpeak = round(PEAK_TFLOPS["bf16"] / 6.0, 1) if x3 else peak
-        pipe_peak = lambda k: PEAK_TFLOPS["bf16"] if k.startswith(("igemm_f32x3", "igemm_bf16")) else peak     # executed FLOPs are priced on the pipe they ran on
+        # ... the two-fp16-piece tile (igemm_f32h2_ws.hip) issues three: bf16 / fp16 peak / 3
+        x3 = dname.startswith(("igemm_f32x3", "igemm_f32h2"))
+        pieces = lambda k: 6.0 if k.startswith("igemm_f32x3") else 3.0
+        dpeak = round(PEAK_TFLOPS["bf16"] / pieces(dname), 1) if x3 else peak
+        pipe_peak = lambda k: PEAK_TFLOPS["bf16"] if k.startswith(("igemm_f32x3", "igemm_f32h2", "igemm_bf16")) else peak     # executed FLOPs are priced on the pipe they ran on
         gemm_busy = sum(e[4] / pipe_peak(k) for k, e in acc.items() if k.startswith("igemm")) / 1e12
-        alg_peak = lambda k: PEAK_TFLOPS["bf16"] / 6.0 if k.startswith("igemm_f32x3") else peak                 # roof of a kernel in algorithmic FLOP/s
+        alg_peak = lambda k: PEAK_TFLOPS["bf16"] / pieces(k) if k.startswith(("igemm_f32x3", "igemm_f32h2")) else peak          # roof of a kernel in algorithmic FLOP/s
         gemm_alg = sum(e[1] / alg_peak(k) for k, e in acc.items() if k.startswith("igemm")) / 1e12
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
         # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
@@ -527,7 +545,9 @@ def main():
         mfma = {"bound": "mfma", "achieved": round(tflops, 2), "peak": dpeak, "unit": "TFLOP/s", "frac": round(tflops / dpeak, 4)}
         if x3:
             mfma["peak_note"] = ("fp32 results on the bf16 matrix pipe: each fp32 operand = three bf16 pieces (exact), six piece products per fp32 product; "
-                                 "peak = 2500 TFLOP/s dense bf16 / 6")
+                                 "peak = 2500 TFLOP/s dense bf16 / 6" if dname.startswith("igemm_f32x3") else
+                                 "fp32 results on the fp16 matrix pipe: each fp32 operand = two block-scaled fp16 pieces (to 2^-23), three piece products per "
+                                 "fp32 product; peak = 2500 TFLOP/s dense fp16 / 3, so frac = executed fp16 FLOP/s / the fp16 peak")
         hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         first, second = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
         roofline = dict(first)
@@ -559,7 +579,10 @@ def main():
                 print(f"  {k:34s} {e[2] // nprof:4d} launches/step {e[0] / nprof:9.3f} ms/step {tf:8.2f} TFLOP/s(alg) {ex:8.2f} TFLOP/s(exec) "
                       f"{gb:8.1f} GB/s(alg)", file=sys.stderr)
         overlapped = measure_overlapped()                     # (extra measurements run after the per-launch timing passes: they leave the chip warm)
-        fp32_pipe_plan = measure_fp32_pipe_plan()
+        exact_split_plan = measure_alt_plan(PLAN_F32X3_EXACT, "exact_split_plan", "plan_flags |= CAPF_PLAN_F32X3_EXACT: the 3x3 convs on round 4's tile -- every operand "
+                                            "split EXACTLY into three bf16 pieces, six piece products per fp32 product; not the headline")
+        fp32_pipe_plan = measure_alt_plan(PLAN_NO_F32X3, "fp32_pipe_plan", "plan_flags |= CAPF_PLAN_NO_F32X3: 3x3 convs on the fp32 matrix pipe (Winograd from batch 24, direct below); "
+                                          "not the headline")
         launches, flops = eng.stats(B)
         par = f"dp{world} (independent frames, " + ("one flat-gradient all-reduce per step)" if a.train else "no collective)")
         result = {
@@ -576,13 +599,15 @@ def main():
             result["distributed"] = dist_info
         if overlapped is not None:
             result["overlapped_steps"] = overlapped
+        if exact_split_plan is not None:
+            result["exact_split_plan"] = exact_split_plan
         if fp32_pipe_plan is not None:
             result["fp32_pipe_plan"] = fp32_pipe_plan
         if train_phases is not None:
             result["train_phases"] = train_phases
         if world == 1 and not a.no_cpu_baseline:
             if not a.train:
-                result["vs_fp32_oracle"] = vs_fp32_oracle(a.backbone, sd_cpu, img, k2d, kc0, out)
+                result["vs_fp32_oracle"] = vs_fp32_oracle(a.backbone, sd_cpu, img, k2d, kc0, out, alt_outputs)
             result["cpu_baseline"] = cpu_baseline(a.backbone, H, W, sd_cpu)
             result["gpu_over_cpu"] = round(fps / result["cpu_baseline"]["value"], 1)
     if world > 1:

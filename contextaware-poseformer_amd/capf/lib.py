@@ -8,7 +8,8 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
-PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3 = 1, 2, 4, 8, 16, 32, 64, 128     # capf_plan_flag
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT = 1, 2, 4, 8, 16, 32, 64, 128, 256     # capf_plan_flag
+ABI_VERSION = 5        # include/capf.h :: CAPF_ABI_VERSION (checked against capf_abi_version() at load)
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
@@ -21,6 +22,8 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_forward_prefix", "capf_op_describe", "capf_op_tensor",
     "capf_op_conv_bf16_ws_pack_elems", "capf_op_pack_conv_bf16_ws", "capf_op_conv_bf16_ws_group",
     "capf_op_conv_f32x3_pack_elems", "capf_op_pack_conv_f32x3", "capf_op_conv_f32x3_group",
+    "capf_op_conv_f32h2_pack_elems", "capf_op_pack_conv_f32h2", "capf_op_conv_f32h2_group",
+    "capf_abi_version", "capf_op_describe_sized",
 ]
 
 
@@ -61,6 +64,11 @@ def load_library():
         raise CapfError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                         "(or make -C contextaware-poseformer_amd/csrc); there is no fallback path")
     lib = ctypes.CDLL(LIB_PATH)
+    # structs cross this boundary (CapfConfig, ConvDesc, OpDesc): a library built from another revision of capf.h must not be driven
+    # with this file's layouts
+    abi = lib.capf_abi_version() if hasattr(lib, "capf_abi_version") else None
+    if abi != ABI_VERSION:
+        raise CapfError(f"{LIB_PATH} implements ABI revision {abi}, this binding expects {ABI_VERSION}: rebuild the library")
     H = c_void_p
     lib.capf_create.argtypes = [POINTER(CapfConfig), c_int, POINTER(H)]
     lib.capf_create.restype = c_int
@@ -91,6 +99,7 @@ def load_library():
     lib.capf_op_executed_flops.argtypes = [H, c_int, c_int, POINTER(c_double)]
     lib.capf_forward_prefix.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]
     lib.capf_op_describe.argtypes = [H, c_int, POINTER(OpDesc)]
+    lib.capf_op_describe_sized.argtypes = [H, c_int, c_void_p, c_size_t]
     lib.capf_op_tensor.argtypes = [H, c_int, c_int, POINTER(c_void_p)]
     lib.capf_forward_profile.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          POINTER(c_float), c_int]
@@ -125,6 +134,9 @@ def load_library():
     lib.capf_op_conv_f32x3_pack_elems.argtypes = [c_int, c_int]
     lib.capf_op_conv_f32x3_pack_elems.restype = c_int64
     lib.capf_op_pack_conv_f32x3.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
+    lib.capf_op_conv_f32h2_pack_elems.argtypes = [c_int, c_int]
+    lib.capf_op_conv_f32h2_pack_elems.restype = c_int64
+    lib.capf_op_pack_conv_f32h2.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
     lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -331,7 +343,7 @@ class Engine:
 
     def op_describe(self, index):
         d = OpDesc()
-        self._check(self.lib.capf_op_describe(self.h, index, byref(d)), "op_describe")
+        self._check(self.lib.capf_op_describe_sized(self.h, index, byref(d), ctypes.sizeof(d)), "op_describe")
         return d
 
     def op_tensor(self, index, slot, shape, dtype_code):
@@ -662,6 +674,47 @@ def conv_nhwc_f32x3_group(problems):
     rc = lib.capf_op_conv_f32x3_group(_stream(problems[0][0]), n, descs)
     if rc:
         raise CapfError(f"capf_op_conv_f32x3_group failed ({rc})")
+    return outs
+
+
+def pack_conv_f32h2(w, bn=None, eps=1e-5):
+    """3x3 weights for the default split-fp32 conv tile (csrc/igemm_f32h2_ws.hip) -> (packed [elems] int16: two fp16 pieces per weight under
+    one power-of-two scale per output channel, then the fp32 inverse scales; fp32 bias [Cout])."""
+    import torch
+    lib = load_library()
+    co, ci, ks, _ = w.shape
+    n = lib.capf_op_conv_f32h2_pack_elems(co, ci)
+    if ks != 3 or n <= 0 or co % 4:
+        raise CapfError(f"split-fp32 conv needs a 3x3 kernel, Cin % 16 == 0 and Cout % 4 == 0 (got ks={ks}, Cin={ci}, Cout={co})")
+    wp = torch.empty(n, device=w.device, dtype=torch.int16)
+    bias = torch.empty(co, device=w.device)
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    rc = lib.capf_op_pack_conv_f32h2(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), co, ci)
+    if rc:
+        raise CapfError(f"capf_op_pack_conv_f32h2 failed ({rc})")
+    return wp, bias
+
+
+def conv_nhwc_f32h2_group(problems):
+    """problems: list of (x, wp_h2, bias, act, residual, Cout), x / residual fp32 NHWC -> list of fp32 outputs (the level's launches of the
+    two-fp16-piece tile, 3x3 / stride 1 / pad 1)."""
+    import torch
+    lib = load_library()
+    n = len(problems)
+    descs = (ConvDesc * n)()
+    outs = []
+    for i, (x, wp, bias, act, res, co) in enumerate(problems):
+        B, H, W, ci = x.shape
+        y = torch.empty(B, H, W, co, device=x.device, dtype=torch.float32)
+        outs.append(y)
+        d = descs[i]
+        d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
+        d.residual = res.data_ptr() if res is not None else None
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, co, 3, 1, act
+    lib.capf_op_conv_f32h2_group.argtypes = [c_void_p, c_int, POINTER(ConvDesc)]
+    rc = lib.capf_op_conv_f32h2_group(_stream(problems[0][0]), n, descs)
+    if rc:
+        raise CapfError(f"capf_op_conv_f32h2_group failed ({rc})")
     return outs
 
 

@@ -48,8 +48,9 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                      params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w2_off, B, pk.N, pk.Cin, pk.ks, pk.Kpad2, s));
             if (pk.x3)
-                HIP_TRY(launch_pack_conv_f32x3(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
-                                               params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w3_off, B, pk.N, pk.Cin, s));
+                HIP_TRY((x3_h2 ? launch_pack_conv_f32h2 : launch_pack_conv_f32x3)(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
+                                                                                  params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f,
+                                                                                  pack_arena + pk.w3_off, B, pk.N, pk.Cin, s));
         } else if (pk.kind == 0) {
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr,
                                      params[pk.bn_m].ptr, params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, pk.ks,
@@ -104,6 +105,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.N = op.N; a.K = op.K; a.Kpad = pk.Kpad;
     if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
     if (pk.ws || pk.x3) a.Wp3 = pack_arena + pk.w3_off;
+    a.x3_h2 = pk.x3 && x3_h2;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
@@ -413,7 +415,8 @@ static std::string g_create_error;
 
 extern "C" {
 
-const char* capf_version(void) { return "capf 0.1 (gfx950)"; }
+const char* capf_version(void) { return "capf 0.5 (gfx950)"; }
+int capf_abi_version(void) { return CAPF_ABI_VERSION; }
 
 const char* capf_last_error(const capf_handle* h) { return h ? h->e.err.c_str() : g_create_error.c_str(); }
 
@@ -432,7 +435,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~255) {
+    if (cfg->plan_flags & ~511) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -896,6 +899,40 @@ int capf_op_conv_f32x3_group(void* stream, int n, const capf_conv_desc* d) {
     return capf::launch_gemm_f32x3_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int64_t capf_op_conv_f32h2_pack_elems(int Cout, int Cin) { return Cin % 16 == 0 && Cout > 0 ? capf::f32h2_pack_elems(Cout, Cin) : 0; }
+
+int capf_op_pack_conv_f32h2(void* stream, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                            float eps, void* wp, float* bias, int Cout, int Cin) {
+    if (!w || !wp || Cin % 16 != 0 || Cout % 4 != 0) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_pack_conv_f32h2(w, gamma, beta, mean, var, eps, wp, bias, Cout, Cin, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* d) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i) {
+        if (d[i].ks != 3 || d[i].stride != 1) return CAPF_ERR_UNSUPPORTED;
+        g[i] = capf::GemmArgs{};
+        g[i].A = static_cast<const float*>(d[i].x);
+        g[i].Wp3 = static_cast<const float*>(d[i].w_packed);
+        g[i].x3_h2 = 1;
+        g[i].bias = d[i].bias;
+        g[i].res = static_cast<const float*>(d[i].residual);
+        g[i].out = static_cast<float*>(d[i].y);
+        g[i].M = d[i].B * d[i].H * d[i].W;
+        g[i].N = d[i].Cout; g[i].K = 9 * d[i].Cin;
+        g[i].conv = 1;
+        g[i].Cin = d[i].Cin; g[i].H = d[i].H; g[i].W = d[i].W; g[i].Ho = d[i].H; g[i].Wo = d[i].W;
+        g[i].ks = 3; g[i].stride = 1; g[i].pad = 1;
+        g[i].omap = capf::row_ld(d[i].Cout);
+        g[i].rmap = capf::row_ld(d[i].Cout);
+        g[i].act = d[i].act;
+        if (!capf::gemm_f32x3_ok(g[i])) return CAPF_ERR_UNSUPPORTED;
+    }
+    return capf::launch_gemm_f32h2_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* d, const void* const* w_rh, int32_t* variant) {
     if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
     capf::GemmArgs g[capf::MAXG];
@@ -1011,7 +1048,7 @@ int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* f
     const capf::Pack& pk = e.packs[op.pack];
     const double MN = 2.0 * (double)op.rows_per_frame * batch * op.N;
     if (op.conv && e.wino_now(op, batch) && pk.x3 && capf::gemm_f32x3_wanted(e.gemm_args(op, batch)))
-        *flops = 6.0 * MN * op.K;                                  // split-fp32 tile: six bf16 piece products per fp32 product, on the bf16 pipe
+        *flops = (e.x3_h2 ? 3.0 : 6.0) * MN * op.K;               // split-fp32 tiles: three fp16 / six bf16 piece products per fp32 product, on the 16-bit pipe
     else if (op.conv && e.wino_now(op, batch)) *flops = MN * op.Cin * (pk.Kpad == 18 * pk.Cin ? 4.5 : 6.0);
     else if (op.wino) *flops = MN * pk.Kpad2;                      // small batch: the direct kernel on the direct layout
     else if (pk.rh && op.conv) *flops = MN * op.K;                 // row-halo layout has no K padding (decided per launch; lower bound)
@@ -1185,6 +1222,16 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
         if (op.kind == capf::OP_FUSE) { d->Ho = op.H; d->Wo = op.W; }
     }
     d->checkpoint = (op.region >= 0 ? e.regions[op.region].second : index) + 1;
+    return CAPF_OK;
+}
+
+int capf_op_describe_sized(const capf_handle* h, int index, void* desc, size_t desc_bytes) {
+    if (!desc || desc_bytes == 0) return CAPF_ERR_INVALID;
+    capf_op_desc full;
+    const int rc = capf_op_describe(h, index, &full);
+    if (rc != CAPF_OK) return rc;
+    memset(desc, 0, desc_bytes);
+    memcpy(desc, &full, desc_bytes < sizeof(full) ? desc_bytes : sizeof(full));
     return CAPF_OK;
 }
 

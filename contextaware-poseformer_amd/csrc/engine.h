@@ -56,7 +56,8 @@ struct Pack {
     bool bf16 = false;             // conv weights packed as bf16 (Kpad % 64 == 0)
     bool rh = false;               // bf16 3x3 stride-1 conv: a second copy in the row-halo layout ([N][9 * Cin] bf16) at w2_off
     bool ws = false;               // bf16 3x3 stride-1 conv: a copy in the 2-D halo tile's layout (igemm_bf16_ws.hip) at w3_off
-    bool x3 = false;               // fp32 3x3 stride-1 conv: a copy as three bf16 pieces (igemm_f32x3_ws.hip) at w3_off
+    bool x3 = false;               // fp32 3x3 stride-1 conv: a copy for the split-fp32 tiles at w3_off -- two block-scaled fp16 pieces
+                                   // (igemm_f32h2_ws.hip; Engine::x3_h2) or three bf16 pieces (igemm_f32x3_ws.hip)
     size_t w3_off = 0;
     bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
 };
@@ -96,6 +97,7 @@ struct Op {
     double flops_per_frame = 0.0;
     int bf16 = 0;                 // tensors of this op are bf16 (conv: bf16 MFMA kernel)
     int wino = 0;                 // 3x3 stride-1 fp32 conv on the Winograd kernel (igemm_wino.hip)
+    int x3_lo = 0, x3_hi = -1;    // batches [x3_lo, x3_hi] at which a split-fp32 tile takes this conv (f32x3_takes; set by build(), empty = never)
     int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
     int region = -1;              // index of the enclosing fork/join region, -1 outside
@@ -178,25 +180,19 @@ struct Engine {
     bool debug = false;            // run the debug-copy ops (capf_set_debug)
     int wino_min_batch = 24;       // below this batch the Winograd-eligible convs the split-fp32 tile does not take run the direct kernel (with
                                    // split-K; batch 16: 4.75 vs 5.86 ms per forward, batch 24: 6.08 vs 6.37)
-    // does the conv leave the direct kernel (for the split-fp32 tile or a Winograd kernel: launch_gemm_wino decides which) at this batch?
-    // (asked several times per conv and launch: the answer for the current batch is kept per op)
+    // does the conv leave the direct kernel (for a split-fp32 tile or a Winograd kernel: launch_gemm_wino decides which) at this batch?
+    // A pure function of the op and the batch: the tile's batch range is precomputed per op by build() (no cache, no mutable state --
+    // const-handle queries on other threads may ask while a forward is being enqueued)
     bool wino_now(const Op& op, int batch) const {
-        if (!op.wino) return false;
-        const size_t i = (size_t)(&op - ops.data());
-        if (batch != wn_batch || wn_cache.size() != ops.size()) { wn_cache.assign(ops.size(), (signed char)-1); wn_batch = batch; }
-        if (i < wn_cache.size() && wn_cache[i] >= 0) return wn_cache[i] != 0;
-        const bool yes = (packs[op.pack].x3 && f32x3_takes(batch, op.H, op.W, op.Cin, op.N)) || batch >= wino_min_batch;
-        if (i < wn_cache.size()) wn_cache[i] = yes ? 1 : 0;
-        return yes;
+        return op.wino && ((batch >= op.x3_lo && batch <= op.x3_hi) || batch >= wino_min_batch);
     }
-    mutable std::vector<signed char> wn_cache;
-    mutable int wn_batch = -1;
     bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels
     bool wino_f43 = true;          // plan: F(4,3) where W % 4 == 0, F(2,3) for the other even widths (CAPF_WINO_F43=0: F(2,3) everywhere, A/B runs)
     std::vector<int> last_variants;   // capf_forward_profile_launches: grouped-bf16 kernel variant per leader op
     bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
     bool use_x3 = true;            // plan: split-fp32 tile for the Winograd-eligible fp32 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_F32X3 clears it)
+    bool x3_h2 = true;             // ... the two-fp16-piece tile (three piece products per MAC); plan_flags & CAPF_PLAN_F32X3_EXACT: the three-bf16-piece tile (six)
     bool use_ws = true;            // plan: 2-D halo layout + kernel for the bf16 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_WS clears it)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)
     bool fused_lifter = true;      // plan: fused embed / context-attention kernels + LayerNorm folded into the GEMMs (CAPF_LIFTER_FUSED=0: the one-kernel-per-op plan, for A/B runs)

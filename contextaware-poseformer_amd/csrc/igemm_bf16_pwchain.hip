@@ -245,8 +245,8 @@ hipError_t launch_gemm_bf16_pwchain(const GemmArgs& a, const GemmArgs& b, hipStr
     if (!gemm_bf16_pwchain_ok(a, b)) return hipErrorInvalidValue;
     const int ntiles = (a.M + 31) / 32;
     constexpr size_t lds_bytes = (size_t)(256 * 64 + 64 * 256) * 2 + (size_t)(256 + 64 + 4 * 32 * 36) * 4;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_pwchain_kernel<64, 256, 64>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static DynLdsAttr attr_once;
+    const hipError_t attr = attr_once.ensure(reinterpret_cast<const void*>(&igemm_bf16_pwchain_kernel<64, 256, 64>), (int)lds_bytes);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((igemm_bf16_pwchain_kernel<64, 256, 64>), dim3(256), dim3(256), lds_bytes, s, a, b, ntiles);
     return hipGetLastError();

@@ -114,8 +114,8 @@ hipError_t launch_gemm_bf16_ws_group(const GemmArgs* list, int n, hipStream_t s)
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
     const size_t lds_bytes = 2 * (size_t)ws_stage_bytes(max_ns);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_group_ws_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ws_stage_bytes(96));
+    static DynLdsAttr attr_once;
+    const hipError_t attr = attr_once.ensure(reinterpret_cast<const void*>(&igemm_bf16_group_ws_kernel), 2 * ws_stage_bytes(96));
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(igemm_bf16_group_ws_kernel, dim3(start), dim3(256), lds_bytes, s, ga);
     return hipGetLastError();

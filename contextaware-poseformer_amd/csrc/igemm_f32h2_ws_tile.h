@@ -1,0 +1,383 @@
+// fp32 3x3 / stride-1 / pad-1 convolution on the 16-bit matrix pipe with HALF the MFMAs of igemm_f32x3_ws_tile.h: every fp32 operand is
+// carried as TWO fp16 pieces under an exact power-of-two block scale, three piece products per fp32 MAC (BasicBlock convs of HRNet,
+// pose_hrnet.py:66-95, under compute_dtype = fp32).
+//
+// Why: the three-bf16-piece tile runs against the board's power limit -- the only lever left is fewer MFMAs per result.
+// With s a power of two such that |s a| < 2^15:  a1 = fp16(s a),  a2 = fp16(s a - a1)  (the remainder is exact in fp32), and
+//     |s a - a1 - a2| <= 2^-23 |s a|          (11 + 11 mantissa bits and the sign of the remainder; fp32 carries 24),
+// for every |s a| >= 2^-3; below that the second piece is an fp16 denormal and the error is at most 2^-25 ABSOLUTE, i.e. 2^-39 of
+// the block's largest value.  Products of fp16 numbers are exact in the pipe's fp32 accumulator.  Of the four piece products
+//     a1 w1 + (a1 w2 + a2 w1)                  dropped: a2 w2 <= 2^-22 |a w|
+// so one term is off by at most 2^-21 of itself (rms ~1e-7), which over the K = 9 Cin terms of a dot product is BELOW the fp32
+// accumulation error any fp32 GEMM has: on random operands 6e-9 of the sum of |terms| rms before accumulation (a pairwise fp32
+// sum of exact products: 8e-9; the three-bf16 tile: 5e-10; both drown in the MFMA's own fp32 accumulation, ~1e-7).  Not exact-
+// operand arithmetic like the three-piece tile (which stays in the library: CAPF_PLAN_F32X3_EXACT), but the same measured distance
+// to an fp64 evaluation as this library's direct fp32 MFMA kernel (tests/test_gpu_ops.py::test_f32h2_*).
+//
+// The scales.  Weights: one power of two per output channel, chosen at pack time (max |w| of the channel's folded filter ->
+// [2^14, 2^15)); its inverse comes back in the epilogue.  Pixels: one power of two per BLOCK AND CHUNK -- the 16 channels x (halo
+// tile) values a block stages at a time -- from their maximum: every lane takes the max of what it loaded, DPP + readlane reduce it
+// per wave, the four wave maxima cross through 16 bytes of LDS under the barrier the stage hand-over needs anyway; the accumulators
+// are rescaled (exact: a power of two) whenever the scale changes between chunks, and 1 / scale of the last chunk goes into the
+// epilogue's multiplier.  Nothing outside the kernel knows about any of this: tensors in HBM are plain fp32 NHWC.
+//
+// Tile: igemm_f32x3_ws_tile.h's (256 output pixels x 32 TN channels, accumulators resident for the whole K, 16-channel chunks with
+// a 1-pixel halo staged once for all nine taps, pixels through registers, weights by LDS-DMA, half-plane LDS image with the
+// conflict-free pixel -> MFMA column deal), with two planes instead of three: 26 KiB of pixels + 18 TN KiB of weights --
+// THREE blocks per CU at TN = 1 (the three-piece tile: two), so that a block's split phase between its two barriers is covered by
+// two others' MFMAs; 6 VALU instructions per pair of values instead of 11; 4 + 2 TN fragment reads feed 6 TN MFMAs per tap.
+#pragma once
+#include "igemm_bf16_ws_tile.h"
+
+namespace capf {
+
+static constexpr int H2_A_BYTES = 2 * WS_A_BYTES;
+static constexpr int H2_AUX_BYTES = 16 + 2 * 64 * 4;        // the four wave maxima of the chunk being split; the slice's inverse weight scales and biases
+inline constexpr int h2_w_bytes(int NS) { return 2 * 9 * NS * 32; }
+inline constexpr int h2_lds_bytes(int NS) { return H2_A_BYTES + h2_w_bytes(NS) + H2_AUX_BYTES; }
+
+struct H2Problem {
+    WsProblem g;                  // geometry (g.x / g.res / g.y unused; g.wp = packed pieces, g.bias)
+    const float* x;               // [B][H][W][C] fp32
+    const float* res;             // [M][ldr] fp32 or nullptr
+    float* y;                     // [M][ldy] fp32
+    const float* winv;            // [ceil(N / 32) * 32] 1 / (the channel's weight scale)
+};
+
+// packed weights: [32-channel slice][C / 16][piece 2][tap 9][32][2 swizzled halves][8] fp16, then [slices * 32] fp32 inverse scales.  One
+// layout for both tile widths: a 64-channel tile stages two neighbouring slices side by side
+inline long h2_piece_elems(int N, int C) { return (long)((N + 31) / 32) * (C / 16) * 2 * 9 * 32 * 16; }
+inline long h2_pack_elems(int N, int C) { return h2_piece_elems(N, C) + 2L * ((N + 31) / 32) * 32; }
+
+inline bool h2_plan(int B, int H, int W, int C, int N, int NS, H2Problem* q) {
+    if (N % 4 != 0 || (NS != 32 && NS != 64)) return false;
+    if ((double)B * H * W * C * 4.0 >= 2.0e9 || (double)B * H * W * N * 4.0 >= 2.0e9) return false;
+    if (!ws_plan(B, H, W, C, (N + 7) & ~7, &q->g)) return false;
+    q->g.N = N;
+    q->g.ldy = q->g.ldr = N;
+    q->g.NS = NS;
+    q->g.NSL = (N + NS - 1) / NS;
+    return true;
+}
+
+// biased exponent of the power-of-two scale for a block maximum with bit pattern `mbits` (>= 0): max * scale in [2^14, 2^15).  Kept within
+// 2^+-63, so that the scale, its inverse, the ratio of two scales and (1 / pixel scale) * (1 / weight scale) are all normal numbers:
+// maxima in [2^-49, 2^77) -- 1.8e-15 .. 1.5e23 -- get their exact scale; smaller ones keep 2^63 (precision relative to the maximum
+// degrades below 2^-49; everything below 2^-87 is zero), larger ones overflow fp16 (Inf, then NaN -- include/capf.h)
+inline __host__ __device__ int h2_scale_exp(int mbits) {
+    const int sb = 268 - (mbits >> 23);
+    return sb < 64 ? 64 : (sb > 190 ? 190 : sb);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+
+typedef _Float16 ws_f16x8 __attribute__((ext_vector_type(8)));
+
+// a pair of fp32 values, scaled by s (a power of two) -> the pair's two packed fp16 pieces
+__device__ __forceinline__ void h2_split2(float x, float y, float s, unsigned& p1, unsigned& p2) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = f2_t{x, y} * s;
+    const h2_t a = __builtin_convertvector(v, h2_t);
+    const f2_t r = v - __builtin_convertvector(a, f2_t);
+    const h2_t b = __builtin_convertvector(r, h2_t);
+    p1 = __builtin_bit_cast(unsigned, a);
+    p2 = __builtin_bit_cast(unsigned, b);
+}
+
+// maximum of a non-negative value over the wave (bit patterns of non-negative floats order like integers), wave-uniform
+__device__ __forceinline__ int h2_wave_max(float v) {
+    int x = __float_as_int(v);
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));     // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));     // row_mirror
+    return max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
+               max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+
+// one tile (logical id bid = pixel tile * NSL + channel slice) with the calling 256-thread block; lds: h2_lds_bytes(32 TN) bytes
+template <int TN>
+__device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const int bid, unsigned char* __restrict__ lds) {
+    constexpr int NS = 32 * TN;
+    constexpr int WP_BYTES = 9 * 32 * 32;                  // one piece of a 32-channel slice's chunk
+    constexpr int WS_BYTES = 2 * WP_BYTES;                 // a slice's chunk: 18 LDS-DMA instructions
+    constexpr int W2_BYTES = TN * WS_BYTES;                // the tile's chunk: TN slices side by side
+    constexpr int NWI = W2_BYTES / 1024;                   // weight DMA instructions per chunk: 18 TN
+    constexpr int NWS = (NWI + 3) / 4;                     // ... per wave
+    constexpr int NAU = 4;                                 // half-pixel units per lane and chunk (832 at most in all)
+    constexpr unsigned OOB = 0x80000000u;
+    const WsProblem& p = q.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int NCC = p.C >> 4;
+    const int tm = bid / p.NSL, slice = bid - tm * p.NSL;
+
+    const ws_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)q.x, 0, 0x7FFFFF00u, 0x00020000);
+    // ---- pixel units of this lane (igemm_f32x3_ws_tile.h): LDS image of a piece = two HALF-PLANES (channels 0-7 / 8-15 of the chunk),
+    // 16 B per staged pixel, pixel-linear; unit qi: lanes 8 k .. 8 k + 7 = eight consecutive pixels of one half
+    constexpr int HP = WS_MAX_PP * 16;                       // one half-plane; piece pc, half hf at (2 pc + hf) HP
+    static_assert(4 * HP == H2_A_BYTES, "plane layout");
+    unsigned a_voff[NAU], a_lds[NAU];
+    const int n_units = 2 * ((p.PP + 7) & ~7);
+    {
+        const int q0 = tm * p.G;
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            const int qi = min(j * 256 + tid, n_units - 1);  // (beyond the geometry: the last unit once more, same bytes same place)
+            const int half = (qi >> 3) & 1;
+            const int px = ((qi >> 4) << 3) | (qi & 7);
+            a_lds[j] = (unsigned)(half * HP + px * 16);
+            const int g = ws_div(px, p.d_segp), rem = px - g * p.SEGP;
+            const int rr = ws_div(rem, p.d_pw), ww = rem - rr * p.PW;
+            const int sg = q0 + g;
+            const int b = ws_div(sg, p.d_rgpi);
+            const int h = (sg - b * p.RGPI) * p.RH + rr - 1, col = ww - 1;
+            const bool ok = px < p.PP && sg < p.RG && h >= 0 && h < p.H && col >= 0 && col < p.W;
+            a_voff[j] = ok ? (unsigned)((((b * p.H + h) * p.W + col) * p.C + half * 8) * 4) : OOB;
+        }
+    }
+    ws_f32x4 ar[NAU][2];
+    auto load_a = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            ar[j][0] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], (unsigned)cc * 64u, 0));
+            ar[j][1] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j] + 16u, (unsigned)cc * 64u, 0));
+        }
+    };
+    int* const aux = reinterpret_cast<int*>(lds + H2_A_BYTES + W2_BYTES);
+    float* const aux_w = reinterpret_cast<float*>(aux + 4);      // [NS] 1 / weight scale of the slice's channels
+    float* const aux_b = aux_w + 64;                             // [NS] their biases
+    auto publish_max = [&]() {                             // this wave's maximum of the loaded chunk -> aux[wave]
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < NAU; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ar[j][k][e]));
+        const int wm = h2_wave_max(m);
+        if (lane == 0) aux[wave] = wm;
+    };
+    auto block_scale_exp = [&]() -> int {                  // (after the barrier behind publish_max)
+        const ws_u32x4 v = *reinterpret_cast<const ws_u32x4*>(aux);
+        const int m = max(max((int)v[0], (int)v[1]), max((int)v[2], (int)v[3]));
+        return __builtin_amdgcn_readfirstlane(h2_scale_exp(m));
+    };
+    auto split_a = [&](float s) {                          // the loaded chunk, scaled -> two fp16 planes
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            ws_u32x4 u1, u2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned s1, s2;
+                h2_split2(ar[j][k >> 1][2 * (k & 1)], ar[j][k >> 1][2 * (k & 1) + 1], s, s1, s2);
+                u1[k] = s1; u2[k] = s2;
+            }
+            *reinterpret_cast<ws_u32x4*>(lds + a_lds[j]) = u1;
+            *reinterpret_cast<ws_u32x4*>(lds + 2 * HP + a_lds[j]) = u2;
+        }
+    };
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const int nsl32 = (p.N + 31) >> 5;                     // (a 64-channel tile's second slice may not exist: its DMA reads zeros)
+    const ws_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wp + (size_t)slice * TN * NCC * (WS_BYTES / 2)), 0,
+                                                             (unsigned)(nsl32 - slice * TN) * (unsigned)NCC * (unsigned)WS_BYTES, 0x00020000);
+    auto fire_w = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NWS; ++i) {
+            const int k = min(i * 4 + wave, NWI - 1);
+            const int j = k / 18, rem = k - j * 18;        // slice j of the tile, instruction rem of its chunk
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (ws_lptr_t)(lds + H2_A_BYTES + k * 1024), 16, w_voff,
+                                                     (unsigned)(j * NCC + cc) * (unsigned)WS_BYTES + (unsigned)rem * 1024u, 0, 0);
+        }
+    };
+    load_a(0);
+    if (tid < NS) {
+        const int n = slice * NS + tid;
+        aux_w[tid] = n < ((p.N + 31) & ~31) ? q.winv[n] : 1.f;
+        aux_b[tid] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+
+    // ---- which tile pixel a lane's MFMA column is (igemm_f32x3_ws_tile.h): ds_read_b128 is served in lane groups {0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} (+ 32); a group costs one LDS cycle iff its 16 staged pixels are distinct mod 16
+    int pl_i[2];
+    {
+        const int in_g1 = (frow >= 4 && frow < 12) || (frow >= 16 && frow < 20) || frow >= 28;
+        const int pos = in_g1 ? (frow < 12 ? frow - 4 : (frow < 20 ? frow - 8 : frow - 16))
+                              : (frow < 4 ? frow : (frow < 16 ? frow - 8 : frow - 12));
+        if ((p.W & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pl_i[i] = ((2 * wave + i) * 2 + in_g1) * 16 + pos;
+        } else {
+            unsigned short* tab = reinterpret_cast<unsigned short*>(lds);            // [16 groups][16 classes]
+            unsigned short* ovf = tab + 256;
+            int* cnt = reinterpret_cast<int*>(lds + 1024);                           // [16] + overflow / empty counters
+            if (tid < 18) cnt[tid] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < p.P) {
+                const int g = ws_div(tid, p.d_rhw), rem = tid - g * p.RHW;
+                const int r = ws_div(rem, p.d_w), w = rem - r * p.W;
+                const int c = ((g * (p.RH + 2) + r) * p.PW + w) & 15;
+                const int rank = atomicAdd(&cnt[c], 1);
+                if (rank < 16) tab[rank * 16 + c] = (unsigned short)tid;
+                else ovf[atomicAdd(&cnt[16], 1)] = (unsigned short)tid;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if ((tid >> 4) >= cnt[tid & 15]) {                                      // an empty cell: an overflowed pixel, or idle
+                const int e = atomicAdd(&cnt[17], 1);
+                tab[tid] = e < cnt[16] ? ovf[e] : (unsigned short)0xFFFFu;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pl_i[i] = tab[((2 * wave + i) * 2 + in_g1) * 16 + pos];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                            // (the planes overwrite the table)
+        }
+    }
+    fire_w(0);                                              // (behind the table's last barrier: the DMA lands in the weight area only)
+    unsigned a_addr[2][3];                                  // pixel block i, filter row kh; kw and the piece are immediates
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int pl = pl_i[i];
+        if (pl >= p.P) { pl = 0; pl_i[i] = 0x7FFF; }         // (idle columns of a ragged geometry: computed, never stored)
+        const int g = ws_div(pl, p.d_rhw), rem = pl - g * p.RHW;
+        const int r = ws_div(rem, p.d_w), w = rem - r * p.W;
+        const int pix0 = (g * (p.RH + 2) + r) * p.PW + w;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) a_addr[i][kh] = (unsigned)((pix0 + kh * p.PW) * 16 + fhalf * HP);
+    }
+    const unsigned b_addr = (unsigned)(H2_A_BYTES + frow * 32 + ((fhalf ^ ((frow >> 3) & 1)) << 4));
+
+    const int Mi = (int)p.M;
+    const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(q.res ? (void*)q.res : (void*)q.y, 0, q.res ? 0x7FFFFF00u : 0u, 0x00020000);
+    const ws_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)q.y, 0, 0x7FFFFF00u, 0x00020000);
+    const int gp0 = tm * p.G * p.RHW;                      // first flat output pixel of the tile
+    // (weight piece, pixel piece) of the three products, smallest first
+    constexpr int PW_[3] = {0, 1, 0};
+    constexpr int PA_[3] = {1, 0, 0};
+
+    // ---- chunk 0: maximum -> scale -> split
+    publish_max();                                         // (the compiler waits for the pixel loads; the weight DMA may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int sb = block_scale_exp();
+    split_a(__int_as_float(sb << 23));
+
+    ws_f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (NCC > 1) load_a(1);
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue addressing: lane = 4 consecutive channels (register group g) of its pixel; the residual rows are requested before
+    // the last chunk's MFMAs
+    auto piece_off = [&](int i, int j, int g, int ld) -> unsigned {
+        const int pl = pl_i[i], n = slice * NS + j * 32 + 8 * g + 4 * fhalf;
+        const int gp = gp0 + pl;
+        return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(gp * ld + n) * 4u : OOB;
+    };
+    ws_f32x4 rr[2][TN][4];
+    ws_f16x8 af[2][2][2], bfr[2][2][TN];
+    for (int cc = 0; cc < NCC; ++cc) {
+        if (cc == NCC - 1) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        rr[i][j][g] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, g, p.ldr), 0, 0));
+        }
+        auto read_frags = [&](int t, int buf) {            // (in the order the products below consume them)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int pw = PW_[o], pa = PA_[o];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[buf][pw][j] = __builtin_bit_cast(ws_f16x8, *reinterpret_cast<const ws_f32x4*>(lds + b_addr + j * WS_BYTES + pw * WP_BYTES + t * 1024));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[buf][pa][i] = __builtin_bit_cast(ws_f16x8, *reinterpret_cast<const ws_f32x4*>(lds + pa * 2 * HP + (t % 3) * 16 + a_addr[i][t / 3]));
+            }
+        };
+        read_frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < 8) read_frags(t + 1, (t + 1) & 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[t & 1][PW_[k]][j], af[t & 1][PA_[k]][i], acc[i][j], 0, 0, 0);
+            if (t < 8) {                                   // the next tap's 4 + 2 TN fragment reads one at a time behind this tap's MFMAs
+#pragma unroll
+                for (int x = 0; x < 4 + 2 * TN; ++x) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (6 * TN > 4 + 2 * TN) __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN - (4 + 2 * TN), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cc + 1 < NCC) {
+            publish_max();                                 // chunk cc + 1's pixels were requested a chunk ago
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // everybody is done reading the stage; the four maxima are in place
+            fire_w(cc + 1);
+            const int sn = block_scale_exp();
+            if (sn != sb) {                                // (block-uniform) the accumulators move to the new scale: exact
+                const float f = __int_as_float((127 + sn - sb) << 23);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= f;
+                sb = sn;
+            }
+            split_a(__int_as_float(sb << 23));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (cc + 2 < NCC) load_a(cc + 2);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue: y = acc / (pixel scale * the channel's weight scale) + bias (+ residual), ReLU
+    // (register 4 g + e of channel block j = channel slice * NS + 32 j + 8 g + 4 fhalf + e)
+    const float inv_s = __int_as_float((254 - sb) << 23);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ws_f32x4 wv = *reinterpret_cast<const ws_f32x4*>(aux_w + j * 32 + 8 * g + 4 * fhalf);
+            const ws_f32x4 bv = *reinterpret_cast<const ws_f32x4*>(aux_b + j * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[e] *= inv_s;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ws_f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = fmaf(acc[i][j][4 * g + e], wv[e], bv[e] + rr[i][j][g][e]);
+                    o[e] = p.relu ? fmaxf(t, 0.f) : t;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), rs_out, piece_off(i, j, g, p.ldy), 0, 0);
+            }
+        }
+}
+
+#endif
+
+}  // namespace capf

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32x3_group_ws_kernel(X3GroupArg
 hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (n > MAXG) return hipErrorInvalidValue;
+    if (list[0].x3_h2) return launch_gemm_f32h2_group(list, n, s);      // (the two-fp16-piece tile: one plan, one kind of pack per engine)
     struct Item { X3Problem q; int cost; };
     Item it[MAXG];
     for (int i = 0; i < n; ++i) {
@@ -99,8 +100,8 @@ hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s) {
     }
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32x3_group_ws_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, x3_lds_bytes(X3_NS));
+    static DynLdsAttr attr_once;
+    const hipError_t attr = attr_once.ensure(reinterpret_cast<const void*>(&igemm_f32x3_group_ws_kernel), x3_lds_bytes(X3_NS));
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(igemm_f32x3_group_ws_kernel, dim3(start), dim3(256), x3_lds_bytes(X3_NS), s, ga);
     return hipGetLastError();
@@ -108,7 +109,7 @@ hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s) {
 
 hipError_t launch_gemm_f32x3(const GemmArgs& a, hipStream_t s) { return launch_gemm_f32x3_group(&a, 1, s); }
 
-const char* gemm_f32x3_kernel_name(const GemmArgs&) { return "igemm_f32x3_group_ws"; }
+const char* gemm_f32x3_kernel_name(const GemmArgs& a) { return a.x3_h2 ? gemm_f32h2_kernel_name(a) : "igemm_f32x3_group_ws"; }
 
 // BN fold + three-way split + re-layout for the tile: with v = w[slice * NS + n][cc * 16 + 8 h + e][kh][kw] * gamma / sqrt(var + eps) (the
 // fp32 value launch_pack_conv folds), piece 0 = bf16(v), piece 1 = bf16(v - piece 0), piece 2 = bf16(v - piece 0 - piece 1) -- exact

@@ -1379,21 +1379,14 @@ static bool wino_prepare(GemmArgs& a) {
     return true;
 }
 
-static hipError_t wino_attr() {
-    static hipError_t once = [] {
-        const void* big[] = {reinterpret_cast<const void*>(igemm_wino_kernel<false>), reinterpret_cast<const void*>(igemm_wino_group_kernel<false>)};
-        for (const void* f : big) {
-            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS * (int)sizeof(float));
-            if (r != hipSuccess) return r;
-        }
-        const void* half[] = {reinterpret_cast<const void*>(igemm_wino_kernel<true>), reinterpret_cast<const void*>(igemm_wino_group_kernel<true>)};
-        for (const void* f : half) {
-            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * (64 + 32) * WBK * (int)sizeof(float));
-            if (r != hipSuccess) return r;
-        }
-        return hipSuccess;
-    }();
-    return once;
+static hipError_t wino_attr() {          // (per device: DynLdsAttr)
+    static DynLdsAttr big[2], half[2];
+    const int big_bytes = WLDS * (int)sizeof(float), half_bytes = 6 * (64 + 32) * WBK * (int)sizeof(float);
+    hipError_t r = big[0].ensure(reinterpret_cast<const void*>(igemm_wino_kernel<false>), big_bytes);
+    if (r == hipSuccess) r = big[1].ensure(reinterpret_cast<const void*>(igemm_wino_group_kernel<false>), big_bytes);
+    if (r == hipSuccess) r = half[0].ensure(reinterpret_cast<const void*>(igemm_wino_kernel<true>), half_bytes);
+    if (r == hipSuccess) r = half[1].ensure(reinterpret_cast<const void*>(igemm_wino_group_kernel<true>), half_bytes);
+    return r;
 }
 
 // CAPF_WINO_MODE (A/B runs only): 0 (default) ping-pong, 64 KiB, two blocks per CU; 1: double-buffered 64 x 64 tile, 128 KiB

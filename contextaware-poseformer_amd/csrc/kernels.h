@@ -76,6 +76,22 @@ struct FastDiv {
 };
 FastDiv make_fastdiv(unsigned d);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: launchers that need more than the 64 KiB default of
+// dynamic LDS keep one of these per kernel (a function-local static) and call ensure() before every launch -- one hipGetDevice, and the
+// attribute call the first time a device is seen (a handle per device in one process: capf_create takes a device index)
+struct DynLdsAttr {
+    unsigned long long seen = 0;     // bit d: set on device d (a benign race: setting the attribute twice is harmless)
+    hipError_t ensure(const void* kernel, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && ((seen >> dev) & 1ull)) return hipSuccess;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev >= 0 && dev < 64) seen |= 1ull << dev;
+        return e;
+    }
+};
+
 // One implicit-GEMM problem:  out[m, n] = act( sum_k A[m, k] * Wp[n, k] + bias[n] + res[m, n] )
 //   conv mode: A[m, k] gathered from an NHWC tensor, m = (b, ho, wo), k = (kh, kw, ci)
 //   rows mode: A[m, k] = A[amap(m) + k]
@@ -88,6 +104,8 @@ struct GemmArgs {
                         // launch_gemm_bf16 / _group run the problems gemm_bf16_ws_wanted() accepts on that kernel.
                         // fp32 3x3 stride-1 convs: the weights as three bf16 pieces (igemm_f32x3_ws.hip), or nullptr;
                         // launch_gemm_wino / _group run the problems gemm_f32x3_wanted() accepts on that kernel
+    int x3_h2;          // fp32 3x3 stride-1 convs: Wp3 holds two block-scaled fp16 pieces (igemm_f32h2_ws.hip, launch_pack_conv_f32h2) and the
+                        // problems gemm_f32x3_wanted() accepts run on THAT tile (three piece products per fp32 MAC instead of six)
     const float* bias;  // [N] or nullptr
     const float* res;   // residual, addressed by rmap, or nullptr
     float* out;         // addressed by omap
@@ -197,6 +215,17 @@ hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s);
 const char* gemm_f32x3_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_f32x3(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                   void* Wp_bf16, float* bias, int Cout, int Cin, hipStream_t s);
+// the same convs with HALF the MFMAs (igemm_f32h2_ws.hip, igemm_f32h2_ws_tile.h): every operand as two fp16 pieces under an exact power-of-two
+// block scale (per output channel for the weights, per block and 16-channel chunk for the pixels, found in the kernel), three piece products
+// per fp32 MAC, fp32 accumulation; operands to 2^-23, one product to 2^-21 -- below the fp32 accumulation error of the dot product it
+// belongs to.  Same eligibility and size rule (gemm_f32x3_wanted); the problems of a list with GemmArgs::x3_h2 set run on this tile
+// (launch_gemm_f32x3_group forwards them).  Weights packed by launch_pack_conv_f32h2 (f32h2_pack_elems(Cout, Cin) 16-bit elements)
+long f32h2_pack_elems(int Cout, int Cin);
+hipError_t launch_gemm_f32h2_group(const GemmArgs* list, int n, hipStream_t s);
+int gemm_f32h2_launches(const GemmArgs* list, int n);   // grids that launch issues: the 32- and the 64-channel tiles of a level go out separately
+const char* gemm_f32h2_kernel_name(const GemmArgs& a);
+hipError_t launch_pack_conv_f32h2(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                  void* Wp_f16, float* bias, int Cout, int Cin, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);

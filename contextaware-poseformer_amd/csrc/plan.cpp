@@ -906,6 +906,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;
+    if (cfg.plan_flags & CAPF_PLAN_F32X3_EXACT) x3_h2 = false;
     // tuning knobs of the diagnostic build only (diag_env is a constant nullptr in the product library)
     if (const char* fz = diag_env("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;
     if (const char* wz = diag_env("CAPF_WINO")) use_wino = atoi(wz) != 0;
@@ -969,6 +970,21 @@ bool Engine::build() {
             }
         batch_limit = (int)std::min(2.0e9, 3.9e9 / worst);
     }
+    // at which batches a split-fp32 tile takes a Winograd-eligible conv (Engine::wino_now): f32x3_takes is monotone in the batch up to the
+    // tile's 2 GB tensor limit, so the range is [first batch it accepts, last batch it accepts]
+    for (Op& op : ops) {
+        if (op.kind != OP_GEMM || !op.wino || !packs[op.pack].x3) continue;
+        const double per_frame = (double)op.H * op.W * (double)std::max(op.Cin, op.N) * 4.0;
+        int hi = (int)std::min(1.0e6, 2.0e9 / per_frame);
+        while (hi >= 1 && hi > (int)(2.0e9 / per_frame) - 4 && !f32x3_takes(hi, op.H, op.W, op.Cin, op.N)) --hi;   // (the limit itself is exclusive)
+        if (hi < 1 || !f32x3_takes(hi, op.H, op.W, op.Cin, op.N)) continue;
+        int lo = 1, top = hi;                       // smallest accepted batch by bisection
+        while (lo < top) {
+            const int mid = lo + (top - lo) / 2;
+            if (f32x3_takes(mid, op.H, op.W, op.Cin, op.N)) top = mid; else lo = mid + 1;
+        }
+        op.x3_lo = lo; op.x3_hi = hi;
+    }
     // pack arena layout
     size_t off = 0;
     for (Pack& pk : packs) {
@@ -989,7 +1005,7 @@ bool Engine::build() {
         }
         if (pk.x3) {
             pk.w3_off = off;
-            off += round64(((size_t)f32x3_pack_elems(pk.N, pk.Cin) + 1) / 2);
+            off += round64(((size_t)(x3_h2 ? f32h2_pack_elems(pk.N, pk.Cin) : f32x3_pack_elems(pk.N, pk.Cin)) + 1) / 2);
         }
         pk.b_off = off;
         off += round64((size_t)pk.N);

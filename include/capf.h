@@ -86,8 +86,12 @@ enum capf_plan_flag {
     CAPF_PLAN_NO_WS = 32,           /* bf16 3x3 stride-1 convs without the 2-D halo tile (row-halo / direct kernels as in round 3) */
     CAPF_PLAN_LIFTER_FP32 = 64,     /* compute_dtype = CAPF_BF16: keep the lifter's qkv / proj / fc1 / fc2 on the fp32 kernels (bf16 backbone only);
                                      * the accuracy / speed trade bench.py reports as `vs_fp32_oracle`                                    */
-    CAPF_PLAN_NO_F32X3 = 128        /* fp32 3x3 stride-1 convs without the split-fp32 tile (three bf16 pieces per operand on the bf16
-                                     * matrix pipe, igemm_f32x3_ws.hip): the Winograd kernels (from batch 24; the direct kernel below)    */
+    CAPF_PLAN_NO_F32X3 = 128,       /* fp32 3x3 stride-1 convs without either split-fp32 tile (igemm_f32h2_ws.hip / igemm_f32x3_ws.hip):
+                                     * the Winograd kernels on the fp32 matrix pipe (from batch 24; the direct kernel below)              */
+    CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
+                                     * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
+                                     * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured
+                                     * distance to an fp64 evaluation (see capf_op_conv_f32h2_group)                                      */
 };
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -101,6 +105,12 @@ void capf_destroy(capf_handle* h);
 int capf_max_batch(const capf_handle* h);
 const char* capf_last_error(const capf_handle* h);  /* h may be NULL: last create error */
 const char* capf_version(void);
+/* ABI revision of THIS header.  A caller compiled against capf.h checks capf_abi_version() == CAPF_ABI_VERSION before it passes structs
+ * (capf_config, capf_conv_desc, capf_op_desc) across the boundary: revision 5 = round 5 (capf_op_desc as declared below -- 240 bytes since
+ * revision 4, 104 before --, plan flags up to CAPF_PLAN_F32X3_EXACT, the capf_op_*_f32h2 entry points, capf_op_describe_sized).  The
+ * version string carries the same number ("capf 0.5 (gfx950)").                                                                            */
+#define CAPF_ABI_VERSION 5
+int capf_abi_version(void);
 
 /* ---- parameter schema == the reference's state_dict ------------- */
 int capf_num_params(const capf_handle* h);
@@ -302,6 +312,23 @@ int capf_op_pack_conv_f32x3(void* stream, const float* w_oihw, const float* gamm
                             const float* var, float eps, void* w_packed_bf16, float* bias, int Cout, int Cin);
 int capf_op_conv_f32x3_group(void* stream, int n, const capf_conv_desc* convs);
 
+/* The default split-fp32 tile (csrc/igemm_f32h2_ws.hip; what capf_forward runs for those convs unless CAPF_PLAN_F32X3_EXACT / _NO_F32X3):
+ * fp32 tensors in and out; an operand a travels as two fp16 numbers a1 = fp16(s a), a2 = fp16(s a - a1) under an exact power-of-two scale s
+ * (weights: one per output channel, fixed at pack time; pixels: one per block of 256 output pixels and 16-channel chunk, found inside the
+ * kernel from the values it staged -- nothing outside the kernel sees a scale), |s a - a1 - a2| <= 2^-23 |s a|; the three products
+ * a1 w1 + a1 w2 + a2 w1 run on the 16-bit matrix pipe with fp32 accumulation (dropped: a2 w2 <= 2^-22 |a w|).  One term is therefore within
+ * 2^-21 of the fp32 product, which over a dot product of 9 Cin terms is below the fp32 accumulation error of ANY fp32 evaluation: the tests
+ * hold this tile to the same bound as the three-piece tile (<= 1e-6 of the sum of |terms| against fp64, <= 2 x this library's direct fp32
+ * MFMA kernel on the same problem).  Ranges: values whose magnitude is below 2^-18 of their block's largest lose relative precision
+ * (absolute error <= 2^-39 of that largest value); scales are kept within 2^+-63: block maxima in [2^-49, 2^77) = 1.8e-15 .. 1.5e23 get
+ * their exact scale, smaller ones lose precision gradually (all-zero blocks are exact), a block maximum of 2^77 or more overflows fp16
+ * (Inf, then NaN); Inf / NaN inputs give NaN for their whole block and chunk (CAPF_PLAN_NO_F32X3 keeps the fp32 pipe's IEEE behaviour).  Same shapes
+ * as above; w_packed holds capf_op_conv_f32h2_pack_elems(Cout, Cin) 16-bit elements (pieces, then the fp32 inverse channel scales).      */
+int64_t capf_op_conv_f32h2_pack_elems(int Cout, int Cin);
+int capf_op_pack_conv_f32h2(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
+                            const float* var, float eps, void* w_packed_f16, float* bias, int Cout, int Cin);
+int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* convs);
+
 /* Up to 8 independent bf16 convs in one grid (what capf_forward issues per dependency level of the HRNet branches of a bf16 model):
  * capf_conv_desc with bf16 x / w_packed / residual / y.  w_row_halo[i] (optional array, entries may be NULL): the same weights
  * from capf_op_pack_conv_bf16_rh; launches of >= 2048 tiles then run the row-halo tiles for those problems, exactly as the
@@ -426,7 +453,10 @@ typedef struct capf_op_desc {
 } capf_op_desc;
 int capf_forward_prefix(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
                         int batch, float* out, int n_ops);
-int capf_op_describe(const capf_handle* h, int index, capf_op_desc* desc);
+int capf_op_describe(const capf_handle* h, int index, capf_op_desc* desc);          /* writes sizeof(capf_op_desc) of THIS header's revision */
+/* ... for callers that cannot rule out a header / library mismatch: never writes more than desc_bytes (what the caller's struct holds);
+ * fields beyond that are dropped, a shorter library struct leaves the caller's tail zeroed.                                            */
+int capf_op_describe_sized(const capf_handle* h, int index, void* desc, size_t desc_bytes);
 int capf_op_tensor(const capf_handle* h, int index, int slot, const void** dev_ptr);
 
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,

@@ -152,9 +152,12 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below batch 6 and
     # the split-fp32 tile from 400 MFLOP per conv (batch 6 for these branches); a plan without that tile (CAPF_PLAN_NO_F32X3) runs them on
     # the Winograd kernel from batch 24
-    assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
-    assert {name: kern for name, kern, _ in eng.op_table(6)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
-    from capf.lib import PLAN_NO_F32X3
+    assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32h2_group_ws"       # (round 5: two fp16 pieces, three products)
+    assert {name: kern for name, kern, _ in eng.op_table(6)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32h2_group_ws"
+    from capf.lib import PLAN_NO_F32X3, PLAN_F32X3_EXACT
+    eng_x = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_F32X3_EXACT), device=None)   # round 4's exact three-piece tile
+    assert {name: kern for name, kern, _ in eng_x.op_table(64)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
+    assert [k for _, k, _ in eng_x.op_table(64) if not k.startswith("igemm_f32x3")] == [k for _, k, _ in eng.op_table(64) if not k.startswith("igemm_f32h2")]
     eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
     assert {name: kern for name, kern, _ in eng_w.op_table(24)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"   # F(4,3): row length 64 is a multiple of 4
     assert {name: kern for name, kern, _ in eng_w.op_table(16)}["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
@@ -243,7 +246,7 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
     """capf_config::plan_flags is the ONLY way to take a kernel family out of the plan: the A/B environment switches of
     earlier rounds are compiled out of the product library (kernels.h diag_env), unknown flag bits are rejected."""
     from capf import Engine
-    from capf.lib import PLAN_NO_F32X3, PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
+    from capf.lib import PLAN_F32X3_EXACT, PLAN_NO_F32X3, PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
     from mvn.models import _native
 
     def kernels(flags, embed=128):
@@ -253,15 +256,18 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
         return [(n, k) for n, k, _ in eng.op_table(64)]
 
     base = kernels(0)
-    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_f32x3") for _, k in base)
+    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_f32h2") for _, k in base)
+    assert not any(k.startswith("igemm_f32x3") for _, k in base)
+    exact = kernels(PLAN_F32X3_EXACT)                                       # round 4's plan: the exact three-bf16-piece tile
+    assert [n for n, k in exact if k.startswith("igemm_f32x3")] == [n for n, k in base if k.startswith("igemm_f32h2")]
     no_x3 = kernels(PLAN_NO_F32X3)                                          # the round-3 plan: Winograd kernels at every batch
-    assert any(k.startswith("igemm_wino") for _, k in no_x3) and not any(k.startswith("igemm_f32x3") for _, k in no_x3)
+    assert any(k.startswith("igemm_wino") for _, k in no_x3) and not any(k.startswith(("igemm_f32x3", "igemm_f32h2")) for _, k in no_x3)
     for var in ("CAPF_LIFTER_FUSED", "CAPF_WINO", "CAPF_BF16_RH", "CAPF_WINO_F43", "CAPF_F32X3_MIN_MFLOP"):
         monkeypatch.setenv(var, "0")
     assert kernels(0) == base                                               # the environment does not reach the product plan
     unfused = kernels(PLAN_NO_FUSED_LIFTER)
     assert not any(k in ("ctx_attn", "embed") for _, k in unfused) and any(k == "deform_sample" for _, k in unfused)
-    assert not any(k.startswith(("igemm_wino", "igemm_f32x3")) for _, k in kernels(PLAN_NO_WINOGRAD))
+    assert not any(k.startswith(("igemm_wino", "igemm_f32x3", "igemm_f32h2")) for _, k in kernels(PLAN_NO_WINOGRAD))
     with pytest.raises(CapfError):
         kernels(1 << 10)
     # embed_dim_ratio beyond the fused kernels' register / LDS budget: the plan falls back to one kernel per op
@@ -273,11 +279,16 @@ def test_executed_flops_of_winograd_ops_are_half_or_two_thirds_of_the_algorithmi
     from capf import Engine
     from mvn.models import _native
     eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
-    # batch 64: the branch convs run the split-fp32 tile -- six bf16 piece products per fp32 product, counted on the bf16 pipe
+    # batch 64: the branch convs run the split-fp32 tile -- three fp16 piece products per fp32 product (six bf16 ones under
+    # CAPF_PLAN_F32X3_EXACT), counted on the 16-bit pipe
     t64, e64 = eng.op_table(64), eng.op_executed_flops(64)
+    assert any(k.startswith("igemm_f32h2") for _, k, _ in t64)
+    assert all(abs(e / a - 3.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32h2"))
+    from capf.lib import PLAN_NO_F32X3, PLAN_F32X3_EXACT
+    eng_x = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_F32X3_EXACT), device=None)
+    t64, e64 = eng_x.op_table(64), eng_x.op_executed_flops(64)
     assert any(k.startswith("igemm_f32x3") for _, k, _ in t64)
     assert all(abs(e / a - 6.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32x3"))
-    from capf.lib import PLAN_NO_F32X3
     eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
     table, ex = eng_w.op_table(32), eng_w.op_executed_flops(32)
     seen = set()

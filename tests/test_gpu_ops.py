@@ -980,10 +980,186 @@ def test_f32x3_engine_path_agrees_with_the_winograd_kernels():
             eng = model.engine_for(img)
         kernels.append(set(k for _, k, _ in eng.op_table(32) if k))
         maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
-    assert any(k.startswith("igemm_f32x3") for k in kernels[0]) and not any(k.startswith("igemm_f32x3") for k in kernels[1])
+    assert any(k.startswith("igemm_f32h2") for k in kernels[0]) and not any(k.startswith(("igemm_f32x3", "igemm_f32h2")) for k in kernels[1])
     assert any(k.startswith("igemm_wino") for k in kernels[1])
     for a, b in zip(*maps):
         rel = ((a - b).norm() / b.norm()).item()
         print(f"split-fp32 vs Winograd: relative L2 {rel:.2e}")
         assert rel < 2e-5
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-4 * outs[1].abs().max().item()
+
+
+# ---- round 5: the default split-fp32 tile -- two block-scaled fp16 pieces per operand, three piece products (csrc/igemm_f32h2_ws.hip) ----
+
+def _h2_fold(wp, co, ci):
+    """Undo capf_op_pack_conv_f32h2: [32-channel slice][Cin / 16][piece 2][tap][32][quad position][8] fp16, then the fp32 inverse channel
+    scales -> (folded weights [co, ci, 3, 3] in fp64 = (piece 0 + piece 1) / scale, the channel scales)."""
+    nsl = (co + 31) // 32
+    npieces = nsl * (ci // 16) * 2 * 9 * 32 * 16
+    raw = wp.cpu()
+    winv = raw[npieces:npieces + 2 * nsl * 32].view(torch.float32).double()
+    t = raw[:npieces].view(torch.float16).double().view(nsl, ci // 16, 2, 9, 32, 2, 8).sum(dim=2)
+    n = torch.arange(32)
+    swap = ((n >> 3) & 1).bool()
+    t = torch.where(swap[None, None, None, :, None, None], t.flip(4), t)           # quad position -> channel half
+    w = t.permute(0, 3, 1, 4, 5, 2).reshape(nsl * 32, ci, 9) * winv.view(-1, 1, 1)
+    return w[:co].reshape(co, ci, 3, 3).contiguous(), winv[:co]
+
+
+def _h2_problem(rng, ci, co, H, W, B, act, res, xscale=None, gamma_spread=0):
+    from capf import lib as capf
+    x = torch.randn(B, ci, H, W, generator=rng) * torch.rand(B, ci, H, W, generator=rng).pow(3)     # magnitudes over several binades
+    if xscale is not None:
+        x = x * xscale
+    w = torch.randn(co, ci, 3, 3, generator=rng) / (ci * 9) ** 0.5
+    gam = torch.rand(co, generator=rng) + 0.5
+    if gamma_spread:
+        gam = gam * torch.exp2(torch.randint(-gamma_spread, gamma_spread + 1, (co,), generator=rng).float())
+    bnp = (gam, torch.randn(co, generator=rng) * 0.1, torch.randn(co, generator=rng) * 0.1, torch.rand(co, generator=rng) * 0.4 + 0.8)
+    bn_cuda = tuple(t.cuda() for t in bnp)
+    wp, bias = capf.pack_conv_f32h2(w.cuda(), bn_cuda)
+    wp3, bias3 = capf.pack_conv_f32x3(w.cuda(), bn_cuda)
+    w_fold = _x3_fold(wp3, co, ci)                                    # the exact fp32 fold (the three-piece pack loses nothing: tested above)
+    assert torch.equal(bias, bias3)
+    w_h2, winv = _h2_fold(wp, co, ci)
+    # the pack: two fp16 pieces of (fold * channel scale) reproduce the fold to 2^-23 (denormal second pieces: 2^-39 of the channel's largest)
+    cmax = w_fold.abs().amax(dim=(1, 2, 3), keepdim=True)
+    assert ((w_h2 - w_fold).abs() <= 2.0 ** -23 * w_fold.abs() + 2.0 ** -38 * cmax).all()
+    sc = torch.log2(winv)
+    assert torch.equal(sc, sc.round())                                # powers of two ...
+    top = cmax.flatten() / winv
+    assert ((top >= 2.0 ** 14) & (top < 2.0 ** 15) | (cmax.flatten() == 0)).all()        # ... that put the channel's largest weight in [2^14, 2^15)
+    r = torch.randn(B, co, H, W, generator=rng) if res else None
+    if r is not None and xscale is not None:
+        r = r * float(xscale if not torch.is_tensor(xscale) else xscale.abs().max())
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rg = r.permute(0, 2, 3, 1).contiguous().cuda() if res else None
+    return x, w, bnp, wp, bias, w_fold, r, xg, rg
+
+
+def test_f32h2_fuzz_against_torch():
+    """The 30 seeded problems of test_f32x3_fuzz_against_torch through the DEFAULT split-fp32 tile (two fp16 pieces under exact power-of-two
+    block scales, three piece products): same bound against the fp64 F.conv2d of the fp32 operands -- 1e-6 of each output's sum of |terms| --
+    and the same yardstick, this library's direct fp32 MFMA kernel on the same problem (<= 2 x its error).  The pack is read back: the two
+    pieces of a weight, unscaled, are within 2^-23 of the fp32 fold; the scales are powers of two."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(20261001)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    worst, n0 = 0.0, len(_x3_check.pairs)
+    for case in range(30):
+        ci = 16 * ri(1, 12)
+        co = 4 * ri(1, 48)
+        H, W, B = ri(1, 40), ri(1, 70), ri(1, 5)
+        if case == 5:
+            H, W, B = 8, 8, 9
+        if case == 6:
+            H, W, B = 64, 64, 2
+        if case == 7:
+            H, W, B = 12, 9, 5
+        if case == 8:
+            H, W, B, ci, co = 16, 16, 3, 128, 128
+        act, res = ri(0, 1), bool(ri(0, 1))
+        x, w, bnp, wp, bias, w_fold, r, xg, rg = _h2_problem(rng, ci, co, H, W, B, act, res)
+        got, = capf.conv_nhwc_f32h2_group([(xg, wp, bias, act, rg, co)])
+        wd, bd = capf.pack_conv(w.cuda(), tuple(t.cuda() for t in bnp))
+        direct = capf.conv_nhwc(xg, wd, bd, 3, 1, act, rg)
+        worst = max(worst, _x3_check(got, x, w_fold, bias, r, act, f"h2 case {case}: Cin {ci} Cout {co} {H}x{W} B{B} act {act} res {res}", direct))
+    e32 = max(b for _, b in _x3_check.pairs[n0:])
+    print(f"two-fp16-piece tile, 30 random problems: worst |error| {worst:.2e} of the sum of |terms| (the direct fp32 MFMA kernel on the same problems: {e32:.2e})")
+
+
+@pytest.mark.parametrize("mode", ["regions", "huge", "tiny", "channels", "dead"])
+def test_f32h2_block_scales_follow_the_data(mode):
+    """What the block scales are for: activations whose magnitude changes by 2^+-12 from one image region / channel group to the next,
+    tensors around 1e20 and 1e-20 (far outside fp16's range without the scale), BatchNorm folds whose channels differ by 2^+-10, and
+    tiles that are entirely zero (dead ReLU regions: the scale clamps, the bias must survive) -- same bound as the fuzz test."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed({"regions": 1, "huge": 2, "tiny": 3, "channels": 4, "dead": 5}[mode])
+    ci, co, H, W, B = 64, 96, 32, 32, 3
+    xscale, spread = None, 0
+    if mode == "regions":
+        xscale = torch.exp2(torch.randint(-12, 13, (B, ci // 16, H // 8, 1), generator=rng).float()).repeat_interleave(16, 1).repeat_interleave(8, 2)
+    elif mode == "huge":
+        xscale = 1e20
+    elif mode == "tiny":
+        xscale = 1e-20
+    elif mode == "channels":
+        spread = 10
+    elif mode == "dead":
+        xscale = torch.ones(B, 1, H, 1)
+        xscale[1] = 0.0                                              # a whole image of zeros
+        xscale[2, :, :16] = 0.0                                      # and half of another
+    x, w, bnp, wp, bias, w_fold, r, xg, rg = _h2_problem(rng, ci, co, H, W, B, 0, True, xscale, spread)
+    got, = capf.conv_nhwc_f32h2_group([(xg, wp, bias, 0, rg, co)])
+    assert torch.isfinite(got).all()
+    err = _x3_check(got, x, w_fold, bias, r, 0, f"h2 {mode}")
+    print(f"two-fp16-piece tile, {mode}: {err:.2e} of the sum of |terms|")
+
+
+@pytest.mark.parametrize("chans,B", [((32, 64, 128, 256), 9), ((48, 96, 192, 384), 5), ((64, 128, 256, 512), 3)])
+def test_grouped_f32h2_launch_matches_torch_and_single_launches(chans, B):
+    """The four HRNet branch convs as ONE grouped launch of the two-fp16-piece tile against fp64 F.conv2d, bit-identical to the four
+    single launches."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(sum(chans) + B)
+    probs, refs = [], []
+    for i, c in enumerate(chans):
+        r_ = 64 >> i
+        x, w, bnp, wp, bias, w_fold, r, xg, rg = _h2_problem(g, c, c, r_, r_, B, 1, True)
+        refs.append((x, w_fold, bias, r))
+        probs.append((xg, wp, bias, 1, rg, c))
+    outs = capf.conv_nhwc_f32h2_group(probs)
+    for y, (x, wf, bias, res), pr in zip(outs, refs, probs):
+        _x3_check(y, x, wf, bias, res, 1, f"h2 {x.shape}")
+        single, = capf.conv_nhwc_f32h2_group([pr])
+        assert torch.equal(single, y)
+
+
+def test_f32h2_wide_and_narrow_tiles_compute_the_same_bits():
+    """From 512 tiles of 64 channels a conv runs 64-channel tiles (two blocks per CU), below 32-channel ones (three): the K order and the
+    block scales do not depend on the width, so the first images of a 256-image batch (64-channel tiles) must equal the same images run
+    as a batch of 3 (32-channel tiles) bit for bit -- at 16x16 a tile is one image."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(77)
+    c, B = 128, 256
+    x, w, bnp, wp, bias, w_fold, r, xg, rg = _h2_problem(g, c, c, 16, 16, B, 1, True)
+    big, = capf.conv_nhwc_f32h2_group([(xg, wp, bias, 1, rg, c)])
+    small, = capf.conv_nhwc_f32h2_group([(xg[:3].contiguous(), wp, bias, 1, rg[:3].contiguous(), c)])
+    assert torch.equal(big[:3], small)
+    _x3_check(big[:8], x[:8], w_fold, bias, r[:8], 1, "h2 64-channel tiles")
+
+
+def test_f32h2_engine_path_agrees_with_the_exact_three_piece_plan():
+    """Batch 32 HRNet-32 fp32: the product plan (two-fp16-piece tile) against CAPF_PLAN_F32X3_EXACT (round 4's exact-operand tile) and
+    CAPF_PLAN_NO_F32X3 (fp32 matrix pipe): the context maps of the two split plans agree to fp32 roundoff -- closer to each other than
+    either is to the Winograd plan."""
+    import copy, contextlib, io
+    from capf import synth
+    from capf.lib import PLAN_F32X3_EXACT, PLAN_NO_F32X3
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    img, k2d, kc = synth.synth_inputs(32, 256, 256, seed=17)
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    maps, outs, kernels = [], [], []
+    for flags in (0, PLAN_F32X3_EXACT, PLAN_NO_F32X3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = CA_PF(cfg, compute_dtype="fp32", plan_flags=flags).eval()
+        synth.load_synthetic(model, seed=4, bn_mode="random")
+        model = model.cuda()
+        with torch.no_grad():
+            outs.append(model(img, k2d, kc.clone()).clone())
+            eng = model.engine_for(img)
+        kernels.append(set(k for _, k, _ in eng.op_table(32) if k))
+        maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
+    assert any(k.startswith("igemm_f32h2") for k in kernels[0]) and not any(k.startswith("igemm_f32x3") for k in kernels[0])
+    assert any(k.startswith("igemm_f32x3") for k in kernels[1]) and not any(k.startswith("igemm_f32h2") for k in kernels[1])
+    for a, b, c in zip(*maps):
+        rel, rel_w = ((a - b).norm() / b.norm()).item(), ((a - c).norm() / c.norm()).item()
+        print(f"two-piece vs exact three-piece plan: relative L2 {rel:.2e}   (vs the Winograd plan {rel_w:.2e})")
+        assert rel < 2e-6 and rel_w < 2e-5
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * outs[1].abs().max().item()
