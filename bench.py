@@ -97,6 +97,9 @@ def parse(argv=None):
                     help="inference, rank 0 at N=1: after the contract's one-batch-at-a-time measurement, ALSO time the same K steps "
                          "issued round-robin over this many engines (own workspaces, own HIP streams) so that consecutive batches "
                          "overlap; reported under \"overlapped_steps\", never as \"value\" (0 / 1 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak (default, the driver's contract) = --batch frames on EVERY GPU; strong (BASELINE.md section 4 item 4) = --batch is the "
+                         "GLOBAL batch, split evenly across the ranks (shard_bounds), so total work is fixed as N grows")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous, sharding, barriers, max-over-ranks and the JSON line "
                     "with a sleep instead of the GPU step (CPU smoke test of the N>1 flow)")
     a = ap.parse_args(argv)
@@ -120,6 +123,8 @@ def config_tag(a):
 
 def workload_string(a, tag):
     head = f"configs[{tag}]" if tag is not None else "custom (not a BASELINE.json configuration)"
+    per = (f"batch {a.batch}/GPU" if getattr(a, "scaling", "weak") == "weak" or a.gpus == 1 else
+           f"GLOBAL batch {a.batch} split over {a.gpus} GPUs ({a.batch // a.gpus}/GPU, strong scaling)")
     arith = (("fp32 tensors, fp32 accumulation; 3x3 stride-1 convs from batch 6: " +
               ("fp32 matrix pipe (Winograd / direct; CAPF_PLAN_NO_F32X3)" if getattr(a, "no_f32x3", False) else
                "each operand split exactly into three bf16 pieces, six piece products on the bf16 matrix pipe (CAPF_PLAN_F32X3_EXACT)" if getattr(a, "x3_exact", False) else
@@ -130,9 +135,9 @@ def workload_string(a, tag):
              "bf16 MFMA operands, fp32 accumulate (backbone convs; lifter GEMMs fp32: --lifter-fp32)" if getattr(a, "lifter_fp32", False) else
              "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)")
     if a.train:
-        return (f"{head}: TRAINING step, batch {a.batch}/GPU {a.backbone} {a.height}x{a.width} (frozen backbone forward, lifter "
+        return (f"{head}: TRAINING step, {per} {a.backbone} {a.height}x{a.width} (frozen backbone forward, lifter "
                 f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), lifter embed {a.embed} levels 4, {arith}")
-    return (f"{head}: batch {a.batch}/GPU {a.backbone} {a.height}x{a.width} image + 17 kpts -> 17x3, PoseFormer lifter embed "
+    return (f"{head}: {per} {a.backbone} {a.height}x{a.width} image + 17 kpts -> 17x3, PoseFormer lifter embed "
             f"{a.embed} levels 4, {arith}, inference")
 
 
@@ -166,6 +171,21 @@ def vs_fp32_oracle(backbone, sd_cpu, img, k2d, kc, got, others=None):
         dd = o[idx].cpu().float() - want
         res[key] = {"max_abs": float(dd.abs().max()), "mean_joint_dist": float(dd.norm(dim=-1).mean())}
     return res
+
+
+def reference_in_bf16(backbone):
+    """The yardstick for a bf16 line's `vs_fp32_oracle`: how far the REAL reference moves from its own fp32 joints when it is evaluated in
+    bf16 (committed fixture tests/golden/bf16_reference.npz, made by oracle/make_goldens.py from the imported reference on a golden frame --
+    other frames and weights than this run's, same architecture and input size)."""
+    import numpy as np
+    case = {"hrnet_48": "w48_256x256_b1", "cpn": "cpn_384x288_b1"}.get(backbone)
+    path = os.path.join(ROOT, "tests", "golden", "bf16_reference.npz")
+    if case is None or not os.path.exists(path):
+        return None
+    d = np.load(path, allow_pickle=False)
+    get = lambda tag: {"max_abs": float(d[f"{case}:{tag}:joints_maxabs"]), "mean_joint_dist": float(d[f"{case}:{tag}:joints_mean_dist"])}
+    return {"golden_case": case, "unit": "m", "torch_autocast_cpu_bfloat16": get("ac"), "fp32_activations_bf16_conv_linear_operands": get("opr"),
+            "note": "|reference in bf16 - reference in fp32| on the golden frame: the reference's own bf16 noise floor"}
 
 
 def cpu_baseline(backbone, H, W, sd_cpu, budget_s=24.0):
@@ -234,9 +254,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     tag = config_tag(a)
     B, H, W = a.batch, a.height, a.width
+    global_frames = B * world
+    if a.scaling == "strong":                              # the global batch is fixed: this rank's shard of it (frames are independent)
+        if B % world != 0:
+            raise SystemExit(f"--scaling strong: the global batch {B} does not divide over {world} ranks")
+        global_frames = B
+        lo_s, hi_s = cdist.shard_bounds(B, rank, world)
+        B = hi_s - lo_s
 
     if a.dry_run:
-        lo, hi = cdist.shard_bounds(B * world, rank, world)
+        lo, hi = cdist.shard_bounds(global_frames, rank, world)
         cdist.barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -258,11 +285,11 @@ def main():
                         "per_rank_frames_per_s": [round(r.item(), 2) for r in rates], "input_seeds": [int(x.item()) for x in seeds]}
         elapsed = cdist.max_over_ranks(mine_s, torch.device("cpu"))
         if rank == 0:
-            print(json.dumps({"metric": "frames/sec", "value": round(B * world * a.steps / elapsed, 2), "unit": "frames/s",
+            print(json.dumps({"metric": "frames/sec", "value": round(global_frames * a.steps / elapsed, 2), "unit": "frames/s",
                               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "none",
-                              "dry_run": True, "config": {"workload": workload_string(a, tag), "frames_per_step": B * world,
-                                                          "shard_of_rank0": [lo, hi]},
+                              "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": a.dtype, "data": "none",
+                              "dry_run": True, "config": {"workload": workload_string(a, tag), "frames_per_step": global_frames,
+                                                          "frames_per_gpu": B, "shard_of_rank0": [lo, hi]},
                               "distributed": dry_dist}))
         if world > 1:
             dist.barrier()
@@ -463,7 +490,7 @@ def main():
                      "per_rank_frames_per_s": [round(r.item(), 2) for r in rates]}
     elapsed = cdist.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / a.steps * 1e3
-    fps = B * world * a.steps / elapsed
+    fps = global_frames * a.steps / elapsed
 
     result = None
     if rank == 0:
@@ -587,9 +614,9 @@ def main():
         par = f"dp{world} (independent frames, " + ("one flat-gradient all-reduce per step)" if a.train else "no collective)")
         result = {
             "metric": "frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": workload_string(a, tag), "baseline_config": tag, "frames_per_step": B * world,
+            "config": {"workload": workload_string(a, tag), "baseline_config": tag, "frames_per_step": global_frames, "frames_per_gpu": B,
                        "parallelism": par, "launches_per_forward": n_launches, "forward_gflop_per_frame": round(flops / B / 1e9, 3),
                        "plan_flags": pflags},
             "end_to_end_forward_tflops": round(fps * flops / B / 1e12, 2),
@@ -608,6 +635,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             if not a.train:
                 result["vs_fp32_oracle"] = vs_fp32_oracle(a.backbone, sd_cpu, img, k2d, kc0, out, alt_outputs)
+                if a.dtype == "bf16":
+                    result["vs_fp32_oracle"]["reference_in_bf16"] = reference_in_bf16(a.backbone)
             result["cpu_baseline"] = cpu_baseline(a.backbone, H, W, sd_cpu)
             result["gpu_over_cpu"] = round(fps / result["cpu_baseline"]["value"], 1)
     if world > 1:

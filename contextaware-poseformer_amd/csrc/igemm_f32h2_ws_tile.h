@@ -31,7 +31,8 @@
 
 namespace capf {
 
-static constexpr int H2_A_BYTES = 2 * WS_A_BYTES;
+static constexpr int H2_HP = WS_MAX_PP * 16 + 64;           // one half-plane (16 B per staged pixel) + 64 B: the two halves of a pixel 16 banks apart
+static constexpr int H2_A_BYTES = 4 * H2_HP;
 static constexpr int H2_AUX_BYTES = 16 + 2 * 64 * 4;        // the four wave maxima of the chunk being split; the slice's inverse weight scales and biases
 inline constexpr int h2_w_bytes(int NS) { return 2 * 9 * NS * 32; }
 inline constexpr int h2_lds_bytes(int NS) { return H2_A_BYTES + h2_w_bytes(NS) + H2_AUX_BYTES; }
@@ -72,6 +73,7 @@ inline __host__ __device__ int h2_scale_exp(int mbits) {
 #if defined(__HIP_DEVICE_COMPILE__)
 
 typedef _Float16 ws_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ws_u32x2 __attribute__((ext_vector_type(2)));
 
 // a pair of fp32 values, scaled by s (a power of two) -> the pair's two packed fp16 pieces
 __device__ __forceinline__ void h2_split2(float x, float y, float s, unsigned& p1, unsigned& p2) {
@@ -105,7 +107,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     constexpr int W2_BYTES = TN * WS_BYTES;                // the tile's chunk: TN slices side by side
     constexpr int NWI = W2_BYTES / 1024;                   // weight DMA instructions per chunk: 18 TN
     constexpr int NWS = (NWI + 3) / 4;                     // ... per wave
-    constexpr int NAU = 4;                                 // half-pixel units per lane and chunk (832 at most in all)
+    constexpr int NAU = 7;                                 // quarter-pixel units (4 channels = 16 B of fp32) per lane and chunk (1664 at most in all)
     constexpr unsigned OOB = 0x80000000u;
     const WsProblem& p = q.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,36 +117,35 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     const int tm = bid / p.NSL, slice = bid - tm * p.NSL;
 
     const ws_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)q.x, 0, 0x7FFFFF00u, 0x00020000);
-    // ---- pixel units of this lane (igemm_f32x3_ws_tile.h): LDS image of a piece = two HALF-PLANES (channels 0-7 / 8-15 of the chunk),
-    // 16 B per staged pixel, pixel-linear; unit qi: lanes 8 k .. 8 k + 7 = eight consecutive pixels of one half
-    constexpr int HP = WS_MAX_PP * 16;                       // one half-plane; piece pc, half hf at (2 pc + hf) HP
-    static_assert(4 * HP == H2_A_BYTES, "plane layout");
+    // ---- pixel units of this lane.  LDS image of a piece = two HALF-PLANES (channels 0-7 / 8-15 of the chunk), 16 B per staged pixel,
+    // pixel-linear (igemm_f32x3_ws_tile.h).  A unit is a QUARTER of a staged pixel's chunk -- 4 channels, one 16-byte load -- and four
+    // consecutive lanes take the four quarters of one pixel: a wave's load instruction is 16 requests of 64 contiguous bytes (eight
+    // consecutive pixels of one half per lane group, as the three-piece tile has it, is 64 requests of 16 bytes: the L1's tag rate,
+    // not its bandwidth, then bounds three resident blocks -- 2048 cycles per chunk and block against 1728 of MFMAs)
+    constexpr int HP = H2_HP;                                // piece pc, half hf at (2 pc + hf) HP
     unsigned a_voff[NAU], a_lds[NAU];
-    const int n_units = 2 * ((p.PP + 7) & ~7);
+    const int n_units = 4 * p.PP;
     {
         const int q0 = tm * p.G;
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
             const int qi = min(j * 256 + tid, n_units - 1);  // (beyond the geometry: the last unit once more, same bytes same place)
-            const int half = (qi >> 3) & 1;
-            const int px = ((qi >> 4) << 3) | (qi & 7);
-            a_lds[j] = (unsigned)(half * HP + px * 16);
+            const int px = qi >> 2, qt = qi & 3;
+            a_lds[j] = (unsigned)((qt >> 1) * HP + px * 16 + (qt & 1) * 8);
             const int g = ws_div(px, p.d_segp), rem = px - g * p.SEGP;
             const int rr = ws_div(rem, p.d_pw), ww = rem - rr * p.PW;
             const int sg = q0 + g;
             const int b = ws_div(sg, p.d_rgpi);
             const int h = (sg - b * p.RGPI) * p.RH + rr - 1, col = ww - 1;
-            const bool ok = px < p.PP && sg < p.RG && h >= 0 && h < p.H && col >= 0 && col < p.W;
-            a_voff[j] = ok ? (unsigned)((((b * p.H + h) * p.W + col) * p.C + half * 8) * 4) : OOB;
+            const bool ok = sg < p.RG && h >= 0 && h < p.H && col >= 0 && col < p.W;
+            a_voff[j] = ok ? (unsigned)((((b * p.H + h) * p.W + col) * p.C + qt * 4) * 4) : OOB;
         }
     }
-    ws_f32x4 ar[NAU][2];
+    ws_f32x4 ar[NAU];
     auto load_a = [&](int cc) {
 #pragma unroll
-        for (int j = 0; j < NAU; ++j) {
-            ar[j][0] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], (unsigned)cc * 64u, 0));
-            ar[j][1] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j] + 16u, (unsigned)cc * 64u, 0));
-        }
+        for (int j = 0; j < NAU; ++j)
+            ar[j] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], (unsigned)cc * 64u, 0));
     };
     int* const aux = reinterpret_cast<int*>(lds + H2_A_BYTES + W2_BYTES);
     float* const aux_w = reinterpret_cast<float*>(aux + 4);      // [NS] 1 / weight scale of the slice's channels
@@ -154,9 +155,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
 #pragma unroll
         for (int j = 0; j < NAU; ++j)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ar[j][k][e]));
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ar[j][e]));
         const int wm = h2_wave_max(m);
         if (lane == 0) aux[wave] = wm;
     };
@@ -168,15 +167,15 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     auto split_a = [&](float s) {                          // the loaded chunk, scaled -> two fp16 planes
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
-            ws_u32x4 u1, u2;
+            ws_u32x2 u1, u2;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 unsigned s1, s2;
-                h2_split2(ar[j][k >> 1][2 * (k & 1)], ar[j][k >> 1][2 * (k & 1) + 1], s, s1, s2);
+                h2_split2(ar[j][2 * k], ar[j][2 * k + 1], s, s1, s2);
                 u1[k] = s1; u2[k] = s2;
             }
-            *reinterpret_cast<ws_u32x4*>(lds + a_lds[j]) = u1;
-            *reinterpret_cast<ws_u32x4*>(lds + 2 * HP + a_lds[j]) = u2;
+            *reinterpret_cast<ws_u32x2*>(lds + a_lds[j]) = u1;
+            *reinterpret_cast<ws_u32x2*>(lds + 2 * HP + a_lds[j]) = u2;
         }
     };
     const unsigned w_voff = (unsigned)lane * 16u;

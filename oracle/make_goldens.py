@@ -177,6 +177,80 @@ def prefetch_case():
     return rec
 
 
+BF16_CASES = ("w48_256x256_b1", "cpn_384x288_b1")
+
+
+def _taps_forward(model, img, k2d, kc, autocast=False):
+    """One forward of the REAL reference with the stage taps of run_case (context maps, token buffers after each block group, joints)."""
+    taps = {}
+    vn = model.volume_net
+    hooks = [
+        model.backbone.register_forward_hook(lambda m, i, o: taps.__setitem__("features", [t.detach().float() for t in o])),
+        vn.context_blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("tok_ctx", o.detach().float())),
+        vn.res_blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("tok_res", o.detach().float())),
+        vn.joint_blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("tok_joint", o.detach().float())),
+    ]
+    with torch.no_grad():
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = model(img, k2d, kc.clone())
+        else:
+            out = model(img, k2d, kc.clone())
+    for h in hooks:
+        h.remove()
+    taps["out"] = out.detach().float()
+    return taps
+
+
+def bf16_reference_case():
+    """How far the REFERENCE ITSELF moves when it is run in bf16: the real reference modules (fp32 synthetic
+    checkpoints of the golden cases) evaluated three ways on the golden inputs --
+        f32   : as the goldens were made;
+        ac    : under torch.autocast("cpu", dtype=torch.bfloat16) -- PyTorch's own bf16 policy: convolutions / linears / matmuls take and
+                return bf16, BatchNorm / residual adds run on bf16 tensors, LayerNorm / softmax / grid_sample in fp32;
+        opr   : fp32 activations, but every nn.Conv2d / nn.Linear sees its input and its weight rounded to bf16 (forward pre-hooks and
+                rounded weight copies): "bf16 only as MFMA operands", the recipe SURVEY section 7 names --
+    and the distances |ac - f32|, |opr - f32| per stage (context maps: relative L2; token buffers and joints: max-abs; joints also the mean
+    joint distance in metres).  Only these distances and the two bf16 joint sets are stored.  tests/bf16_report.py takes its end-to-end
+    budget from them: the HIP path under compute_dtype = bf16 may sit as far from fp32 as the reference's own bf16 evaluation does."""
+    rec = {}
+    for name in BF16_CASES:
+        case = CASES[name]
+        torch.set_num_threads(8)
+        model, _ = _refshim.build_reference(case["backbone"])
+        synth.load_synthetic(model, seed=case["wseed"], bn_mode=case["bn"])
+        img, k2d, kc = case_inputs(case)
+        f32 = _taps_forward(model, img, k2d, kc)
+        ac = _taps_forward(model, img, k2d, kc, autocast=True)
+        # operand rounding: weights rounded in place (restored afterwards), inputs rounded by pre-hooks
+        saved, hooks = {}, []
+        rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        for mod_name, mod in model.named_modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)):
+                saved[mod_name] = mod.weight.data.clone()
+                mod.weight.data.copy_(rnd(mod.weight.data))
+                hooks.append(mod.register_forward_pre_hook(lambda m, inp: tuple(rnd(t) if torch.is_floating_point(t) else t for t in inp)))
+        opr = _taps_forward(model, img, k2d, kc)
+        for h in hooks:
+            h.remove()
+        mods = dict(model.named_modules())
+        for mod_name, w in saved.items():
+            mods[mod_name].weight.data.copy_(w)
+        again = _taps_forward(model, img, k2d, kc)
+        assert torch.equal(again["out"], f32["out"])                   # the model is back to its fp32 self
+        for tag, t in (("ac", ac), ("opr", opr)):
+            for l in range(4):
+                a, b = t["features"][l].double(), f32["features"][l].double()
+                rec[f"{name}:{tag}:feat{l}_rel"] = np.array(((a - b).norm() / b.norm()).item())
+            for k in ("tok_ctx", "tok_res", "tok_joint"):
+                rec[f"{name}:{tag}:{k}_maxabs"] = np.array((t[k] - f32[k]).abs().max().item())
+            d = t["out"] - f32["out"]
+            rec[f"{name}:{tag}:joints_maxabs"] = np.array(d.abs().max().item())
+            rec[f"{name}:{tag}:joints_mean_dist"] = np.array(d.norm(dim=-1).mean().item())
+            rec[f"{name}:{tag}:out"] = t["out"].numpy()
+    return rec
+
+
 def schemas():
     import json
     out = {}
@@ -210,7 +284,7 @@ def compare(name, rec, path):
 
 
 def main():
-    """python oracle/make_goldens.py [--check] [case ... | schema | losses | prefetch]
+    """python oracle/make_goldens.py [--check] [case ... | schema | losses | prefetch | bf16_reference]
     --check: regenerate in memory from the reference and compare with the committed fixtures (exit 1 on mismatch)."""
     import json
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -229,7 +303,7 @@ def main():
             else:
                 with open(path, "w") as f:
                     json.dump(sch, f, separators=(",", ":"))
-    todo = [(n, lambda n=n, c=c: run_case(n, c)) for n, c in CASES.items()] + [("losses", loss_case), ("prefetch", prefetch_case)]
+    todo = [(n, lambda n=n, c=c: run_case(n, c)) for n, c in CASES.items()] + [("losses", loss_case), ("prefetch", prefetch_case), ("bf16_reference", bf16_reference_case)]
     for name, fn in todo:
         if only and name not in only:
             continue

@@ -13,6 +13,10 @@ every stage).  So:
     sits |E-F| away from the fp32 truth, and the HIP path may not sit further away than 1.5x that (+ 1e-3 m on the joints,
     the fp32 tolerance) at any stage.  The bound is derived from the oracle, not from the thing being tested."""
 
+import os
+
+import numpy as np
+
 SLACK = 1.5            # |H-F| <= SLACK * |E-F| + floor
 FLOOR_JOINTS = 1e-3    # metres (north-star fp32 tolerance)
 FLOOR_MAPS = 1e-3      # relative L2
@@ -55,3 +59,30 @@ def check_bf16_report(rep):
         assert hf <= SLACK * ef + floor, (k, hf, ef)
         assert he <= SLACK * (hf + ef) + floor, (k, he, hf, ef)          # triangle: H and E are both within their budgets of F
     assert rep["joints"][1] <= BUDGET_CAP, rep["joints"]
+
+
+def reference_bf16_distances(case):
+    """How far the REAL reference moves from its own fp32 outputs when IT is evaluated in bf16, on golden case `case` (fixture
+    tests/golden/bf16_reference.npz, written by oracle/make_goldens.py bf16_reference_case from the imported reference):
+    {"ac": torch.autocast("cpu", bfloat16), "opr": fp32 activations with bf16-rounded conv / linear operands} -> {stage: distance}
+    (context maps relative L2, token buffers and joints max-abs, joints_mean_dist in metres) + the two bf16 joint sets."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_reference.npz"), allow_pickle=False)
+    out = {}
+    for tag in ("ac", "opr"):
+        pre = f"{case}:{tag}:"
+        out[tag] = {k[len(pre):]: (d[k] if k.endswith(":out") else float(d[k])) for k in d.files if k.startswith(pre)}
+    return out
+
+
+def check_against_reference_bf16(tag, hip, ref_dist, slack=1.25):
+    """hip: {stage: distance of the HIP bf16 run from the REFERENCE's fp32 golden, same frame, same weights}.  The yardstick is the
+    reference itself: the HIP path may not sit further from the reference's fp32 result than the reference's own bf16 evaluations do --
+    `slack` x the larger of (autocast, operand rounding) per stage; joints additionally no further than slack x the AUTOCAST run (the
+    reference's bf16 as PyTorch defines it)."""
+    print(f"{tag}:  stage              |HIP bf16 - ref fp32|   |ref autocast-bf16 - ref fp32|   |ref bf16-operands - ref fp32|")
+    for k, h in hip.items():
+        a, o = ref_dist["ac"][k], ref_dist["opr"][k]
+        print(f"    {k:18s} {h:16.3e} {a:28.3e} {o:30.3e}")
+    for k, h in hip.items():
+        a, o = ref_dist["ac"][k], ref_dist["opr"][k]
+        assert h <= slack * max(a, o), (k, h, a, o)

@@ -24,7 +24,7 @@ def _built_library():
     return so
 
 
-def make_model(backbone, device=None, wseed=0, bn="random"):
+def make_model(backbone, device=None, wseed=0, bn="random", compute_dtype=None, plan_flags=0):
     """Host CA_PF with a synthetic checkpoint; returns (model, state_dict on CPU)."""
     import copy
     from capf import synth
@@ -34,7 +34,7 @@ def make_model(backbone, device=None, wseed=0, bn="random"):
     cfg = backbone_preset(copy.deepcopy(config), backbone)
     cfg.model.backbone.fix_weights = True
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg).eval()
+        model = (CA_PF(cfg) if compute_dtype is None and not plan_flags else CA_PF(cfg, compute_dtype=compute_dtype or "fp32", plan_flags=plan_flags)).eval()
     sd = synth.load_synthetic(model, seed=wseed, bn_mode=bn)
     if device is not None:
         model = model.to(device)

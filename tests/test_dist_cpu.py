@@ -165,6 +165,26 @@ def test_bench_eight_rank_dry_run_of_the_cpn_configuration():
     assert j["config"]["workload"].startswith("configs[4]")
 
 
+def test_bench_strong_scaling_dry_run_splits_a_fixed_global_batch():
+    """BASELINE.md section 4 item 4 asks for weak AND global-batch-fixed scaling: `--scaling strong` keeps --batch as the GLOBAL batch and
+    shards it over the ranks (capf.dist.shard_bounds), says so in the line, and counts the whole job's frames once."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--dry-run",
+                        "--backend", "gloo", "--config", "3", "--scaling", "strong"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 4
+    assert j["config"]["frames_per_step"] == 512 and j["config"]["frames_per_gpu"] == 128 and j["config"]["shard_of_rank0"] == [0, 128]
+    assert "GLOBAL batch 512 split over 4 GPUs" in j["config"]["workload"]
+    assert abs(j["value"] - 512 * 3 / (j["ms_per_step"] * 3e-3)) < 1.0          # the job's frames over the slowest rank's time
+    # a global batch that does not divide is refused, not rounded
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--dry-run",
+                        "--backend", "gloo", "--batch", "64", "--scaling", "strong"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "does not divide" in (r.stderr + r.stdout)
+
+
 def test_bench_labels_follow_the_arguments():
     import importlib.util, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

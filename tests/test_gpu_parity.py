@@ -142,3 +142,43 @@ def test_mpi_variant_matches_reference_golden(name):
     err = np.abs(out.cpu().numpy() - g["out"]).max()
     print(f"mpi variant {name}: max|hip-ref| {err:.2e}")
     assert err <= TOL_OUT
+
+
+@pytest.mark.parametrize("name", ["w48_256x256_b1", "cpn_384x288_b1"])
+def test_bf16_run_is_no_further_from_the_reference_than_the_references_own_bf16(name):
+    """a yardstick for compute_dtype = bf16 that comes from the REFERENCE.  tests/golden/bf16_reference.npz holds how far
+    the real reference moves from its own fp32 outputs on this golden frame when it is evaluated under torch.autocast(bfloat16) and with
+    bf16-rounded conv / linear operands.  The HIP bf16 path runs the SAME frame with the SAME weights and is held, stage by stage, to the
+    larger of those two distances x 1.25 -- measured against the reference's fp32 golden (not against this repository's oracle)."""
+    from bf16_report import check_against_reference_bf16, reference_bf16_distances
+    case = CASES[name]
+    g = load_golden(name)
+    model, sd = make_model(case["backbone"], device="cuda", wseed=case["wseed"], bn=case["bn"], compute_dtype="bf16")
+    img, k2d, kc = case_inputs(case)
+    eng = model.engine_for(img.cuda())
+    eng.set_debug(True)
+    with torch.no_grad():
+        out = model(img.cuda(), k2d.cuda(), kc.cuda()).cpu().numpy()
+    B = case["B"]
+    hip = {}
+    # (the fp32 goldens keep a 4x4 window of every context map, not the maps: the maps' distances are compared through the windows)
+    tok = {"tok_ctx": eng.tensor("tok_ctx").cpu().permute(0, 2, 1, 3).numpy(), "tok_res": eng.tensor("tok_res").cpu().reshape(B * 17, 5, -1).numpy(),
+           "tok_joint": eng.tensor("tok_joint").cpu().reshape(B, 17, -1).numpy()}
+    for k, v in tok.items():
+        hip[k + "_maxabs"] = float(np.abs(v - g[k]).max())
+    d = out - g["out"]
+    hip["joints_maxabs"] = float(np.abs(d).max())
+    hip["joints_mean_dist"] = float(np.linalg.norm(d, axis=-1).mean())
+    ref = reference_bf16_distances(name)
+    for l in range(4):
+        f = eng.tensor(f"feat{l}").float().cpu().numpy()
+        Bc, C, H, W = g[f"feat{l}_shape"]
+        h0, w0 = H // 3, W // 3
+        win = f[:, h0:h0 + 4, w0:w0 + 4, :]
+        rel = float(np.linalg.norm(win - g[f"feat{l}_slice"]) / np.linalg.norm(g[f"feat{l}_slice"]))
+        print(f"    feat{l} window: relative L2 {rel:.3e}   (whole map, reference autocast {ref['ac'][f'feat{l}_rel']:.3e}, operands {ref['opr'][f'feat{l}_rel']:.3e})")
+        assert rel <= 3.0 * max(ref["ac"][f"feat{l}_rel"], ref["opr"][f"feat{l}_rel"])      # a 4x4 window against a whole-map norm: loose
+    check_against_reference_bf16(f"{name} bf16", hip, ref)
+    # ... and the joints are closer to the reference's fp32 result than the reference's own autocast evaluation is
+    print(f"    joints: HIP {hip['joints_mean_dist']:.3e} m mean / {hip['joints_maxabs']:.3e} max;  reference under autocast "
+          f"{ref['ac']['joints_mean_dist']:.3e} / {ref['ac']['joints_maxabs']:.3e}")

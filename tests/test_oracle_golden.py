@@ -249,3 +249,31 @@ def test_grid_sample_in_cells_is_grid_sample_with_the_cells_given():
     dl = torch.autograd.grad(left.sum(), gx, retain_graph=True)[0][..., 0]
     dr = torch.autograd.grad(right.sum(), gx)[0][..., 0]
     assert (dl - dr).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["w48_256x256_b1", "cpn_384x288_b1"])
+def test_bf16_emulation_sits_between_the_references_two_bf16_evaluations(name):
+    """The bf16-emulating oracle (the yardstick of the end-to-end bf16 GPU tests, bf16_report.py) against what the REAL reference does
+    in bf16 on the same golden frame (tests/golden/bf16_reference.npz: torch.autocast(bfloat16), and fp32 activations with bf16-rounded
+    conv / linear operands): the emulation's distance to the reference's fp32 joints must not exceed the autocast run's, nor be
+    implausibly small next to the operand-rounding run's -- i.e. the builder's emulation is a bf16 evaluation of the reference's
+    arithmetic as the reference itself would produce one, not a private notion of bf16."""
+    from bf16_report import reference_bf16_distances
+    case = CASES[name]
+    g = load_golden(name)
+    _, sd = make_model(case["backbone"], wseed=case["wseed"], bn=case["bn"])
+    img, k2d, kc = case_inputs(case)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        emu = oracle.ca_pf_forward(sd, img, k2d, kc.clone(), backbone=case["backbone"], emulate_bf16=True).numpy()
+    d = emu - g["out"]
+    mean, worst = float(np.linalg.norm(d, axis=-1).mean()), float(np.abs(d).max())
+    ref = reference_bf16_distances(name)
+    print(f"{name}: emulation {mean:.3e} m mean / {worst:.3e} max from the reference's fp32 joints;  reference under autocast "
+          f"{ref['ac']['joints_mean_dist']:.3e} / {ref['ac']['joints_maxabs']:.3e};  with bf16 operands only {ref['opr']['joints_mean_dist']:.3e} / {ref['opr']['joints_maxabs']:.3e}")
+    assert mean <= 1.25 * ref["ac"]["joints_mean_dist"] and worst <= 1.25 * ref["ac"]["joints_maxabs"]
+    assert mean >= 0.4 * ref["opr"]["joints_mean_dist"]
+    # the reference's two bf16 joint sets are data of this test too: they differ from the fp32 golden by what the fixture says
+    for tag in ("ac", "opr"):
+        dd = ref[tag]["out"] - g["out"]
+        assert abs(float(np.abs(dd).max()) - ref[tag]["joints_maxabs"]) <= 1e-7
