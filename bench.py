@@ -131,7 +131,9 @@ def workload_string(a, tag):
                "each operand as two fp16 pieces under exact power-of-two block scales (to 2^-23), three piece products on the 16-bit matrix pipe -- same "
                "measured distance to fp64 as the direct fp32 MFMA kernel; Inf / NaN / |x| >= 1.5e23 give NaN (igemm_f32h2_ws); the exact-operand and "
                "fp32-pipe plans are timed on the same line (exact_split_plan, fp32_pipe_plan)") +
-              "; every other conv / GEMM: fp32 MFMA") if a.dtype == "f32" else
+              ("; every other conv / GEMM: fp32 MFMA" if getattr(a, "no_f32x3", False) else
+               "; the other convs and the lifter's plain projections: the same two-piece arithmetic (igemm_f32h2g); pointwise layer1 convs, stem, "
+               "LayerNorm-folded projections: fp32 MFMA")) if a.dtype == "f32" else
              "bf16 MFMA operands, fp32 accumulate (backbone convs; lifter GEMMs fp32: --lifter-fp32)" if getattr(a, "lifter_fp32", False) else
              "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)")
     if a.train:
@@ -312,10 +314,10 @@ def main():
     cfg.model.poseformer.embed_dim_ratio = a.embed
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        from capf.lib import PLAN_F32X3_EXACT, PLAN_LIFTER_FP32, PLAN_NO_F32X3
+        from capf.lib import PLAN_F32X3_EXACT, PLAN_LIFTER_FP32, PLAN_NO_F32H2_GEMM, PLAN_NO_F32X3
         pflags = PLAN_LIFTER_FP32 if (a.lifter_fp32 and a.dtype == "bf16") else 0
         if a.no_f32x3:
-            pflags |= PLAN_NO_F32X3
+            pflags |= PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM
         if a.x3_exact and a.dtype != "bf16":
             pflags |= PLAN_F32X3_EXACT
         model = CA_PF(cfg, compute_dtype="bf16" if a.dtype == "bf16" else "fp32", plan_flags=pflags).eval()
@@ -528,6 +530,7 @@ def main():
                         kern = (("igemm_bf16_group", "igemm_bf16_group_pp", "igemm_bf16_group_rh", "igemm_bf16_group_ws")[max(0, variants[l])] if kern.startswith("igemm_bf16")
                                 else ("igemm_wino43_group" if kern.startswith("igemm_wino43") else
                                       "igemm_wino_group" if kern.startswith("igemm_wino") else
+                                      "igemm_f32h2g_group" if kern.startswith("igemm_f32h2g") else
                                       kern if kern.startswith(("igemm_f32_pwchain", "igemm_f32x3", "igemm_f32h2")) else "igemm_f32_group"))
                         if table[l][1].startswith("igemm_bf16_pwchain"):
                             kern = table[l][1]
@@ -608,8 +611,8 @@ def main():
         overlapped = measure_overlapped()                     # (extra measurements run after the per-launch timing passes: they leave the chip warm)
         exact_split_plan = measure_alt_plan(PLAN_F32X3_EXACT, "exact_split_plan", "plan_flags |= CAPF_PLAN_F32X3_EXACT: the 3x3 convs on round 4's tile -- every operand "
                                             "split EXACTLY into three bf16 pieces, six piece products per fp32 product; not the headline")
-        fp32_pipe_plan = measure_alt_plan(PLAN_NO_F32X3, "fp32_pipe_plan", "plan_flags |= CAPF_PLAN_NO_F32X3: 3x3 convs on the fp32 matrix pipe (Winograd from batch 24, direct below); "
-                                          "not the headline")
+        fp32_pipe_plan = measure_alt_plan(PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM, "fp32_pipe_plan", "plan_flags |= CAPF_PLAN_NO_F32X3 | CAPF_PLAN_NO_F32H2_GEMM: every conv / GEMM on "
+                                          "the fp32 matrix pipe (3x3: Winograd from batch 24, direct below) -- round 3's plan; not the headline")
         launches, flops = eng.stats(B)
         par = f"dp{world} (independent frames, " + ("one flat-gradient all-reduce per step)" if a.train else "no collective)")
         result = {

@@ -8,7 +8,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
-PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT = 1, 2, 4, 8, 16, 32, 64, 128, 256     # capf_plan_flag
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512     # capf_plan_flag
 ABI_VERSION = 5        # include/capf.h :: CAPF_ABI_VERSION (checked against capf_abi_version() at load)
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
@@ -24,6 +24,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_op_conv_f32x3_pack_elems", "capf_op_pack_conv_f32x3", "capf_op_conv_f32x3_group",
     "capf_op_conv_f32h2_pack_elems", "capf_op_pack_conv_f32h2", "capf_op_conv_f32h2_group",
     "capf_abi_version", "capf_op_describe_sized",
+    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g",
 ]
 
 
@@ -137,6 +138,11 @@ def load_library():
     lib.capf_op_conv_f32h2_pack_elems.argtypes = [c_int, c_int]
     lib.capf_op_conv_f32h2_pack_elems.restype = c_int64
     lib.capf_op_pack_conv_f32h2.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int]
+    lib.capf_op_f32h2_gemm_pack_elems.argtypes = [c_int, c_int]
+    lib.capf_op_f32h2_gemm_pack_elems.restype = c_int64
+    lib.capf_op_pack_f32h2_gemm.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int, c_int]
+    lib.capf_op_conv_f32h2g.argtypes = [P, P, P, P, P, P] + [c_int] * 8
+    lib.capf_op_linear_f32h2g.argtypes = [P, P, P, P, P, P] + [c_int] * 4
     lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -716,6 +722,78 @@ def conv_nhwc_f32h2_group(problems):
     if rc:
         raise CapfError(f"capf_op_conv_f32h2_group failed ({rc})")
     return outs
+
+
+def pack_f32h2_gemm(w, bn=None, eps=1e-5):
+    """Weights for the two-fp16-piece GEMM (csrc/igemm_f32h2.hip): a conv filter [Cout, Cin, ks, ks] (BatchNorm folded if given) or an
+    nn.Linear weight [N, K] -> (packed fp32-typed buffer [elems]: [N][Kpad] of {piece 0 | piece 1} chunks + [N] inverse scales; fp32 bias
+    [N] for convs, None for linears)."""
+    import torch
+    lib = load_library()
+    if w.dim() == 4:
+        n, ci, ks, _ = w.shape
+        k = ks * ks * ci
+    else:
+        (n, k), ci, ks = w.shape, 0, 0
+    elems = lib.capf_op_f32h2_gemm_pack_elems(n, k)
+    wp = torch.empty(elems, device=w.device, dtype=torch.float32)
+    bias = torch.zeros(n, device=w.device) if w.dim() == 4 else None
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    rc = lib.capf_op_pack_f32h2_gemm(_stream(w), _p(w.contiguous()), _p(g), _p(b), _p(m), _p(v), eps, _p(wp), _p(bias), n, ci, ks, k)
+    if rc:
+        raise CapfError(f"capf_op_pack_f32h2_gemm failed ({rc})")
+    return wp, bias
+
+
+def conv_nhwc_f32h2g(x, wp, bias, ks, stride=1, act=0, residual=None, cout=None):
+    """y = act(conv2d(x; two-fp16-piece pack) + bias (+ residual)), NHWC fp32, padding ks // 2, one launch of igemm_f32h2g."""
+    import torch
+    lib = load_library()
+    B, H, W, ci = x.shape
+    co = cout if cout is not None else bias.numel()
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    y = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32)
+    rc = lib.capf_op_conv_f32h2g(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, ci, co, ks, stride, act)
+    if rc:
+        raise CapfError(f"capf_op_conv_f32h2g failed ({rc})")
+    return y
+
+
+def conv_nhwc_f32h2g_group(problems):
+    """problems: list of (x, wp, bias, ks, stride, act, residual, Cout) -> list of outputs, ONE grid of igemm_f32h2g_group_kernel."""
+    import torch
+    lib = load_library()
+    n = len(problems)
+    descs = (ConvDesc * n)()
+    outs = []
+    for i, (x, wp, bias, ks, stride, act, res, co) in enumerate(problems):
+        B, H, W, ci = x.shape
+        pad = ks // 2
+        Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y = torch.empty(B, Ho, Wo, co, device=x.device, dtype=torch.float32)
+        outs.append(y)
+        d = descs[i]
+        d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
+        d.residual = res.data_ptr() if res is not None else None
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, co, ks, stride, act
+    lib.capf_op_conv_f32h2g_group.argtypes = [c_void_p, c_int, POINTER(ConvDesc)]
+    rc = lib.capf_op_conv_f32h2g_group(_stream(problems[0][0]), n, descs)
+    if rc:
+        raise CapfError(f"capf_op_conv_f32h2g_group failed ({rc})")
+    return outs
+
+
+def linear_f32h2g(x, wp, bias, n, act=0, residual=None):
+    """y[M, N] = act(x[M, K] @ W^T + bias (+ residual)) on the two-fp16-piece GEMM (K % 32 == 0, N % 4 == 0)."""
+    import torch
+    lib = load_library()
+    M, K = x.shape
+    y = torch.empty(M, n, device=x.device, dtype=torch.float32)
+    rc = lib.capf_op_linear_f32h2g(_stream(x), _p(x), _p(wp), _p(bias), _p(residual), _p(y), M, n, K, act)
+    if rc:
+        raise CapfError(f"capf_op_linear_f32h2g failed ({rc})")
+    return y
 
 
 def conv_nhwc_bf16_group(problems):

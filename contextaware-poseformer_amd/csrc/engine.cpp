@@ -27,6 +27,12 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
             return CAPF_ERR_STATE;
         }
     }
+    for (const Pack& pk : packs) {                      // the convs' two-fp16-piece copies (igemm_f32h2.hip); the linears' are packed lazily
+        if (!pk.h2g || pk.kind != 0 || lifter_only) continue;
+        HIP_TRY(launch_pack_f32h2_gemm(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr, params[pk.bn_v].ptr,
+                                       1e-5f, pack_arena + pk.wh_off, nullptr, pk.N, pk.Cin, pk.ks, pk.K, pk.KpadH, s));
+    }
+    h2g_lifter_dirty = true;
     for (const Pack& pk : packs) {
         if (pk.direct) continue;
         if (lifter_only && pk.kind == 0) continue;      // conv+BN packs belong to the frozen backbone
@@ -87,6 +93,23 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
     return CAPF_OK;
 }
 
+// The lifter's linears as two fp16 pieces (igemm_f32h2.hip), rebuilt on the forward's stream when an inference forward of batch >= 6 finds
+// them stale: several linears concatenated along N are packed on their own rows, the inverse scales of all rows follow the whole matrix
+int Engine::ensure_h2g_lifter(hipStream_t s) {
+    if (!h2g_lifter_dirty) return CAPF_OK;
+    for (const Pack& pk : packs) {
+        if (!pk.h2g || pk.kind != 1) continue;
+        int n0 = 0;
+        for (int i = 0; i < pk.n_lin; ++i) {
+            const int n = (int)params[pk.w[i]].shape[0];
+            HIP_TRY(launch_pack_f32h2_gemm_rows(params[pk.w[i]].ptr, pack_arena + pk.wh_off, n0, n, pk.N, pk.K, pk.KpadH, s));
+            n0 += n;
+        }
+    }
+    h2g_lifter_dirty = false;
+    return CAPF_OK;
+}
+
 GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     auto ptr = [&](int buf) -> float* { return (buf >= 0 && ws) ? bptr(buf, batch) : nullptr; };
     const Pack& pk = packs[op.pack];
@@ -106,6 +129,9 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
     if (pk.ws || pk.x3) a.Wp3 = pack_arena + pk.w3_off;
     a.x3_h2 = pk.x3 && x3_h2;
+    // the plain fp32 MFMA kernels' problems on the two-fp16-piece GEMM from batch 6 (launch_gemm_f32 / _group route them; below, the fp32
+    // kernels with split-K win); not in a training forward (DropPath row scales), not with a LayerNorm fold
+    if (pk.h2g && batch >= H2G_MIN_BATCH && op.ln_w < 0 && !op.bf16 && !op.pw_pair && !(op.wino && wino_now(op, batch))) a.Wh2 = pack_arena + pk.wh_off;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
@@ -336,6 +362,10 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
 // the product schedule (grouped launches included).
 int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev, LaunchLog* log) {
     hipStream_t main_stream = s;
+    if (use_h2g && batch >= H2G_MIN_BATCH && last_op > n_backbone_ops && !bf16()) {
+        const int rc = ensure_h2g_lifter(s);
+        if (rc) return rc;
+    }
     const bool grouped = (lanes == 2 || lanes == 3) && !ev;
     const bool par = lanes == 1 && !ev && !log && side[0];
     for (int oi = first_op; oi < last_op; ++oi) {
@@ -435,7 +465,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~511) {
+    if (cfg->plan_flags & ~1023) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -774,6 +804,62 @@ int capf_op_conv_group(void* stream, int n, const capf_conv_desc* d) {
     return capf::launch_gemm_f32_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int64_t capf_op_f32h2_gemm_pack_elems(int N, int K) { return N > 0 && K > 0 ? capf::f32h2_gemm_pack_elems(N, (K + 31) / 32 * 32) : 0; }
+
+int capf_op_pack_f32h2_gemm(void* stream, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                            float eps, float* wp, float* bias, int N, int Cin, int ks, int K) {
+    if (!w || !wp || N <= 0 || (N & 3) || K <= 0 || (ks > 0 && K != ks * ks * Cin)) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_pack_f32h2_gemm(w, gamma, beta, mean, var, eps, wp, bias, N, Cin, ks, K, (K + 31) / 32 * 32,
+                                        static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+static capf::GemmArgs h2g_conv_args(const float* x, const float* wp, const float* bias, const float* residual, float* y, int B, int H, int W,
+                                    int Cin, int Cout, int ks, int stride, int act) {
+    capf::GemmArgs a{};
+    const int pad = ks / 2;
+    a.A = x; a.Wh2 = wp; a.bias = bias; a.res = residual; a.out = y;
+    a.Ho = (H + 2 * pad - ks) / stride + 1;
+    a.Wo = (W + 2 * pad - ks) / stride + 1;
+    a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = ks * ks * Cin; a.Kpad = (a.K + 31) / 32 * 32;
+    a.conv = 1; a.Cin = Cin; a.H = H; a.W = W; a.ks = ks; a.stride = stride; a.pad = pad;
+    a.omap = capf::row_ld(Cout); a.rmap = capf::row_ld(Cout); a.amap = capf::row_ld(0);
+    a.act = act;
+    return a;
+}
+
+int capf_op_conv_f32h2g(void* stream, const float* x, const float* wp, const float* bias, const float* residual, float* y,
+                        int B, int H, int W, int Cin, int Cout, int ks, int stride, int act) {
+    if (ks < 1 || stride < 1) return CAPF_ERR_INVALID;
+    const capf::GemmArgs a = h2g_conv_args(x, wp, bias, residual, y, B, H, W, Cin, Cout, ks, stride, act);
+    if (!capf::gemm_f32h2g_ok(a)) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_gemm_f32h2g(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_conv_f32h2g_group(void* stream, int n, const capf_conv_desc* d) {
+    if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
+    capf::GemmArgs g[capf::MAXG];
+    for (int i = 0; i < n; ++i) {
+        if (d[i].ks < 1 || d[i].stride < 1) return CAPF_ERR_INVALID;
+        g[i] = h2g_conv_args(static_cast<const float*>(d[i].x), static_cast<const float*>(d[i].w_packed), d[i].bias,
+                             static_cast<const float*>(d[i].residual), static_cast<float*>(d[i].y), d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].Cout,
+                             d[i].ks, d[i].stride, d[i].act);
+        if (!capf::gemm_f32h2g_ok(g[i])) return CAPF_ERR_UNSUPPORTED;
+    }
+    return capf::launch_gemm_f32h2g_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_linear_f32h2g(void* stream, const float* x, const float* wp, const float* bias, const float* residual, float* y,
+                          int M, int N, int K, int act) {
+    if (K % 32 != 0) return CAPF_ERR_UNSUPPORTED;
+    capf::GemmArgs a{};
+    a.A = x; a.Wh2 = wp; a.bias = bias; a.res = residual; a.out = y;
+    a.M = M; a.N = N; a.K = K; a.Kpad = K;
+    a.amap = capf::row_ld(K); a.omap = capf::row_ld(N); a.rmap = capf::row_ld(N);
+    a.act = act;
+    if (!capf::gemm_f32h2g_ok(a)) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_gemm_f32h2g(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_op_linear(void* stream, const float* x, const float* w, const float* bias, const float* residual, float* y,
                    int M, int N, int K, int act) {
     if (K % 32 != 0) return CAPF_ERR_UNSUPPORTED;
@@ -1050,6 +1136,8 @@ int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* f
     if (op.conv && e.wino_now(op, batch) && pk.x3 && capf::gemm_f32x3_wanted(e.gemm_args(op, batch)))
         *flops = (e.x3_h2 ? 3.0 : 6.0) * MN * op.K;               // split-fp32 tiles: three fp16 / six bf16 piece products per fp32 product, on the 16-bit pipe
     else if (op.conv && e.wino_now(op, batch)) *flops = MN * op.Cin * (pk.Kpad == 18 * pk.Cin ? 4.5 : 6.0);
+    else if (const capf::GemmArgs ga = e.gemm_args(op, batch); !op.bf16 && capf::gemm_f32h2g_ok(ga) && !capf::gemm_f32_pw_ok(ga))
+        *flops = 3.0 * MN * pk.KpadH;                              // two-fp16-piece GEMM: three piece products per fp32 product, on the 16-bit pipe
     else if (op.wino) *flops = MN * pk.Kpad2;                      // small batch: the direct kernel on the direct layout
     else if (pk.rh && op.conv) *flops = MN * op.K;                 // row-halo layout has no K padding (decided per launch; lower bound)
     else *flops = MN * (pk.direct ? op.K : pk.Kpad);

@@ -59,6 +59,9 @@ struct Pack {
     bool x3 = false;               // fp32 3x3 stride-1 conv: a copy for the split-fp32 tiles at w3_off -- two block-scaled fp16 pieces
                                    // (igemm_f32h2_ws.hip; Engine::x3_h2) or three bf16 pieces (igemm_f32x3_ws.hip)
     size_t w3_off = 0;
+    bool h2g = false;              // fp32 conv / linear: a copy as two block-scaled fp16 pieces for igemm_f32h2.hip ([N][KpadH] floats + [N] inverse
+    size_t wh_off = 0;             // channel scales) at wh_off; KpadH = the direct fp32 layout's padded K
+    int KpadH = 0;
     bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
 };
 
@@ -97,6 +100,8 @@ struct Op {
     double flops_per_frame = 0.0;
     int bf16 = 0;                 // tensors of this op are bf16 (conv: bf16 MFMA kernel)
     int wino = 0;                 // 3x3 stride-1 fp32 conv on the Winograd kernel (igemm_wino.hip)
+    int pw_pair = 0;              // one of a 64 -> 256 / 256 -> 64 pointwise pair that igemm_f32_pwchain.hip can run as one launch: stays on the fp32
+                                  // kernels in every plan (the chained and the two-launch routes are bit-identical; test_pointwise_chain_*)
     int x3_lo = 0, x3_hi = -1;    // batches [x3_lo, x3_hi] at which a split-fp32 tile takes this conv (f32x3_takes; set by build(), empty = never)
     int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
@@ -192,6 +197,11 @@ struct Engine {
     std::vector<int> last_variants;   // capf_forward_profile_launches: grouped-bf16 kernel variant per leader op
     bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
     bool use_x3 = true;            // plan: split-fp32 tile for the Winograd-eligible fp32 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_F32X3 clears it)
+    bool use_h2g = true;           // plan: every other fp32 conv / linear of an inference batch >= 6 on the two-fp16-piece GEMM (igemm_f32h2.hip; plan_flags &
+                                   // CAPF_PLAN_NO_F32H2_GEMM clears it)
+    static constexpr int H2G_MIN_BATCH = 6;
+    bool h2g_lifter_dirty = true;  // the linear packs' two-piece copies are stale (parameters changed since they were packed)
+    int ensure_h2g_lifter(hipStream_t s);
     bool x3_h2 = true;             // ... the two-fp16-piece tile (three piece products per MAC); plan_flags & CAPF_PLAN_F32X3_EXACT: the three-bf16-piece tile (six)
     bool use_ws = true;            // plan: 2-D halo layout + kernel for the bf16 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_WS clears it)
     bool use_wino = true;          // plan: Winograd F(2,3) kernel for the eligible 3x3 stride-1 fp32 convs (CAPF_WINO=0: direct kernel everywhere, A/B runs)

@@ -1011,6 +1011,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
     if (a.conv && a.Cin % 4 != 0)
         return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : (stem_stream_f32_ok(a) ? "igemm_f32_stem_stream<w4,64x64>" : "igemm_f32_smallc<w4,128x64>");
     if (gemm_f32_pw_ok(a)) return gemm_f32_pw_kernel_name();
+    if (gemm_f32h2g_ok(a)) return gemm_f32h2g_kernel_name(a, false);
     if (gemm_f32_rows_splitk(a)) return "igemm_f32_rows_splitk";
     return buf[pick_tile(a)][a.conv ? 1 : 0];
 }
@@ -1105,6 +1106,21 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (n == 1 && !worth_splitting(list[0])) return launch_gemm_f32(list[0], s);
     if (n > MAXG) return hipErrorInvalidValue;
+    {   // problems that carry the two-fp16-piece pack (GemmArgs::Wh2, igemm_f32h2.hip) go out as their own grid; the HBM-bound pointwise
+        // convs keep their kernel (launch_gemm_f32 routes them)
+        GemmArgs h2[MAXG], rest[MAXG];
+        int nh = 0, nr = 0;
+        for (int i = 0; i < n; ++i) {
+            if (gemm_f32h2g_ok(list[i]) && !gemm_f32_pw_ok(list[i])) h2[nh++] = list[i];
+            else rest[nr++] = list[i];
+        }
+        if (nh) {
+            const hipError_t e = nh == 1 ? launch_gemm_f32h2g(h2[0], s) : launch_gemm_f32h2g_group(h2, nh, s);
+            if (e != hipSuccess) return e;
+            for (int i = 0; i < nr; ++i) rest[i].Wh2 = nullptr;
+            return nr ? launch_gemm_f32_group(rest, nr, s) : hipSuccess;
+        }
+    }
     static const int BMs[3] = {128, 64, 128}, BNs[3] = {64, 64, 32};
     // work in units of one 64x64x32 tile-chunk (1024 MFMA cycles of a CU), per CU
     double total = 0.0;
@@ -1198,6 +1214,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
     if (gemm_f32_pw_ok(a_in)) return launch_gemm_f32_pw(a_in, s);
+    if (gemm_f32h2g_ok(a_in)) return launch_gemm_f32h2g(a_in, s);
     if (a_in.splits <= 1 && worth_splitting(a_in)) return launch_gemm_f32_group(&a_in, 1, s);
     GemmArgs a = a_in;
     if (gemm_f32_rows_splitk(a_in)) {                                      // a handful of tiles with a long K loop: slices + in-launch reduction

@@ -106,6 +106,9 @@ struct GemmArgs {
                         // launch_gemm_wino / _group run the problems gemm_f32x3_wanted() accepts on that kernel
     int x3_h2;          // fp32 3x3 stride-1 convs: Wp3 holds two block-scaled fp16 pieces (igemm_f32h2_ws.hip, launch_pack_conv_f32h2) and the
                         // problems gemm_f32x3_wanted() accepts run on THAT tile (three piece products per fp32 MAC instead of six)
+    const float* Wh2;   // the same weights as the two-fp16-piece pack of igemm_f32h2.hip (launch_pack_f32h2_gemm: Wp's [N][Kpad] geometry, then [N]
+                        // inverse channel scales), or nullptr: launch_gemm_f32 / _group run the problem on that kernel where gemm_f32h2g_ok()
+                        // accepts it (the HBM-bound pointwise kernels keep theirs)
     const float* bias;  // [N] or nullptr
     const float* res;   // residual, addressed by rmap, or nullptr
     float* out;         // addressed by omap
@@ -226,6 +229,18 @@ int gemm_f32h2_launches(const GemmArgs* list, int n);   // grids that launch iss
 const char* gemm_f32h2_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_f32h2(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                   void* Wp_f16, float* bias, int Cout, int Cin, hipStream_t s);
+// ... and everything else that is fp32 and MFMA-shaped -- 1x1 / stride-2 / lone convs, the lifter's linears -- on the same two-piece arithmetic
+// (igemm_f32h2.hip): the A tile is staged as fp32 exactly as igemm_f32.hip stages it and split by the wave that consumes it (scale per wave,
+// 32 rows and 32-deep chunk); weights packed by launch_pack_f32h2_gemm over the fp32 pack's geometry (GemmArgs::Wh2)
+long f32h2_gemm_pack_elems(int N, int Kpad);            // floats
+bool gemm_f32h2g_ok(const GemmArgs& a);
+hipError_t launch_gemm_f32h2g(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_f32h2g_group(const GemmArgs* list, int n, hipStream_t s);     // convs with plain row maps, one grid
+const char* gemm_f32h2g_kernel_name(const GemmArgs& a, bool grouped);
+hipError_t launch_pack_f32h2_gemm(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                  float* Wp, float* bias, int N, int Cin, int ks, int K, int Kpad, hipStream_t s);   // ks = 0: linear [N][K]
+// rows [n0, n0 + n) of an [Ntot][Kpad] pack from one nn.Linear weight [n][K] (several linears concatenated along N share a pack)
+hipError_t launch_pack_f32h2_gemm_rows(const float* w, float* Wp, int n0, int n, int Ntot, int K, int Kpad, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);

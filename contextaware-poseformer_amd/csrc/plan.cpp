@@ -134,6 +134,10 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     // fp32: the Winograd-eligible convs also keep their weights as three bf16 pieces for the split-fp32 tile (igemm_f32x3_ws.hip), which
     // takes them from 400 MFLOP per conv and batch 6 up (f32x3_takes)
     if (use_wino && use_x3 && x.W <= 256) pk.x3 = true;
+    // fp32: every conv with 16-byte-aligned channel counts also keeps its weights as two block-scaled fp16 pieces in the direct layout's
+    // geometry (igemm_f32h2.hip): what runs on the plain fp32 MFMA kernel at batch < 6 runs there from batch 6 (1x1 / stride-2 fuse and
+    // transition convs, lone convs; the HBM-bound pointwise kernels of layer1 keep theirs)
+    if (!use_bf16 && use_h2g && x.C % 4 == 0 && Cout % 4 == 0) { pk.h2g = true; pk.KpadH = use_wino ? pk.Kpad2 : pk.Kpad; }
     packs.push_back(pk);
 
     Op op;
@@ -447,6 +451,9 @@ static int make_linear_pack(Engine& e, const std::vector<std::string>& names, bo
     if (quad) pk.Kpad = K;                     // (K % 4 == 0: embed dims and level channel counts)
     pk.direct = !as_bf16 && !quad && (pk.n_lin == 1 && pk.Kpad == K);
     pk.bf16 = as_bf16;                         // bf16 copy [N][Kpad] for the bf16 MFMA projections (compute_dtype = bf16)
+    // the fp32 projections also as two fp16 pieces for igemm_f32h2.hip, packed LAZILY (Engine::ensure_h2g_lifter): a training loop changes the
+    // weights every step and its forward runs train.cpp's GEMMs, so the copy is rebuilt only when an inference forward needs it
+    if (!as_bf16 && !quad && e.use_h2g && !e.bf16() && K % 4 == 0 && N % 4 == 0) { pk.h2g = true; pk.KpadH = round32(K); }
     e.packs.push_back(pk);
     return (int)e.packs.size() - 1;
 }
@@ -907,6 +914,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;
     if (cfg.plan_flags & CAPF_PLAN_F32X3_EXACT) x3_h2 = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_F32H2_GEMM) use_h2g = false;
     // tuning knobs of the diagnostic build only (diag_env is a constant nullptr in the product library)
     if (const char* fz = diag_env("CAPF_LIFTER_FUSED")) fused_lifter = atoi(fz) != 0;
     if (const char* wz = diag_env("CAPF_WINO")) use_wino = atoi(wz) != 0;
@@ -970,6 +978,15 @@ bool Engine::build() {
             }
         batch_limit = (int)std::min(2.0e9, 3.9e9 / worst);
     }
+    // the layer1 bottleneck pairs (conv3 -> next block's conv1) the pointwise-chain kernel takes: structural half of gemm_f32_pwchain_ok
+    for (size_t i = 0; i + 1 < ops.size(); ++i) {
+        Op& a = ops[i];
+        Op& b = ops[i + 1];
+        if (a.kind != OP_GEMM || b.kind != OP_GEMM || !a.conv || !b.conv || a.bf16 || b.bf16) continue;
+        if (a.ks != 1 || b.ks != 1 || a.stride != 1 || b.stride != 1 || a.Cin != 64 || a.N != 256 || b.Cin != 256 || b.N != 64) continue;
+        if (b.in[0] != a.out || b.region != a.region || b.lane != a.lane || a.aux < 0 || b.aux >= 0) continue;
+        a.pw_pair = b.pw_pair = 1;
+    }
     // at which batches a split-fp32 tile takes a Winograd-eligible conv (Engine::wino_now): f32x3_takes is monotone in the batch up to the
     // tile's 2 GB tensor limit, so the range is [first batch it accepts, last batch it accepts]
     for (Op& op : ops) {
@@ -1010,6 +1027,11 @@ bool Engine::build() {
         pk.b_off = off;
         off += round64((size_t)pk.N);
     }
+    for (Pack& pk : packs)                  // (direct linears included: the h2 copy is a pack of its own)
+        if (pk.h2g) {
+            pk.wh_off = off;
+            off += round64((size_t)f32h2_gemm_pack_elems(pk.N, pk.KpadH));
+        }
     pack_elems = off;
     return true;
 }

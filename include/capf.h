@@ -88,6 +88,8 @@ enum capf_plan_flag {
                                      * the accuracy / speed trade bench.py reports as `vs_fp32_oracle`                                    */
     CAPF_PLAN_NO_F32X3 = 128,       /* fp32 3x3 stride-1 convs without either split-fp32 tile (igemm_f32h2_ws.hip / igemm_f32x3_ws.hip):
                                      * the Winograd kernels on the fp32 matrix pipe (from batch 24; the direct kernel below)              */
+    CAPF_PLAN_NO_F32H2_GEMM = 512,  /* every OTHER fp32 conv / linear (1x1, stride 2, lone convs, the lifter's projections) on the fp32 matrix pipe at
+                                     * every batch (igemm_f32.hip) instead of the two-fp16-piece GEMM from batch 6 (igemm_f32h2.hip, inference plans) */
     CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
                                      * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
                                      * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured
@@ -328,6 +330,24 @@ int64_t capf_op_conv_f32h2_pack_elems(int Cout, int Cin);
 int capf_op_pack_conv_f32h2(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
                             const float* var, float eps, void* w_packed_f16, float* bias, int Cout, int Cin);
 int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* convs);
+
+/* The two-fp16-piece arithmetic for every OTHER fp32 conv / linear (csrc/igemm_f32h2.hip; what capf_forward runs from batch 6 for the 1x1 and
+ * stride-2 convs of the fuse / transition layers, pose_hrnet.py:225-303, lone convs, and -- in inference plans -- the lifter's nn.Linear layers,
+ * pose_dformer.py:15-59): the activation tile is staged as fp32 and split by the wave that consumes it (one power-of-two scale per wave,
+ * 32 rows and 32-deep K chunk), the weights are split at pack time (one scale per output channel); same ranges and the same accuracy
+ * statement as capf_op_conv_f32h2_group.  capf_op_pack_f32h2_gemm writes capf_op_f32h2_gemm_pack_elems(N, K) floats: the fp32 pack's
+ * [N][Kpad] geometry (Kpad = K rounded up to 32; conv: ks >= 1, w OIHW, K = ks * ks * Cin, BatchNorm folded, bias written if not NULL;
+ * linear: ks = 0, Cin ignored, w [N][K], bias untouched) holding [piece 0: 32 fp16 | piece 1: 32 fp16] per 32-deep chunk, then the N
+ * fp32 inverse channel scales.  capf_op_conv_f32h2g / capf_op_linear_f32h2g: capf_op_conv / capf_op_linear on that pack (Cin % 4 == 0,
+ * Cout % 4 == 0, ks <= 5; K % 32 == 0, N % 4 == 0); capf_op_conv_f32h2g_group: up to 8 such convs in one grid.                          */
+int64_t capf_op_f32h2_gemm_pack_elems(int N, int K);
+int capf_op_pack_f32h2_gemm(void* stream, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                            float eps, float* w_packed, float* bias, int N, int Cin, int ks, int K);
+int capf_op_conv_f32h2g(void* stream, const float* x_nhwc, const float* w_packed, const float* bias, const float* residual, float* y,
+                        int B, int H, int W, int Cin, int Cout, int ks, int stride, int act);
+int capf_op_conv_f32h2g_group(void* stream, int n, const capf_conv_desc* convs);
+int capf_op_linear_f32h2g(void* stream, const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                          int M, int N, int K, int act);
 
 /* Up to 8 independent bf16 convs in one grid (what capf_forward issues per dependency level of the HRNet branches of a bf16 model):
  * capf_conv_desc with bf16 x / w_packed / residual / y.  w_row_halo[i] (optional array, entries may be NULL): the same weights

@@ -145,10 +145,19 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     64x64 branch keeps its tall 256x32 tile when it is launched on its own."""
     from capf import Engine
     from mvn.models import _native
+    from capf.lib import PLAN_NO_F32H2_GEMM
     eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
     table = {name: kern for name, kern, _ in eng.op_table(64)}
-    assert table["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
-    assert table["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
+    # round 5: from batch 6 the lifter's plain projections run the two-fp16-piece GEMM (64 x 64 tiles as well); the LayerNorm-folded ones
+    # (K = 128: res blocks' qkv / fc1, context blocks' fc1) and every batch below 6 stay on the fp32 MFMA kernel
+    assert table["joint0.qkv"] == "igemm_f32h2g<64x64,rows>" and table["joint0.fc2"] == "igemm_f32h2g<64x64,rows>"
+    assert table["res0.qkv"] == "igemm_f32<w4,64x64,rows>"
+    assert {name: kern for name, kern, _ in eng.op_table(4)}["joint0.qkv"].startswith("igemm_f32<")
+    eng_f = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32H2_GEMM), device=None)
+    table_f = {name: kern for name, kern, _ in eng_f.op_table(64)}
+    assert table_f["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
+    assert table_f["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
+    assert not any(k.startswith("igemm_f32h2g") for k in table_f.values())
     # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below batch 6 and
     # the split-fp32 tile from 400 MFLOP per conv (batch 6 for these branches); a plan without that tile (CAPF_PLAN_NO_F32X3) runs them on
     # the Winograd kernel from batch 24
@@ -157,18 +166,27 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     from capf.lib import PLAN_NO_F32X3, PLAN_F32X3_EXACT
     eng_x = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_F32X3_EXACT), device=None)   # round 4's exact three-piece tile
     assert {name: kern for name, kern, _ in eng_x.op_table(64)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32x3_group_ws"
-    assert [k for _, k, _ in eng_x.op_table(64) if not k.startswith("igemm_f32x3")] == [k for _, k, _ in eng.op_table(64) if not k.startswith("igemm_f32h2")]
+    assert [k for _, k, _ in eng_x.op_table(64) if not k.startswith("igemm_f32x3")] == [k for _, k, _ in eng.op_table(64) if not k.startswith("igemm_f32h2_")]
     eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
     assert {name: kern for name, kern, _ in eng_w.op_table(24)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"   # F(4,3): row length 64 is a multiple of 4
-    assert {name: kern for name, kern, _ in eng_w.op_table(16)}["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
+    # (between batch 6 and the Winograd kernels' batch 24 the direct route is the two-fp16-piece GEMM; the whole fp32-pipe plan of round 3
+    # is CAPF_PLAN_NO_F32X3 | CAPF_PLAN_NO_F32H2_GEMM)
+    assert {name: kern for name, kern, _ in eng_w.op_table(16)}["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32h2g<")
+    eng_p = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM), device=None)
+    assert {name: kern for name, kern, _ in eng_p.op_table(16)}["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
+    assert not any(k.startswith(("igemm_f32h2", "igemm_f32x3")) for _, k, _ in eng_p.op_table(64))
     small = {name: kern for name, kern, _ in eng.op_table(4)}
     assert small["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32<")
     # layer1's HBM-bound 1x1 bottleneck convs: the pointwise kernel from 2048 tiles per launch, the general tile below
     assert table["backbone.layer1.0.conv3"] == "igemm_f32_pw<w4,128x64>"
     assert table["backbone.layer1.1.conv1"] == "igemm_f32_pw<w4,128x64>"
+    # (the conv3 -> next conv1 pairs stay on the fp32 kernels at every batch: the chained and the two-launch routes must give the same bits)
     assert {name: kern for name, kern, _ in eng.op_table(8)}["backbone.layer1.0.conv3"].startswith("igemm_f32<")
+    assert {name: kern for name, kern, _ in eng.op_table(8)}["backbone.layer1.0.conv1"].startswith("igemm_f32h2g<")
+    assert {name: kern for name, kern, _ in eng_f.op_table(8)}["backbone.layer1.0.conv1"].startswith("igemm_f32<")
     big = {name: kern for name, kern, _ in eng.op_table(512)}
-    assert big["joint0.qkv"] in ("igemm_f32<w4,128x128,rows>", "igemm_f32<w4,128x64,rows>")
+    assert big["joint0.qkv"] == "igemm_f32h2g<128x64,rows>"
+    assert {name: kern for name, kern, _ in eng_f.op_table(512)}["joint0.qkv"] in ("igemm_f32<w4,128x128,rows>", "igemm_f32<w4,128x64,rows>")
 
 
 def test_conv_group_rejects_bad_arguments_without_a_gpu():
@@ -246,7 +264,7 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
     """capf_config::plan_flags is the ONLY way to take a kernel family out of the plan: the A/B environment switches of
     earlier rounds are compiled out of the product library (kernels.h diag_env), unknown flag bits are rejected."""
     from capf import Engine
-    from capf.lib import PLAN_F32X3_EXACT, PLAN_NO_F32X3, PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
+    from capf.lib import PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM, PLAN_NO_F32X3, PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, CapfError
     from mvn.models import _native
 
     def kernels(flags, embed=128):
@@ -256,18 +274,22 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
         return [(n, k) for n, k, _ in eng.op_table(64)]
 
     base = kernels(0)
-    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_f32h2") for _, k in base)
+    assert any(k == "ctx_attn" for _, k in base) and any(k.startswith("igemm_f32h2_") for _, k in base) and any(k.startswith("igemm_f32h2g") for _, k in base)
     assert not any(k.startswith("igemm_f32x3") for _, k in base)
-    exact = kernels(PLAN_F32X3_EXACT)                                       # round 4's plan: the exact three-bf16-piece tile
-    assert [n for n, k in exact if k.startswith("igemm_f32x3")] == [n for n, k in base if k.startswith("igemm_f32h2")]
-    no_x3 = kernels(PLAN_NO_F32X3)                                          # the round-3 plan: Winograd kernels at every batch
-    assert any(k.startswith("igemm_wino") for _, k in no_x3) and not any(k.startswith(("igemm_f32x3", "igemm_f32h2")) for _, k in no_x3)
+    exact = kernels(PLAN_F32X3_EXACT)                                       # round 4's tile for the 3x3 convs: the exact three-bf16-piece split
+    assert [n for n, k in exact if k.startswith("igemm_f32x3")] == [n for n, k in base if k.startswith("igemm_f32h2_")]
+    no_x3 = kernels(PLAN_NO_F32X3)                                          # 3x3 convs on the Winograd kernels at every batch
+    assert any(k.startswith("igemm_wino") for _, k in no_x3) and not any(k.startswith(("igemm_f32x3", "igemm_f32h2_")) for _, k in no_x3)
+    no_g = kernels(PLAN_NO_F32H2_GEMM)                                      # the other convs / linears on the fp32 matrix pipe
+    assert not any(k.startswith("igemm_f32h2g") for _, k in no_g) and [n for n, k in no_g if k.startswith("igemm_f32h2_")] == [n for n, k in base if k.startswith("igemm_f32h2_")]
+    r3 = kernels(PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM)                        # round 3's plan: everything on the fp32 pipe
+    assert not any(k.startswith(("igemm_f32x3", "igemm_f32h2")) for _, k in r3)
     for var in ("CAPF_LIFTER_FUSED", "CAPF_WINO", "CAPF_BF16_RH", "CAPF_WINO_F43", "CAPF_F32X3_MIN_MFLOP"):
         monkeypatch.setenv(var, "0")
     assert kernels(0) == base                                               # the environment does not reach the product plan
     unfused = kernels(PLAN_NO_FUSED_LIFTER)
     assert not any(k in ("ctx_attn", "embed") for _, k in unfused) and any(k == "deform_sample" for _, k in unfused)
-    assert not any(k.startswith(("igemm_wino", "igemm_f32x3", "igemm_f32h2")) for _, k in kernels(PLAN_NO_WINOGRAD))
+    assert not any(k.startswith(("igemm_wino", "igemm_f32x3", "igemm_f32h2_")) for _, k in kernels(PLAN_NO_WINOGRAD))
     with pytest.raises(CapfError):
         kernels(1 << 10)
     # embed_dim_ratio beyond the fused kernels' register / LDS budget: the plan falls back to one kernel per op
@@ -282,14 +304,15 @@ def test_executed_flops_of_winograd_ops_are_half_or_two_thirds_of_the_algorithmi
     # batch 64: the branch convs run the split-fp32 tile -- three fp16 piece products per fp32 product (six bf16 ones under
     # CAPF_PLAN_F32X3_EXACT), counted on the 16-bit pipe
     t64, e64 = eng.op_table(64), eng.op_executed_flops(64)
-    assert any(k.startswith("igemm_f32h2") for _, k, _ in t64)
-    assert all(abs(e / a - 3.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32h2"))
-    from capf.lib import PLAN_NO_F32X3, PLAN_F32X3_EXACT
+    assert any(k.startswith("igemm_f32h2_") for _, k, _ in t64) and any(k.startswith("igemm_f32h2g") for _, k, _ in t64)
+    assert all(abs(e / a - 3.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32h2_"))
+    assert all(3.0 - 1e-9 <= e / a <= 3.6 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32h2g"))        # (K padded to 32)
+    from capf.lib import PLAN_NO_F32H2_GEMM, PLAN_NO_F32X3, PLAN_F32X3_EXACT
     eng_x = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_F32X3_EXACT), device=None)
     t64, e64 = eng_x.op_table(64), eng_x.op_executed_flops(64)
     assert any(k.startswith("igemm_f32x3") for _, k, _ in t64)
     assert all(abs(e / a - 6.0) < 1e-9 for (n, k, a), e in zip(t64, e64) if k.startswith("igemm_f32x3"))
-    eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
+    eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM), device=None)
     table, ex = eng_w.op_table(32), eng_w.op_executed_flops(32)
     seen = set()
     for (name, kern, alg), e in zip(table, ex):

@@ -79,13 +79,13 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
 
 def test_cfg1_layerwise_hrnet32_fp32_batch64():
     k = layerwise("hrnet_32", "fp32", 64, 256, 256, [0, 21, 42, 63])
-    assert any(x.startswith("igemm_f32h2") for x in k)          # (the branch convs: split-fp32 tile from 400 MFLOP per conv, batch >= 6)
+    assert any(x.startswith("igemm_f32h2_") for x in k)          # (the branch convs: split-fp32 tile from 400 MFLOP per conv, batch >= 6)
 
 
 def test_cfg3_layerwise_hrnet32_fp32_batch512():
     """configs[3]'s per-GPU batch: the size at which the Winograd kernel's algorithmic rate reads 1.03 of the nominal peak."""
     k = layerwise("hrnet_32", "fp32", 512, 256, 256, [0, 170, 341, 511])
-    assert any(x.startswith("igemm_f32h2") for x in k)
+    assert any(x.startswith("igemm_f32h2_") for x in k)
 
 
 def test_cfg2_layerwise_hrnet48_bf16_batch256():

@@ -980,7 +980,7 @@ def test_f32x3_engine_path_agrees_with_the_winograd_kernels():
             eng = model.engine_for(img)
         kernels.append(set(k for _, k, _ in eng.op_table(32) if k))
         maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
-    assert any(k.startswith("igemm_f32h2") for k in kernels[0]) and not any(k.startswith(("igemm_f32x3", "igemm_f32h2")) for k in kernels[1])
+    assert any(k.startswith("igemm_f32h2_") for k in kernels[0]) and not any(k.startswith(("igemm_f32x3", "igemm_f32h2_")) for k in kernels[1])
     assert any(k.startswith("igemm_wino") for k in kernels[1])
     for a, b in zip(*maps):
         rel = ((a - b).norm() / b.norm()).item()
@@ -1156,10 +1156,169 @@ def test_f32h2_engine_path_agrees_with_the_exact_three_piece_plan():
             eng = model.engine_for(img)
         kernels.append(set(k for _, k, _ in eng.op_table(32) if k))
         maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
-    assert any(k.startswith("igemm_f32h2") for k in kernels[0]) and not any(k.startswith("igemm_f32x3") for k in kernels[0])
-    assert any(k.startswith("igemm_f32x3") for k in kernels[1]) and not any(k.startswith("igemm_f32h2") for k in kernels[1])
+    assert any(k.startswith("igemm_f32h2_") for k in kernels[0]) and not any(k.startswith("igemm_f32x3") for k in kernels[0])
+    assert any(k.startswith("igemm_f32x3") for k in kernels[1]) and not any(k.startswith("igemm_f32h2_") for k in kernels[1])
     for a, b, c in zip(*maps):
         rel, rel_w = ((a - b).norm() / b.norm()).item(), ((a - c).norm() / c.norm()).item()
         print(f"two-piece vs exact three-piece plan: relative L2 {rel:.2e}   (vs the Winograd plan {rel_w:.2e})")
         assert rel < 2e-6 and rel_w < 2e-5
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * outs[1].abs().max().item()
+
+
+# ---- round 5: the two-fp16-piece arithmetic for every other fp32 conv / linear (csrc/igemm_f32h2.hip) ----
+
+def _h2g_unpack(wp, n, k):
+    """Undo capf_op_pack_f32h2_gemm: [N][Kpad / 32][piece 2][32] fp16 + [N] fp32 inverse scales -> (weights [N, K] fp64, scales [N])."""
+    kpad = (k + 31) // 32 * 32
+    raw = wp.cpu()
+    winv = raw[n * kpad:n * kpad + n].double()
+    t = raw[:n * kpad].view(torch.float16).double().view(n, kpad // 32, 2, 32).sum(dim=2).reshape(n, kpad)
+    return (t * winv.view(-1, 1))[:, :k], winv
+
+
+def _h2g_conv_check(got_nhwc, x, w_fold, bias, res, act, stride, what, direct):
+    ks = w_fold.shape[-1]
+    xd = x.double()
+    want = F.conv2d(xd, w_fold, bias.double().cpu(), stride, ks // 2)
+    mass = F.conv2d(xd.abs(), w_fold.abs(), bias.double().abs().cpu(), stride, ks // 2)
+    if res is not None:
+        want, mass = want + res.double(), mass + res.double().abs()
+    if act:
+        want = F.relu(want)
+    err = ((got_nhwc.double().cpu().permute(0, 3, 1, 2) - want).abs() / mass).max().item()
+    err32 = ((direct.double().cpu().permute(0, 3, 1, 2) - want).abs() / mass).max().item()
+    assert err <= 1e-6, f"{what}: {err:.3e} of the sum of |terms|"
+    assert err <= 2.0 * err32 + 5e-8, f"{what}: {err:.3e} vs {err32:.3e} for the direct fp32 kernel"
+    return err, err32
+
+
+def test_f32h2g_conv_fuzz_against_torch():
+    """1x1 / 3x3 / 5x5 convs, stride 1 and 2, channel counts that are and are not multiples of 32 (block-uniform and per-thread tap walk),
+    ragged M and N tiles, with and without residual / ReLU, through the two-fp16-piece GEMM (csrc/igemm_f32h2.hip) against an fp64 F.conv2d
+    of the same fp32 operands -- 1e-6 of the sum of |terms|, and at most 2 x the error of this library's direct fp32 MFMA kernel on the same
+    problem.  The pack is read back: (piece 0 + piece 1) / scale is within 2^-23 of the fp32 fold the fp32 pack holds."""
+    from capf import lib as capf
+    rng = torch.Generator().manual_seed(20261002)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    worst, worst32 = 0.0, 0.0
+    for case in range(24):
+        ks = (1, 3, 3, 5)[ri(0, 3)]
+        stride = ri(1, 2)
+        ci = 4 * ri(1, 40) if case % 3 else 32 * ri(1, 8)
+        co = 4 * ri(1, 70)
+        H, W, B = ri(3, 36), ri(3, 40), ri(1, 6)
+        act, res = ri(0, 1), bool(ri(0, 1))
+        x = torch.randn(B, ci, H, W, generator=rng) * torch.rand(B, ci, H, W, generator=rng).pow(3)
+        w = torch.randn(co, ci, ks, ks, generator=rng) / (ci * ks * ks) ** 0.5
+        bnp = (torch.rand(co, generator=rng) + 0.5, torch.randn(co, generator=rng) * 0.1, torch.randn(co, generator=rng) * 0.1,
+               torch.rand(co, generator=rng) * 0.4 + 0.8)
+        bn_cuda = tuple(t.cuda() for t in bnp)
+        wd, bd = capf.pack_conv(w.cuda(), bn_cuda)                                   # the fp32 pack: [Cout][Kpad], k = (kh, kw, ci)
+        k = ks * ks * ci
+        w_fold = wd.cpu().double()[:, :k].view(co, ks, ks, ci).permute(0, 3, 1, 2).contiguous()
+        wp, bias = capf.pack_f32h2_gemm(w.cuda(), bn_cuda)
+        assert torch.equal(bias, bd)
+        w_h2, winv = _h2g_unpack(wp, co, k)
+        flat = wd.cpu().double()[:, :k]
+        cmax = flat.abs().amax(dim=1, keepdim=True)
+        assert ((w_h2 - flat).abs() <= 2.0 ** -23 * flat.abs() + 2.0 ** -38 * cmax).all()
+        assert torch.equal(torch.log2(winv), torch.log2(winv).round())
+        pad = ks // 2
+        Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        r = torch.randn(B, co, Ho, Wo, generator=rng) if res else None
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+        rg = r.permute(0, 2, 3, 1).contiguous().cuda() if res else None
+        got = capf.conv_nhwc_f32h2g(xg, wp, bias, ks, stride, act, rg, co)
+        direct = capf.conv_nhwc(xg, wd, bd, ks, stride, act, rg)
+        e, e32 = _h2g_conv_check(got, x, w_fold, bias, r, act, stride, f"h2g conv case {case}: {ci}->{co} k{ks} s{stride} {H}x{W} B{B} act {act} res {res}", direct)
+        worst, worst32 = max(worst, e), max(worst32, e32)
+    print(f"two-fp16-piece GEMM, 24 random convs: worst |error| {worst:.2e} of the sum of |terms| (the direct fp32 MFMA kernel: {worst32:.2e})")
+
+
+def test_f32h2g_grouped_convs_match_single_launches():
+    """The convs of an HRNet fuse layer (1x1 at the low resolutions, 3x3 stride-2 chains) as ONE grid of igemm_f32h2g_group_kernel: bit-identical to
+    the single launches, and against fp64."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(99)
+    B = 7
+    shapes = [(64, 32, 32, 1, 1), (128, 32, 16, 1, 1), (32, 64, 64, 3, 2), (64, 128, 32, 3, 2), (256, 64, 8, 1, 1), (128, 256, 16, 3, 2)]      # (Cin, Cout, HW, ks, stride)
+    probs, refs = [], []
+    for ci, co, hw, ks, st in shapes:
+        x = torch.randn(B, ci, hw, hw, generator=g)
+        w = torch.randn(co, ci, ks, ks, generator=g) / (ci * ks * ks) ** 0.5
+        bnp = tuple(t.cuda() for t in (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+                                       torch.rand(co, generator=g) * 0.4 + 0.8))
+        wd, bd = capf.pack_conv(w.cuda(), bnp)
+        wp, bias = capf.pack_f32h2_gemm(w.cuda(), bnp)
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+        probs.append((xg, wp, bias, ks, st, 0, None, co))
+        refs.append((x, wd, bd, ks, st, ci, co))
+    outs = capf.conv_nhwc_f32h2g_group(probs)
+    for y, pr, (x, wd, bd, ks, st, ci, co) in zip(outs, probs, refs):
+        single = capf.conv_nhwc_f32h2g(pr[0], pr[1], pr[2], ks, st, 0, None, co)
+        assert torch.equal(single, y)
+        w_fold = wd.cpu().double()[:, :ks * ks * ci].view(co, ks, ks, ci).permute(0, 3, 1, 2).contiguous()
+        _h2g_conv_check(y, x, w_fold, bd, None, 0, st, f"grouped h2g {ci}->{co}", capf.conv_nhwc(pr[0], wd, bd, ks, st, 0, None))
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(1088, 640, 1920, 0, False), (1088, 640, 640, 0, True), (1088, 640, 1280, 2, False), (1088, 1280, 640, 0, True),
+                                           (5440, 128, 128, 0, True), (5440, 256, 128, 0, True), (37, 96, 52, 2, True)])
+def test_f32h2g_linear_matches_fp64(M, K, N, act, res):
+    """The lifter's projections at batch 64 (joint blocks: 17 B rows of 640; res blocks: 85 B rows of 128; pose_dformer.py:15-59) and a ragged
+    one: y = act(x W^T + b (+ residual)) on the two-fp16-piece GEMM against fp64 (1e-6 of the sum of |terms|, GELU through its Lipschitz
+    bound) and against this library's fp32 MFMA GEMM on the same problem."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * torch.rand(M, K, generator=g).pow(2)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    wp, _ = capf.pack_f32h2_gemm(w.cuda())
+    w_h2, winv = _h2g_unpack(wp, N, K)
+    cmax = w.double().abs().amax(dim=1, keepdim=True)
+    assert ((w_h2 - w.double()).abs() <= 2.0 ** -23 * w.double().abs() + 2.0 ** -38 * cmax).all()
+    got = capf.linear_f32h2g(x.cuda(), wp, b.cuda(), N, act, r.cuda() if res else None).cpu().double()
+    direct = capf.linear(x.cuda(), w.cuda(), b.cuda(), act, r.cuda() if res else None).cpu().double()
+    pre = x.double() @ w.double().t() + b.double()
+    mass = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    if res:
+        pre, mass = pre + r.double(), mass + r.double().abs()            # (the residual goes in before the activation, as in igemm_f32.hip)
+    want = F.gelu(pre) if act == 2 else pre
+    err, err32 = ((got - want).abs() / mass).max().item(), ((direct - want).abs() / mass).max().item()
+    print(f"h2g linear {M}x{K}->{N} act {act} res {res}: {err:.2e} of the sum of |terms| (fp32 MFMA GEMM: {err32:.2e})")
+    assert err <= 1.2e-6 and err <= 2.0 * err32 + 5e-8
+
+
+def test_f32h2g_engine_path_agrees_with_the_fp32_pipe_gemms():
+    """Batch 32 HRNet-32 fp32: the product plan runs the fuse / transition / lone convs and the lifter's projections on igemm_f32h2g, a plan
+    with CAPF_PLAN_NO_F32H2_GEMM on igemm_f32 (fp32 matrix pipe).  Context maps and poses agree to fp32 roundoff."""
+    import copy, contextlib, io
+    from capf import synth
+    from capf.lib import PLAN_NO_F32H2_GEMM
+    from mvn.models.conpose import CA_PF
+    from mvn.utils.cfg import backbone_preset, config
+    cfg = backbone_preset(copy.deepcopy(config), "hrnet_32")
+    cfg.model.backbone.fix_weights = True
+    img, k2d, kc = synth.synth_inputs(32, 256, 256, seed=19)
+    img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
+    maps, outs, kernels = [], [], []
+    for flags in (0, PLAN_NO_F32H2_GEMM):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = CA_PF(cfg, compute_dtype="fp32", plan_flags=flags).eval()
+        synth.load_synthetic(model, seed=5, bn_mode="random")
+        model = model.cuda()
+        with torch.no_grad():
+            outs.append(model(img, k2d, kc.clone()).clone())
+            eng = model.engine_for(img)
+        kernels.append([k for _, k, _ in eng.op_table(32) if k])
+        maps.append([eng.tensor(f"feat{l}").float().clone() for l in range(4)])
+    assert sum(k.startswith("igemm_f32h2g") for k in kernels[0]) >= 60 and not any(k.startswith("igemm_f32h2g") for k in kernels[1])
+    assert any(k.startswith("igemm_f32<") for k in kernels[1])
+    for a, b in zip(*maps):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"two-fp16-piece GEMM plan vs fp32-pipe GEMM plan: relative L2 {rel:.2e}")
+        assert rel < 2e-6
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * outs[1].abs().max().item()
