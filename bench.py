@@ -562,16 +562,28 @@ def main():
         gemm_alg = sum(e[1] / alg_peak(k) for k, e in acc.items() if k.startswith("igemm")) / 1e12
         # HBM bytes per launch of that kernel: offline PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
         # separate rocprofv3 --pmc runs, tools/summarize_profiles.py), null if not collected for this configuration
-        traffic, tsrc = None, None
-        for tfile, key in ((os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), f"cfg{tag}"),
-                           (os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"), f"cfg{tag}"),
-                           (os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"), f"cfg{tag}"),
-                           (os.path.join(ROOT, "profiles", "r01_hbm_traffic.json"), None)):
-            if traffic is None and tag is not None and os.path.exists(tfile):
-                data = json.load(open(tfile))
-                data = data.get(key, {}) if key else (data if tag == 1 else {})
-                traffic = data.get(dname, {}).get("hbm_bytes_per_launch")
-                tsrc = os.path.relpath(tfile, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None
+        traffic, tsrc, tstale = None, None, None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            from summarize_profiles import csrc_sha
+            sha_now = csrc_sha()
+        except Exception:
+            sha_now = None
+        for rnd in ("r05", "r04", "r03", "r02"):
+            tfile = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
+            if traffic is None and tstale is None and tag is not None and os.path.exists(tfile):
+                data = json.load(open(tfile)).get(f"cfg{tag}", {})
+                got = data.get(dname, {}).get("hbm_bytes_per_launch") if isinstance(data.get(dname), dict) else None
+                if got is None:
+                    continue
+                sha_then = data.get("_csrc_sha")
+                if sha_then is not None and sha_now is not None and sha_then != sha_now:
+                    tstale = (f"{os.path.relpath(tfile, ROOT)} was collected on csrc {sha_then}, this run times csrc {sha_now}: "
+                              f"not reported (re-run tools/profile_round.sh)")
+                    break
+                traffic = got
+                tsrc = (os.path.relpath(tfile, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes" +
+                        (f"; csrc {sha_then}" if sha_then else "; no source hash recorded: an earlier round's file") + ")")
         mfma = {"bound": "mfma", "achieved": round(tflops, 2), "peak": dpeak, "unit": "TFLOP/s", "frac": round(tflops / dpeak, 4)}
         if x3:
             mfma["peak_note"] = ("fp32 results on the bf16 matrix pipe: each fp32 operand = three bf16 pieces (exact), six piece products per fp32 product; "
@@ -582,7 +594,7 @@ def main():
         first, second = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
         roofline = dict(first)
         roofline.update({
-            "kernel": dname, "traffic": traffic, "traffic_source": tsrc, "other_roof": second,
+            "kernel": dname, "traffic": traffic, "traffic_source": tsrc if traffic else tstale, "other_roof": second,
             # `achieved` / `frac` above credit the kernel with the ALGORITHMIC (direct-convolution-equivalent) FLOPs, as SURVEY.md
             # 8(d) prescribes; a Winograd kernel EXECUTES 1/2 (F(4,3)) or 2/3 (F(2,3)) of those multiplies, so the matrix pipe's
             # own utilisation is the second pair: executed FLOPs / duration / peak (an upper bound on SQ_VALU_MFMA_BUSY, which the

@@ -399,4 +399,17 @@ hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int
     return hipGetLastError();
 }
 
+// ---- many small device-to-device copies as ONE launch (the bias vectors of the lifter's packed linears: capf_lifter_params_changed issued
+// 216 hipMemcpyAsync per optimizer step, 0.9 ms of a training step): block b copies segment b of a table that lives in device memory
+__global__ __launch_bounds__(256) void copy_segments_kernel(const CopySegment* __restrict__ tab) {
+    const CopySegment sg = tab[blockIdx.x];
+    for (int i = threadIdx.x; i < sg.n; i += 256) sg.dst[i] = sg.src[i];
+}
+
+hipError_t launch_copy_segments(const CopySegment* table_dev, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(n), dim3(256), 0, s, table_dev);
+    return hipGetLastError();
+}
+
 }  // namespace capf

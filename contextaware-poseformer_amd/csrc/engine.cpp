@@ -33,6 +33,7 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                                        1e-5f, pack_arena + pk.wh_off, nullptr, pk.N, pk.Cin, pk.ks, pk.K, pk.KpadH, s));
     }
     h2g_lifter_dirty = true;
+    std::vector<CopySegment> jobs;                      // the packed linears' bias vectors: one launch for all of them (below)
     for (const Pack& pk : packs) {
         if (pk.direct) continue;
         if (lifter_only && pk.kind == 0) continue;      // conv+BN packs belong to the frozen backbone
@@ -49,6 +50,7 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                 HIP_TRY(launch_pack_conv_bf16_ws(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                                  params[pk.bn_v].ptr, 1e-5f, pack_arena + pk.w3_off, B, pk.N, pk.Cin, s));
         } else if (pk.kind == 0 && pk.wino) {
+            if (!pk.wino_skip)
             HIP_TRY(launch_pack_conv_wino(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
                                           params[pk.bn_v].ptr, 1e-5f, W, B, pk.N, pk.Cin, s, pk.Kpad == 18 * pk.Cin ? 43 : 23));
             HIP_TRY(launch_pack_conv(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr,
@@ -68,7 +70,7 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
                 unsigned short* Wb = reinterpret_cast<unsigned short*>(W) + (size_t)n0 * pk.Kpad;
                 HIP_TRY(launch_pack_conv_bf16(params[pk.w[i]].ptr, nullptr, nullptr, nullptr, nullptr, 0.f, Wb, nullptr, n, pk.K, 1,
                                               pk.Kpad, s));
-                HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+                jobs.push_back(CopySegment{params[pk.b[i]].ptr, B + n0, n, 0});
                 n0 += n;
             }
         } else if (pk.quad) {            // fused lifter kernels: Wq[k / 4][n][4], the linears concatenated along n
@@ -76,7 +78,7 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
             for (int i = 0; i < pk.n_lin; ++i) {
                 const int n = (int)params[pk.w[i]].shape[0];
                 HIP_TRY(launch_pack_linear_quad(params[pk.w[i]].ptr, W, n, pk.K, n0, pk.N, s));
-                HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+                jobs.push_back(CopySegment{params[pk.b[i]].ptr, B + n0, n, 0});
                 n0 += n;
             }
         } else {
@@ -84,10 +86,22 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
             for (int i = 0; i < pk.n_lin; ++i) {
                 const int n = (int)params[pk.w[i]].shape[0];
                 HIP_TRY(launch_pack_linear(params[pk.w[i]].ptr, W + (size_t)n0 * pk.Kpad, n, pk.K, pk.Kpad, s));
-                HIP_TRY(hipMemcpyAsync(B + n0, params[pk.b[i]].ptr, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+                jobs.push_back(CopySegment{params[pk.b[i]].ptr, B + n0, n, 0});
                 n0 += n;
             }
         }
+    }
+    if (!jobs.empty()) {
+        CopySegment* tab_dev = reinterpret_cast<CopySegment*>(pack_arena + bias_tab_off);
+        const bool same = bias_tab_on_device && bias_tab.size() == jobs.size() &&
+                          memcmp(bias_tab.data(), jobs.data(), jobs.size() * sizeof(CopySegment)) == 0;
+        if (!same) {                                    // (parameters moved or first pack: a per-step lifter repack finds the table in place)
+            HIP_TRY(hipStreamSynchronize(s));           // an upload still reading the previous host image must not see it change
+            bias_tab = jobs;
+            HIP_TRY(hipMemcpyAsync(tab_dev, bias_tab.data(), bias_tab.size() * sizeof(CopySegment), hipMemcpyHostToDevice, s));
+            bias_tab_on_device = true;
+        }
+        HIP_TRY(launch_copy_segments(tab_dev, (int)jobs.size(), s));
     }
     packed = true;
     return CAPF_OK;
@@ -135,6 +149,8 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
+    } else if (op.wino && pk.wino_skip) {
+        a.Wp = nullptr;                              // no Winograd layout was packed: only a split-fp32 tile (Wp3) may take this launch
     }
     a.conv = op.conv;
     a.Cin = op.Cin; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo;

@@ -63,6 +63,8 @@ struct Pack {
     size_t wh_off = 0;             // channel scales) at wh_off; KpadH = the direct fp32 layout's padded K
     int KpadH = 0;
     bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
+    bool wino_skip = false;        // ... which no batch up to cfg.max_batch can reach (a split-fp32 tile takes the conv from its first Winograd batch to
+                                   // max_batch): not packed, no arena space; the conv never runs a Winograd kernel (build())
 };
 
 enum OpKind {
@@ -124,6 +126,7 @@ struct TrainLayout {
     Att res[4], joint[4];
     size_t xhh, rsh, yh;
     size_t dX, gA, gB, gC, cat, dU[4], tA, tB, wT, slabs, red;
+    size_t slabs_elems = 0, red_elems = 0;   // capacities of the two scratch areas above (what the weight-gradient slicing may use)
     size_t total;
 };
 
@@ -170,6 +173,9 @@ struct Engine {
     size_t pack_elems = 0;
 
     float* pack_arena = nullptr;   // device, owned
+    size_t bias_tab_off = 0;       // inside the arena: the CopySegment table of the packed linears' bias vectors (launch_copy_segments)
+    std::vector<CopySegment> bias_tab;   // its host image (kept alive for the asynchronous upload); rebuilt by every full repack
+    bool bias_tab_on_device = false;
     float* split_ws = nullptr;     // device, owned: split-K slabs + per-tile counters of the small-batch conv launches
     int* split_cnt = nullptr;
     // the two-chain schedule (lanes == 3) runs two grouped chains CONCURRENTLY: the side chain's split-K convs get slabs and
@@ -189,7 +195,7 @@ struct Engine {
     // A pure function of the op and the batch: the tile's batch range is precomputed per op by build() (no cache, no mutable state --
     // const-handle queries on other threads may ask while a forward is being enqueued)
     bool wino_now(const Op& op, int batch) const {
-        return op.wino && ((batch >= op.x3_lo && batch <= op.x3_hi) || batch >= wino_min_batch);
+        return op.wino && ((batch >= op.x3_lo && batch <= op.x3_hi) || (batch >= wino_min_batch && !packs[op.pack].wino_skip));
     }
     bool wino_f43_cpn = false;
     int wino_f43_min_hw = 0, wino_f43_max_hw = 1 << 30;   // F(4,3) only for maps with min <= H * W <= max pixels

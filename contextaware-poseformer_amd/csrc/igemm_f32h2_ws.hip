@@ -24,7 +24,8 @@ static bool h2_from_args(const GemmArgs& a, H2Problem* q) {
     if ((a.omap.S1 & 3) || (a.omap.off & 3) || (a.res && ((a.rmap.S1 & 3) || (a.rmap.off & 3)))) return false;     // 16-byte pieces
     if ((double)a.M * (double)a.omap.S1 * 4.0 >= 2.0e9 || (a.res && (double)a.M * (double)a.rmap.S1 * 4.0 >= 2.0e9)) return false;
     if (!h2_plan(a.M / (a.H * a.W), a.H, a.W, a.Cin, a.N, 32, q)) return false;
-    if (a.N % 64 == 0 && (long)q->g.tiles_m * (a.N / 64) >= 512) { q->g.NS = 64; q->g.NSL = a.N / 64; }
+    static const long wide_min = [] { const char* e = diag_env("CAPF_H2_WIDE_MIN_TILES"); return e ? atol(e) : 512L; }();      // (diag builds: A/B runs)
+    if (a.N % 64 == 0 && (long)q->g.tiles_m * (a.N / 64) >= wide_min) { q->g.NS = 64; q->g.NSL = a.N / 64; }
     q->x = a.A;
     q->g.wp = reinterpret_cast<const unsigned short*>(a.Wp3);
     q->winv = reinterpret_cast<const float*>(q->g.wp + h2_piece_elems(a.N, a.Cin));

@@ -1368,7 +1368,7 @@ bool gemm_wino_ok(const GemmArgs& a) {
 
 // rewrite a direct-conv problem description into the tile-grid form the tile functions expect; false if out of range
 static bool wino_prepare(GemmArgs& a) {
-    if (!gemm_wino_ok(a)) return false;
+    if (!a.Wp || !gemm_wino_ok(a)) return false;        // (no Winograd pack: the engine skips layouts its plan cannot reach)
     const int px = is43(a) ? 4 : 2;
     const long tiles = (long)(a.M / (a.Ho * a.Wo)) * a.H * (a.W / px);
     if ((double)a.M * (double)a.omap.S1 >= 4.0e9 || tiles > 0x7fffffffL) return false;

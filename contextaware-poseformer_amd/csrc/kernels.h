@@ -274,6 +274,14 @@ hipError_t launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W,
 hipError_t launch_bilinear_resize(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo,
                                   hipStream_t s, int bf16 = 0, const float* add = nullptr);   // out = resize(in) (+ add, same shape as out)
 
+// n small float copies in one launch; the table ({src, dst, n} per segment) is in device memory
+struct CopySegment {
+    const float* src;
+    float* dst;
+    int n, pad;
+};
+hipError_t launch_copy_segments(const CopySegment* table_dev, int n, hipStream_t s);
+
 // ---- lifter -----------------------------------------------------------------------------------
 // kcrop -> ref in place (conpose.py:34-35);  X[b,p,0,:] = coord_embed(k2d[b,p]) + pos[0,p,:]
 hipError_t launch_prep_embed(float* kcrop, const float* k2d, const float* w, const float* bias,

@@ -1001,13 +1001,15 @@ bool Engine::build() {
             if (f32x3_takes(mid, op.H, op.W, op.Cin, op.N)) top = mid; else lo = mid + 1;
         }
         op.x3_lo = lo; op.x3_hi = hi;
+        // the Winograd layout of this conv is dead weight when the tile covers every batch the Winograd kernels could be asked for
+        if (lo <= wino_min_batch && hi >= cfg.max_batch) packs[op.pack].wino_skip = true;
     }
     // pack arena layout
     size_t off = 0;
     for (Pack& pk : packs) {
         if (pk.direct) continue;
         pk.w_off = off;
-        off += round64(pk.bf16 ? ((size_t)pk.N * pk.Kpad + 1) / 2 : (size_t)pk.N * pk.Kpad);
+        off += pk.wino_skip ? 64 : round64(pk.bf16 ? ((size_t)pk.N * pk.Kpad + 1) / 2 : (size_t)pk.N * pk.Kpad);
         if (pk.wino) {
             pk.w2_off = off;
             off += round64((size_t)pk.N * pk.Kpad2);
@@ -1032,6 +1034,13 @@ bool Engine::build() {
             pk.wh_off = off;
             off += round64((size_t)f32h2_gemm_pack_elems(pk.N, pk.KpadH));
         }
+    {   // room for the bias-copy table: one CopySegment per linear of every packed (non-direct) linear pack
+        size_t nseg = 0;
+        for (const Pack& pk : packs)
+            if (pk.kind == 1 && !pk.direct) nseg += (size_t)pk.n_lin;
+        bias_tab_off = off;
+        off += round64(nseg * (sizeof(CopySegment) / sizeof(float)));
+    }
     pack_elems = off;
     return true;
 }

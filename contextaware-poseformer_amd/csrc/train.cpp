@@ -70,8 +70,10 @@ void Engine::train_layout(int B, TrainLayout& L) const {
     L.tA = take(maxNR, (size_t)3 * D * 32);
     L.tB = take(maxNR, (size_t)3 * D * 32);
     L.wT = take(0, (size_t)3 * D * D + 64 * 2 * D);            // largest transposed weight [K][Npad]
-    L.slabs = take(0, (size_t)16 * (3 * D * D + 3 * D));       // split-K slabs of the largest weight gradient (+ its bias gradient)
-    L.red = take(0, (size_t)64 * 3 * D);
+    L.slabs_elems = (size_t)16 * (3 * D * D + 3 * D);          // split-K slabs of the largest weight gradient (+ its bias gradient)
+    L.slabs = take(0, L.slabs_elems);
+    L.red_elems = (size_t)64 * 3 * D;
+    L.red = take(0, L.red_elems);
     L.total = cur;
 }
 
@@ -101,10 +103,12 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
                          int K, const float* Xin, RowMap xmap, const float* W, float* dX, RowMap dxmap, bool acc_dx,
                          float* gW, float* gb) {
     float* red = tw + L.red;
-    const size_t red_elems = (size_t)64 * 3 * cfg.embed_dim_ratio * (cfg.levels + 1);
+    const size_t red_elems = L.red_elems;
     // dW (and db, when it sits right behind dW in the flat gradient -- every nn.Linear's weight / bias pair does) straight from the
     // row-major dY and X: no transposes, no column-reduction launches (wgrad_tn_kernel; 64-multiples and plain row pitches only)
-    if (gW && N % 64 == 0 && K % 64 == 0 && dymap.G == 1 && xmap.G == 1 && (double)rows * (double)std::max(dymap.S1, xmap.S1) * 4.0 < 2.0e9) {
+    // (its operand tiles are 16-byte LDS-DMA loads: row pitches and offsets must be multiples of four elements)
+    if (gW && N % 64 == 0 && K % 64 == 0 && dymap.G == 1 && xmap.G == 1 && ((dymap.S1 | dymap.off | xmap.S1 | xmap.off) & 3) == 0 &&
+        (double)rows * (double)std::max(dymap.S1, xmap.S1) * 4.0 < 2.0e9) {
         const bool bias_here = gb && gb == gW + (long)N * K;
         if (gb && !bias_here) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
         const int tiles = (N / 64) * (K / 64), chunks = (rows + 31) / 32;
@@ -112,7 +116,7 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
         // row slices: ~2048 blocks per launch (four rounds of two per CU, so that a tile count that is no multiple of 256 costs a few per
         // cent, not a half-empty round), at least 16 chunks each, as many as the slab buffer holds -- the small layers (128 x 128:
         // four tiles, 43520 rows) ran 64 blocks of 85 chunks
-        const long slab_cap = (long)16 * (3L * cfg.embed_dim_ratio * (cfg.levels + 1) * cfg.embed_dim_ratio * (cfg.levels + 1) + 3L * cfg.embed_dim_ratio * (cfg.levels + 1));
+        const long slab_cap = (long)L.slabs_elems;                  // (the layout's own number: train_layout)
         int splits = std::max(1, (2048 + tiles - 1) / tiles);
         splits = std::min(splits, std::max(1, chunks / 16));
         splits = (int)std::min<long>(splits, std::max<long>(1, slab_cap / slab));
@@ -286,7 +290,7 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
     float* gA = tw + L.gA;
     float* gB = tw + L.gB;
     float* red = tw + L.red;
-    const size_t red_elems = (size_t)64 * 3 * cfg.embed_dim_ratio * (cfg.levels + 1);
+    const size_t red_elems = L.red_elems;
     auto G = [&](const std::string& n) { return flat + grad_off[param_index.at(n)]; };
     const float* m_ctx = masks;
     const float* m_res = masks ? masks + (size_t)2 * Lv * B : nullptr;

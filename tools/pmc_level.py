@@ -18,7 +18,7 @@ from capf import lib as capf
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kind", default="wino43", choices=["wino43", "wino23", "bf16rh", "bf16ws", "x3"])
+    ap.add_argument("--kind", default="wino43", choices=["wino43", "wino23", "bf16rh", "bf16ws", "x3", "h2"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--branches", default="0,1,2,3")
@@ -39,6 +39,9 @@ def main():
         if a.kind == "x3":
             wp, b = capf.pack_conv_f32x3(w)
             probs.append((x, wp, b, 1, res, c))
+        elif a.kind == "h2":
+            wp, b = capf.pack_conv_f32h2(w)
+            probs.append((x, wp, b, 1, res, c))
         elif ws:
             wp, b = capf.pack_conv_bf16_ws(w)
             probs.append((x.bfloat16(), wp, b, 1, res.bfloat16(), c))
@@ -54,6 +57,9 @@ def main():
         if a.kind == "x3":
             capf.conv_nhwc_f32x3_group(probs)
             return 4
+        if a.kind == "h2":
+            capf.conv_nhwc_f32h2_group(probs)
+            return 5
         if ws:
             capf.conv_nhwc_bf16_ws_group(probs)
             return 3
@@ -71,15 +77,15 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
-    frac = {"wino43": 0.5, "wino23": 2.0 / 3.0, "bf16rh": 1.0, "bf16ws": 1.0, "x3": 6.0}[a.kind]     # x3: six bf16 products per fp32 product
+    frac = {"wino43": 0.5, "wino23": 2.0 / 3.0, "bf16rh": 1.0, "bf16ws": 1.0, "x3": 6.0, "h2": 3.0}[a.kind]     # x3 / h2: six bf16 / three fp16 products per fp32 product
     ex = alg * frac
-    x3 = a.kind == "x3"
+    x3 = a.kind in ("x3", "h2")
     # v_mfma_f32_32x32x2_f32: 4096 FLOP, 64 cycles / SIMD;  v_mfma_f32_32x32x16_bf16: 32768 FLOP, 32 cycles / SIMD
     n_mfma = ex / (32768.0 if (bf or x3) else 4096.0)
     busy = n_mfma * (32 if (bf or x3) else 64)
     peak = 2500.0 if (bf or x3) else 157.3
     print(f"{a.kind} batch {B} branches {sel}: {us:8.1f} us per grouped launch (variant {variant});  algorithmic {alg / 1e9:.2f} GFLOP = "
-          f"{alg / us / 1e6:7.1f} TFLOP/s ({alg / us / 1e6 / (peak / 6.0 if x3 else peak):.3f} of peak),  executed {ex / 1e9:.2f} GFLOP = {ex / us / 1e6:7.1f} TFLOP/s "
+          f"{alg / us / 1e6:7.1f} TFLOP/s ({alg / us / 1e6 / (peak / frac if x3 else peak):.3f} of peak),  executed {ex / 1e9:.2f} GFLOP = {ex / us / 1e6:7.1f} TFLOP/s "
           f"({ex / us / 1e6 / peak:.3f});  {n_mfma / 1e6:.3f} M MFMAs = {busy / 1e6:.1f} M SQ_VALU_MFMA_BUSY_CYCLES expected")
 
 

@@ -70,8 +70,24 @@ def short(name):
     m = re.match(r"(?:void )?capf::igemm_f32_smallc_kernel", name)
     if m:
         return "igemm_f32_smallc<w4,128x64>"
+    m = re.match(r"(?:void )?capf::igemm_f32h2g_kernel<(\d+),", name)
+    if m:
+        return "igemm_f32h2g<conv>" if m.group(1) == "1" else "igemm_f32h2g<rows>"
     m = re.match(r"(?:void )?capf::(\w+?)(?:_kernel)?[<(]", name)
     return m.group(1) if m else name[:60]
+
+
+def csrc_sha():
+    """sha256 over the kernel sources the library is built from (sorted names + contents of csrc/*.hip, *.h, *.cpp, Makefile and include/capf.h):
+    stored beside the HBM traffic of a round so that bench.py can tell whether the counters were collected on the sources it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "contextaware-poseformer_amd", "csrc")
+    files = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile")
+    for f in files + [os.path.join("..", "..", "include", "capf.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -121,6 +137,7 @@ def main():
         if key:           # one file per round, one entry per configuration
             allcfg = json.load(open(dst)) if os.path.exists(dst) else {}
             allcfg[key] = traffic
+            allcfg[key]["_csrc_sha"] = csrc_sha()          # (the sources these counters were collected on; bench.py nulls `traffic` on a mismatch)
             json.dump(allcfg, open(dst, "w"), indent=1, sort_keys=True)
         else:
             json.dump(traffic, open(dst, "w"), indent=1, sort_keys=True)
