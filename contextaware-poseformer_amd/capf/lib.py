@@ -24,6 +24,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_op_conv_f32x3_pack_elems", "capf_op_pack_conv_f32x3", "capf_op_conv_f32x3_group",
     "capf_op_conv_f32h2_pack_elems", "capf_op_pack_conv_f32h2", "capf_op_conv_f32h2_group",
     "capf_abi_version", "capf_op_describe_sized",
+    "capf_jpeg_info", "capf_jpeg_coefficients", "capf_jpeg_decode",
     "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g",
 ]
 
@@ -943,6 +944,55 @@ def warp_affine(frames, mats, output_size):
     rc = lib.capf_warp_affine(_stream(out), _p(ptrs), _p(dims), _p(m), B, out_h, out_w, _p(out))
     if rc:
         raise CapfError(f"capf_warp_affine failed ({rc})")
+    return out
+
+
+def jpeg_info(data):
+    """data: bytes of a JPEG file -> dict(width, height, components, h_samp, v_samp, scratch_bytes); CapfError for what capf_jpeg_decode does
+    not take (progressive, arithmetic, CMYK, ...).  Host code, no GPU."""
+    lib = load_library()
+    lib.capf_jpeg_info.argtypes = [c_char_p, c_size_t] + [POINTER(c_int32)] * 5 + [POINTER(c_size_t)]
+    w, h, nc, hs, vs, sb = c_int32(), c_int32(), c_int32(), c_int32(), c_int32(), c_size_t()
+    rc = lib.capf_jpeg_info(data, len(data), byref(w), byref(h), byref(nc), byref(hs), byref(vs), byref(sb))
+    if rc:
+        raise CapfError(f"capf_jpeg_info: not a JPEG this path decodes ({rc})")
+    return dict(width=w.value, height=h.value, components=nc.value, h_samp=hs.value, v_samp=vs.value, scratch_bytes=sb.value)
+
+
+def jpeg_coefficients(data):
+    """The host half of the decoder: quantised DCT coefficients (natural order) per component, list of int16 numpy arrays
+    [block rows, block cols, 64] over the MCU-padded image.  No GPU."""
+    import numpy as np
+    lib = load_library()
+    info = jpeg_info(data)
+    lib.capf_jpeg_coefficients.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t]
+    hs, vs, nc = info["h_samp"], info["v_samp"], info["components"]
+    mx, my = -(-info["width"] // (8 * hs)), -(-info["height"] // (8 * vs))
+    shapes = [(my * vs, mx * hs)] + [(my, mx)] * (nc - 1)
+    total = sum(a * b * 64 for a, b in shapes)
+    buf = np.zeros(total, np.int16)
+    rc = lib.capf_jpeg_coefficients(data, len(data), buf.ctypes.data_as(c_void_p), total)
+    if rc:
+        raise CapfError(f"capf_jpeg_coefficients failed ({rc})")
+    out, o = [], 0
+    for a, b in shapes:
+        out.append(buf[o:o + a * b * 64].reshape(a, b, 64))
+        o += a * b * 64
+    return out
+
+
+def jpeg_decode(data, device="cuda"):
+    """cv2.imread(..., IMREAD_COLOR) of a baseline JPEG held in memory: bytes -> uint8 CUDA tensor [H, W, 3], BGR (host Huffman decode, GPU
+    IDCT / upsampling / colour conversion; bit-exact against libjpeg-turbo's default decode)."""
+    import torch
+    lib = load_library()
+    info = jpeg_info(data)
+    lib.capf_jpeg_decode.argtypes = [c_void_p, c_char_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
+    out = torch.empty(info["height"], info["width"], 3, dtype=torch.uint8, device=device)
+    scratch = torch.empty(info["scratch_bytes"], dtype=torch.uint8, device=device)
+    rc = lib.capf_jpeg_decode(_stream(out), data, len(data), _p(out), out.stride(0), _p(scratch), scratch.numel())
+    if rc:
+        raise CapfError(f"capf_jpeg_decode failed ({rc})")
     return out
 
 

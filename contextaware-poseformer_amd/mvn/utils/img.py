@@ -25,3 +25,17 @@ def crop_image_batch(images, centers, scales, output_size):
     images: list of uint8 CUDA tensors [H_i, W_i, 3]; centers / scales: per-frame (x, y) pairs."""
     mats = np.stack([get_affine_transform(c, s, 0, output_size) for c, s in zip(centers, scales)])
     return _capf.warp_affine(list(images), mats, output_size)
+
+
+def imread(path_or_bytes, device="cuda"):
+    """cv2.imread(path, cv2.IMREAD_COLOR | cv2.IMREAD_IGNORE_ORIENTATION) of Human36M.__getitem__ (datasets/human36m.py:292-295) for a baseline
+    JPEG: uint8 CUDA tensor [H, W, 3], BGR.  The host walks the Huffman stream, the GPU does the rest (capf_jpeg_decode); files this path does
+    not take (progressive, CMYK, ...) raise CapfError -- there is no CPU fallback in this package."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    return _capf.jpeg_decode(bytes(data), device)
+
+
+def load_and_crop_batch(paths_or_bytes, centers, scales, output_size, device="cuda"):
+    """The whole per-sample image path of Human36M.__getitem__ (human36m.py:292-300) for a batch: decode every frame on the GPU, then ONE
+    warp launch for all crops.  Returns uint8 CUDA [B, output_size[1], output_size[0], 3], what the prefetcher (capf_preprocess) consumes."""
+    return crop_image_batch([imread(p, device) for p in paths_or_bytes], centers, scales, output_size)

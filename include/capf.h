@@ -403,6 +403,23 @@ int capf_keypoints_loss(void* stream, int mode, const float* pred, const float* 
  *   row pitch in bytes; m: device double [batch][6] FORWARD matrices; out: uint8 [batch, out_h, out_w, 3].
  *   OpenCV's fixed-point arithmetic (10-bit coordinates, 5-bit fractions, 15-bit weights) is restated from its
  *   published algorithm -- OpenCV is absent from the build container, so this row's parity is unpinned. */
+/* capf_jpeg_info / capf_jpeg_decode: the image decode in FRONT of that crop -- cv2.imread(path, IMREAD_COLOR | IMREAD_IGNORE_ORIENTATION) of
+ *   Human36M.__getitem__ (human36m.py:292-295) for a baseline JPEG held in host memory: uint8 BGR [height][width][3] on the device, ready
+ *   for capf_warp_affine.  The host walks the entropy-coded segment (Huffman decode, DC prediction, restart markers); dequantisation +
+ *   inverse DCT, chroma upsampling and YCbCr -> BGR run on the GPU.  The arithmetic is libjpeg's default decode path restated -- "islow"
+ *   integer IDCT (jidctint.c), "fancy" triangle upsampling (jdsample.c), 16-bit fixed point colour conversion (jdcolor.c) -- which is what
+ *   cv2.imread and Pillow run: the result is bit-exact against Pillow's libjpeg-turbo decode (tests/test_jpeg.py; OpenCV itself is not
+ *   in the image).  Baseline / extended sequential Huffman, 8 bit, grey or YCbCr in one interleaved scan, 4:4:4 / 4:2:2 / 4:2:0, restart
+ *   intervals; anything else (progressive, arithmetic, CMYK, other sampling) returns CAPF_ERR_UNSUPPORTED and the caller keeps its host
+ *   decoder.  capf_jpeg_info: geometry + the scratch bytes capf_jpeg_decode needs (device memory, 16-byte aligned).  capf_jpeg_decode
+ *   enqueues on `stream` and waits for the coefficient upload (it reuses a per-thread host staging buffer): a loader-side call, never
+ *   part of capf_forward.  capf_jpeg_coefficients: the host half alone -- quantised coefficients in natural order, component after
+ *   component, blocks [rows][cols][64] over the MCU-padded image (no GPU needed).                                                      */
+int capf_jpeg_info(const uint8_t* data, size_t n_bytes, int32_t* width, int32_t* height, int32_t* components, int32_t* h_samp,
+                   int32_t* v_samp, size_t* scratch_bytes);
+int capf_jpeg_coefficients(const uint8_t* data, size_t n_bytes, int16_t* coef, size_t coef_elems);
+int capf_jpeg_decode(void* stream, const uint8_t* data, size_t n_bytes, uint8_t* out_bgr, size_t out_pitch_bytes, void* scratch,
+                     size_t scratch_bytes);
 int capf_affine_from_center_scale(const double center[2], const double scale[2], int out_w, int out_h, double m[6]);
 int capf_warp_affine(void* stream, const uint8_t* const* frames, const int32_t* dims, const double* m, int batch,
                      int out_h, int out_w, uint8_t* out);
