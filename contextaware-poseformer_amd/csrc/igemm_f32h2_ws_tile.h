@@ -33,7 +33,8 @@ namespace capf {
 
 static constexpr int H2_HP = WS_MAX_PP * 16 + 64;           // one half-plane (16 B per staged pixel) + 64 B: the two halves of a pixel 16 banks apart
 static constexpr int H2_A_BYTES = 4 * H2_HP;
-static constexpr int H2_AUX_BYTES = 16 + 2 * 64 * 4;        // the four wave maxima of the chunk being split; the slice's inverse weight scales and biases
+static constexpr int H2_AUX_BYTES = 16 + 2 * 64 * 4 + 4 * 64 * 4;   // the four wave maxima of the chunk being split; the slice's inverse weight scales and
+                                                                   // biases; per wave, which tile pixel each of its 2 x 32 MFMA columns is (epilogue)
 inline constexpr int h2_w_bytes(int NS) { return 2 * 9 * NS * 32; }
 inline constexpr int h2_lds_bytes(int NS) { return H2_A_BYTES + h2_w_bytes(NS) + H2_AUX_BYTES; }
 
@@ -150,6 +151,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     int* const aux = reinterpret_cast<int*>(lds + H2_A_BYTES + W2_BYTES);
     float* const aux_w = reinterpret_cast<float*>(aux + 4);      // [NS] 1 / weight scale of the slice's channels
     float* const aux_b = aux_w + 64;                             // [NS] their biases
+    int* const aux_px = reinterpret_cast<int*>(aux_b + 64) + wave * 64;   // [2][32] this wave's column -> tile pixel table
     auto publish_max = [&]() {                             // this wave's maximum of the loaded chunk -> aux[wave]
         float m = 0.f;
 #pragma unroll
@@ -250,6 +252,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
         for (int kh = 0; kh < 3; ++kh) a_addr[i][kh] = (unsigned)((pix0 + kh * p.PW) * 16 + fhalf * HP);
     }
     const unsigned b_addr = (unsigned)(H2_A_BYTES + frow * 32 + ((fhalf ^ ((frow >> 3) & 1)) << 4));
+    if (fhalf == 0) { aux_px[frow] = pl_i[0]; aux_px[32 + frow] = pl_i[1]; }      // (read after the barriers of the first chunk)
 
     const int Mi = (int)p.M;
     const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(q.res ? (void*)q.res : (void*)q.y, 0, q.res ? 0x7FFFFF00u : 0u, 0x00020000);
@@ -279,22 +282,31 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
 
     // ---- epilogue addressing: lane = 4 consecutive channels (register group g) of its pixel; the residual rows are requested before
     // the last chunk's MFMAs
-    auto piece_off = [&](int i, int j, int g, int ld) -> unsigned {
-        const int pl = pl_i[i], n = slice * NS + j * 32 + 8 * g + 4 * fhalf;
+    // Coalesced layout of the epilogue: lane (er, ec) = 8 consecutive channels (32 B) of block row h * 16 + er, so that four lanes cover a
+    // pixel's 128 contiguous bytes and a wave instruction touches 16 full lines -- as pixel-per-lane (what the accumulators are) a 16-byte
+    // store / residual load is 64 requests of 16 B at a stride of ld * 4 bytes.  The accumulators cross through 4.5 KiB of per-wave LDS
+    // scratch (over the dead pixel planes) after the K loop; which pixel a block row is comes from aux_px.
+    const int er = lane >> 2, ec = (lane & 3) * 8;
+    auto row_off = [&](int pl, int j, int q, int ld) -> unsigned {        // quad q (4 channels) of the lane's 8
+        const int n = slice * NS + j * 32 + ec + 4 * q;
         const int gp = gp0 + pl;
         return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(gp * ld + n) * 4u : OOB;
     };
-    ws_f32x4 rr[2][TN][4];
+    ws_f32x4 rr[2][TN][4];                                  // [pixel block][channel block][h * 2 + q]
     ws_f16x8 af[2][2][2], bfr[2][2][TN];
     for (int cc = 0; cc < NCC; ++cc) {
         if (cc == NCC - 1) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int h = 0; h < 2; ++h) {
+                    const int pl = aux_px[i * 32 + h * 16 + er];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        rr[i][j][g] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, piece_off(i, j, g, p.ldr), 0, 0));
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            rr[i][j][h * 2 + q] = __builtin_bit_cast(ws_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, row_off(pl, j, q, p.ldr), 0, 0));
+                }
         }
         auto read_frags = [&](int t, int buf) {            // (in the order the products below consume them)
 #pragma unroll
@@ -354,27 +366,48 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     }
 
     // ---- epilogue: y = acc / (pixel scale * the channel's weight scale) + bias (+ residual), ReLU
-    // (register 4 g + e of channel block j = channel slice * NS + 32 j + 8 g + 4 fhalf + e)
+    // (accumulator register 4 g + e of channel block j = channel slice * NS + 32 j + 8 g + 4 fhalf + e of the lane's pixel)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // every wave is done with the planes: the scratch below overlays them
+    constexpr int EPS = 36;
+    float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
     const float inv_s = __int_as_float((254 - sb) << 23);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+        ws_f32x4 wv[2], bv[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            ws_f32x4 wv = *reinterpret_cast<const ws_f32x4*>(aux_w + j * 32 + 8 * g + 4 * fhalf);
-            const ws_f32x4 bv = *reinterpret_cast<const ws_f32x4*>(aux_b + j * 32 + 8 * g + 4 * fhalf);
+        for (int q = 0; q < 2; ++q) {
+            wv[q] = *reinterpret_cast<const ws_f32x4*>(aux_w + j * 32 + ec + 4 * q);
+            bv[q] = *reinterpret_cast<const ws_f32x4*>(aux_b + j * 32 + ec + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) wv[e] *= inv_s;
+            for (int e = 0; e < 4; ++e) wv[q][e] *= inv_s;
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ws_f32x4 o;
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = fmaf(acc[i][j][4 * g + e], wv[e], bv[e] + rr[i][j][g][e]);
-                    o[e] = p.relu ? fmaxf(t, 0.f) : t;
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<ws_f32x4*>(&ep[frow * EPS + 8 * g + 4 * fhalf]) =
+                    ws_f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = h * 16 + er;
+                const int pl = aux_px[i * 32 + row];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const ws_f32x4 x = *reinterpret_cast<const ws_f32x4*>(&ep[row * EPS + ec + 4 * q]);
+                    ws_f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(x[e], wv[q][e], bv[q][e] + rr[i][j][h * 2 + q][e]);
+                        o[e] = p.relu ? fmaxf(t, 0.f) : t;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), rs_out, row_off(pl, j, q, p.ldy), 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), rs_out, piece_off(i, j, g, p.ldy), 0, 0);
             }
         }
+    }
 }
 
 #endif
