@@ -38,11 +38,6 @@ static bool h2_from_args(const GemmArgs& a, H2Problem* q) {
     return true;
 }
 
-bool gemm_f32h2_ok(const GemmArgs& a) {
-    H2Problem q;
-    return h2_from_args(a, &q);
-}
-
 struct H2GroupArgs {
     H2Problem g[MAXG];
     int start[MAXG + 1];
@@ -106,15 +101,6 @@ hipError_t launch_gemm_f32h2_group(const GemmArgs* list, int n, hipStream_t s) {
     if (nw) { const hipError_t e = h2_launch<2>(wide, nw, s); if (e != hipSuccess) return e; }
     if (nn) { const hipError_t e = h2_launch<1>(narrow, nn, s); if (e != hipSuccess) return e; }
     return hipSuccess;
-}
-
-int gemm_f32h2_launches(const GemmArgs* list, int n) {       // how many grids launch_gemm_f32h2_group issues for this list (1 or 2)
-    int nn = 0, nw = 0;
-    for (int i = 0; i < n; ++i) {
-        H2Problem q;
-        if (h2_from_args(list[i], &q)) (q.g.NS == 64 ? nw : nn)++;
-    }
-    return (nn > 0) + (nw > 0);
 }
 
 const char* gemm_f32h2_kernel_name(const GemmArgs&) { return "igemm_f32h2_group_ws"; }

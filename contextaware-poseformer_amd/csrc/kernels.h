@@ -225,7 +225,6 @@ hipError_t launch_pack_conv_f32x3(const float* w, const float* gamma, const floa
 // (launch_gemm_f32x3_group forwards them).  Weights packed by launch_pack_conv_f32h2 (f32h2_pack_elems(Cout, Cin) 16-bit elements)
 long f32h2_pack_elems(int Cout, int Cin);
 hipError_t launch_gemm_f32h2_group(const GemmArgs* list, int n, hipStream_t s);
-int gemm_f32h2_launches(const GemmArgs* list, int n);   // grids that launch issues: the 32- and the 64-channel tiles of a level go out separately
 const char* gemm_f32h2_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_f32h2(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                   void* Wp_f16, float* bias, int Cout, int Cin, hipStream_t s);
