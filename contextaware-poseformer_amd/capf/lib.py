@@ -16,7 +16,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_set_param", "capf_params_changed", "capf_lifter_params_changed", "capf_workspace_bytes", "capf_set_workspace", "capf_forward",
     "capf_backbone_forward", "capf_lifter_forward", "capf_set_debug", "capf_set_lanes", "capf_op_conv_group", "capf_affine_from_center_scale", "capf_warp_affine", "capf_op_schedule", "capf_forward_profile_launches", "capf_forward_profile_variants", "capf_tensor", "capf_forward_stats",
     "capf_num_ops", "capf_op_info", "capf_forward_profile", "capf_op_pack_conv", "capf_op_conv", "capf_op_linear",
-    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_op_conv_bf16_group", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_mpjpe", "capf_adamw_step",
+    "capf_preprocess", "capf_fliptest_fuse", "capf_op_pack_conv_bf16", "capf_op_conv_bf16", "capf_op_conv_bf16_rh_width", "capf_op_pack_conv_bf16_rh", "capf_op_conv_bf16_rh", "capf_op_conv_bf16_group", "capf_forward_train", "capf_backward", "capf_grad_elems", "capf_grad_info", "capf_train_h2_matrices", "capf_mpjpe", "capf_adamw_step",
     "capf_pose_errors", "capf_segment_sums", "capf_keypoints_loss", "capf_train_generation", "capf_max_batch", "capf_op_bytes", "capf_op_linear_bf16", "capf_op_pack_conv_wino", "capf_op_conv_wino", "capf_op_conv_wino_group",
     "capf_op_bilinear_corners", "capf_mpjpe_nd", "capf_op_executed_flops",
     "capf_forward_prefix", "capf_op_describe", "capf_op_tensor",
@@ -116,6 +116,8 @@ def load_library():
     lib.capf_grad_elems.argtypes = [H]
     lib.capf_grad_elems.restype = c_int64
     lib.capf_grad_info.argtypes = [H, c_int, POINTER(c_int64)]
+    lib.capf_train_h2_matrices.argtypes = [H]
+    lib.capf_train_h2_matrices.restype = c_int
     lib.capf_mpjpe.argtypes = [P, P, P, c_int, P, P, c_float]
     lib.capf_mpjpe_nd.argtypes = [P, P, P, c_int, c_int, P, P, c_float]
     lib.capf_adamw_step.argtypes = [P, P, P, P, P, c_int64] + [c_float] * 5 + [c_int, c_float]

@@ -695,6 +695,8 @@ int64_t capf_train_generation(const capf_handle* h) { return h ? h->e.train_gene
 
 int64_t capf_grad_elems(const capf_handle* h) { return h ? h->e.grad_elems : -1; }
 
+int capf_train_h2_matrices(const capf_handle* h) { return h ? (int)h->e.t_h2_specs.size() : 0; }
+
 int capf_grad_info(const capf_handle* h, int index, int64_t* offset) {
     if (!h || index < 0 || index >= (int)h->e.params.size() || !offset) return CAPF_ERR_INVALID;
     *offset = h->e.grad_off[index];

@@ -126,6 +126,7 @@ struct TrainLayout {
     Att res[4], joint[4];
     size_t xhh, rsh, yh;
     size_t dX, gA, gB, gC, cat, dU[4], tA, tB, wT, slabs, red;
+    size_t h2w, h2max;                       // the step's weights as two-fp16-piece packs (W and W^T: Engine::t_h2_specs), and their maxima scratch
     size_t slabs_elems = 0, red_elems = 0;   // capacities of the two scratch areas above (what the weight-gradient slicing may use)
     size_t total;
 };
@@ -248,14 +249,28 @@ struct Engine {
     long grad_elems = 0;
     int train_batch = 0;                 // batch of the forward_train whose activations are still in the workspace (0: none)
     int64_t train_generation = 0;        // bumped by every run that (over)writes the workspace
-    void invalidate_train() { train_batch = 0; ++train_generation; }
+    void invalidate_train() { train_batch = 0; ++train_generation; t_h2_base = nullptr; }
     int batch_limit = 0;                 // largest batch the 32-bit tensor addressing of the kernels allows (build())
     void train_layout(int B, TrainLayout& L) const;
     size_t train_elems(int B) const;
     int forward_train(hipStream_t s, int B, const float* masks);
     int backward(hipStream_t s, int B, const float* dOut, float* flat_grad, const float* masks);
     int t_gemm(hipStream_t s, const float* A, RowMap amap, int M, int N, int K, const float* W, int Kpad, const float* bias,
-               float* out, RowMap omap, const float* res, RowMap rmap, int act, const float* rscale, int rs_div);
+               float* out, RowMap omap, const float* res, RowMap rmap, int act, const float* rscale, int rs_div, const float* Wh2 = nullptr);
+    // The lifter's linears on the two-fp16-piece GEMM during a training step (forward: y = x W^T, backward: dX = dY W): which matrices,
+    // where their packs sit in the training region (offsets from TrainLayout::h2w), and the table the pack launch reads (kernels.h)
+    struct H2TrainSpec { int param, pack; int N, K, ld; bool fwd, bwd; };   // source: parameter `param`, or (param < 0) the row pack `pack`
+    std::vector<H2TrainSpec> t_h2_specs;
+    std::vector<H2TrainW> t_h2_tab;      // host image of the device table (offsets filled by t_h2_plan, pointers by t_h2_prepare)
+    std::map<const float*, int> t_h2_index;
+    size_t t_h2_tab_off = 0;             // inside the pack arena
+    size_t t_h2_elems = 0, t_h2_max_elems = 0;
+    int t_h2_tiles = 0;
+    bool t_h2_on_device = false;
+    float* t_h2_base = nullptr;          // this step's packs (set by t_h2_prepare; nullptr: the step runs on the fp32 matrix pipe)
+    void t_h2_plan();
+    int t_h2_prepare(hipStream_t s, const TrainLayout& L, float* tw, int B);
+    const float* t_h2_pack(const float* W, bool transposed) const;
     int t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const float* dY, RowMap dymap, int rows, int N, int K,
                      const float* Xin, RowMap xmap, const float* W, float* dX, RowMap dxmap, bool acc_dx, float* gW, float* gb);
 

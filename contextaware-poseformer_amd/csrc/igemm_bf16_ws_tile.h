@@ -62,9 +62,14 @@ struct WsProblem {
 };
 
 // tile geometry for a conv; false = this tile cannot take it (the caller keeps the row-halo / direct kernel)
-inline bool ws_plan(int B, int H, int W, int C, int N, WsProblem* p) {
+// (tile_relative: the kernel addresses x / y / res from per-tile bases -- only the pixel count has to fit 31 bits)
+inline bool ws_plan(int B, int H, int W, int C, int N, WsProblem* p, bool tile_relative = false) {
     if (B <= 0 || H <= 0 || W <= 0 || C % 16 != 0 || N % 8 != 0 || W > WS_MAX_P) return false;
-    if ((double)B * H * W * C * 2.0 >= 2.0e9 || (double)B * H * W * N * 2.0 >= 2.0e9) return false;
+    if (tile_relative) {
+        if ((double)B * H * W >= 2.0e9) return false;
+    } else if ((double)B * H * W * C * 2.0 >= 2.0e9 || (double)B * H * W * N * 2.0 >= 2.0e9) {
+        return false;
+    }
     const int TR = WS_MAX_P / W;
     int RH = 0, G = 1;
     if (TR >= H) {

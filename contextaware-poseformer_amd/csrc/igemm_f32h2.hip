@@ -232,6 +232,7 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     long o_row[TM], r_row[TM];
     bool m_ok[TM];
+    float rs[TM];                                           // per-row scale of the branch output (DropPath keep mask / keep_prob), 1 without
     g2_f32x4 bv[TN][4], wv[TN][4], rv[TM][TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -249,8 +250,9 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + (lane & 31);
         m_ok[i] = full || m < p.M;
-        o_row[i] = 0; r_row[i] = 0;
+        o_row[i] = 0; r_row[i] = 0; rs[i] = 1.0f;
         if (m_ok[i]) {
+            if (p.rscale) rs[i] = p.rscale[m / p.rs_div];
             o_row[i] = PLAIN ? (long)m * p.omap.S1 + p.omap.off : g2_rowmap(p.omap, m);
             if (p.res) r_row[i] = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : g2_rowmap(p.rmap, m);
         }
@@ -274,7 +276,7 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
                 g2_f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(acc[i][j][4 * g + e], wv[j][g][e] * inv_s, bv[j][g][e]) + rv[i][j][g][e];
+                    float t = fmaf(fmaf(acc[i][j][4 * g + e], wv[j][g][e] * inv_s, bv[j][g][e]), rs[i], rv[i][j][g][e]);
                     if (p.act == ACT_GELU) t = g2_gelu(t);
                     if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
                     v[e] = t;
@@ -331,13 +333,13 @@ __global__ __launch_bounds__(256, 3) void igemm_f32h2g_group_kernel(G2GroupArgs 
 static bool g2_plain(const GemmArgs& a) { return a.omap.G == 1 && (!a.res || a.rmap.G == 1); }
 
 // What this kernel takes (a function of the problem alone): fp32 conv (any ks <= 5 / stride / pad, NHWC) or rows-mode GEMM with
-// K % 32 == 0 staged rows, N % 4 == 0, 16-byte aligned output / residual rows, no LayerNorm fold, no DropPath row scale, no split-K
+// K % 32 == 0 staged rows, N % 4 == 0, 16-byte aligned output / residual rows, no LayerNorm fold, no split-K
 bool gemm_f32h2g_ok(const GemmArgs& a) {
-    if (!a.Wh2 || a.out_bf16 || a.rscale || a.ln_g || a.splits > 1 || a.M <= 0 || a.N <= 0 || (a.N & 3) || a.Kpad % G2_BK != 0) return false;
+    if (!a.Wh2 || a.out_bf16 || a.ln_g || a.splits > 1 || a.M <= 0 || a.N <= 0 || (a.N & 3) || a.Kpad % G2_BK != 0) return false;
     if (a.act == ACT_GELU && a.conv) return false;
     if (a.conv) {
         if (a.ks < 1 || a.ks > 5 || a.Cin % 4 != 0 || a.K != a.ks * a.ks * a.Cin || a.Ho <= 0 || a.Wo <= 0) return false;
-        if ((double)a.M / (a.Ho * a.Wo) * a.H * a.W * a.Cin * 4.0 >= 2.0e9) return false;
+        if ((double)a.H * a.W * a.Cin * 4.0 * 3.0 >= 2.0e9) return false;    // (input offsets count from the tile's first pixel: one tile spans < 2 frames)
         if (a.omap.G != 1 || (a.res && a.rmap.G != 1)) return false;
     } else {
         if (a.K % 4 != 0 || a.amap.G < 1 || (a.amap.S1 & 3) || (a.amap.S2 & 3) || (a.amap.off & 3)) return false;
@@ -370,6 +372,7 @@ hipError_t launch_gemm_f32h2g(const GemmArgs& a_in, hipStream_t s) {
     if (!gemm_f32h2g_ok(a_in)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.Wp = a.Wh2;
+    if (a.rs_div <= 0) a.rs_div = 1;
     g2_fill(a);
     const int cfg = g2_cfg(a), tiles = g2_tiles(a, cfg);
     const bool plain = g2_plain(a);
@@ -486,6 +489,102 @@ hipError_t launch_pack_f32h2_gemm_rows(const float* w, float* Wp, int n0, int n,
     hipLaunchKernelGGL(g2_pack_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, s, w, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0.f, reinterpret_cast<unsigned short*>(Wp + (long)n0 * Kpad), winv,
                        (float*)nullptr, n, 0, 0, K, Kpad, total);
+    return hipGetLastError();
+}
+
+// ---- the training step's weights (train.cpp): every nn.Linear of the lifter as W (forward) AND as W^T (input gradient), all matrices of
+// the step in three launches off one table.  A block = one 32 x 32 tile of one W: pass 1 leaves the row and column maxima (bit patterns
+// of non-negative floats order like integers: atomicMax, order-independent), pass 2 scales by the row's / column's power of two, splits
+// and writes the tile into the forward pack and -- across 4 KiB of LDS -- into the transposed one, 64 contiguous bytes per row and piece.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const H2TrainW& g2_find(const H2TrainW* __restrict__ tab, int n, int tile) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+    }
+    return tab[lo];
+}
+#endif
+
+template <int PASS>
+__global__ __launch_bounds__(256) void g2_train_pack_kernel(const H2TrainW* __restrict__ tab, int n, float* __restrict__ base, int* __restrict__ maxima) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float tile[32][33];
+    const H2TrainW e = g2_find(tab, n, (int)blockIdx.x);
+    const int t = (int)blockIdx.x - e.tile_start, tk_n = (e.K + 31) >> 5;
+    const int tn = t / tk_n, tk = t - tn * tk_n;
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const int nn = tn * 32 + r, k0 = tk * 32 + q * 4;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (nn < e.N && k0 + i < e.K) ? e.w[(long)nn * e.ld + k0 + i] : 0.f;
+    int* rowmax = maxima + e.max_off;
+    int* colmax = rowmax + e.N;
+    if (PASS == 0) {
+        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (q == 0 && nn < e.N) atomicMax(&rowmax[nn], __float_as_int(m));
+        if (e.bwd_off >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[r][q * 4 + i] = fabsf(v[i]);
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                float c = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 32; ++rr) c = fmaxf(c, tile[rr][threadIdx.x]);
+                const int k = tk * 32 + (int)threadIdx.x;
+                if (k < e.K) atomicMax(&colmax[k], __float_as_int(c));
+            }
+        }
+    } else {
+        auto split_store = [](unsigned short* dst, const float* x, float sc) {       // four values -> 4 + 4 fp16 (piece 1 sits 32 halves on)
+            unsigned short p0[4], p1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y = x[i] * sc;
+                const _Float16 a = (_Float16)y;
+                const _Float16 b = (_Float16)(y - (float)a);
+                p0[i] = __builtin_bit_cast(unsigned short, a);
+                p1[i] = __builtin_bit_cast(unsigned short, b);
+            }
+            *reinterpret_cast<uint2*>(dst) = uint2{(unsigned)p0[0] | ((unsigned)p0[1] << 16), (unsigned)p0[2] | ((unsigned)p0[3] << 16)};
+            *reinterpret_cast<uint2*>(dst + 32) = uint2{(unsigned)p1[0] | ((unsigned)p1[1] << 16), (unsigned)p1[2] | ((unsigned)p1[3] << 16)};
+        };
+        if (e.fwd_off >= 0 && nn < e.N) {
+            const int Kpad = tk_n * 32;
+            const int sb = h2_scale_exp(rowmax[nn]);
+            float* fw = base + e.fwd_off;
+            split_store(reinterpret_cast<unsigned short*>(fw) + ((long)nn * tk_n + tk) * 64 + q * 4, v, __int_as_float(sb << 23));
+            if (tk == 0 && q == 0) fw[(long)e.N * Kpad + nn] = __int_as_float((254 - sb) << 23);
+        }
+        if (e.bwd_off >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[r][q * 4 + i] = v[i];
+            __syncthreads();
+            const int k = tk * 32 + r;                       // this thread: row k of W^T, its columns (n) tn * 32 + 4 q ..
+            if (k < e.K) {
+                const int tn_n = (e.N + 31) >> 5, Np = tn_n * 32;
+                const int sb = h2_scale_exp(colmax[k]);
+                float x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = tile[q * 4 + i][r];
+                float* bw = base + e.bwd_off;
+                split_store(reinterpret_cast<unsigned short*>(bw) + ((long)k * tn_n + tn) * 64 + q * 4, x, __int_as_float(sb << 23));
+                if (tn == 0 && q == 0) bw[(long)e.K * Np + k] = __int_as_float((254 - sb) << 23);
+            }
+        }
+    }
+#endif
+}
+
+hipError_t launch_pack_f32h2_train(const H2TrainW* tab_dev, int n, int tiles, float* base, int* maxima, long maxima_elems, hipStream_t s) {
+    if (n <= 0 || tiles <= 0) return hipSuccess;
+    hipError_t r = hipMemsetAsync(maxima, 0, sizeof(int) * (size_t)maxima_elems, s);
+    if (r != hipSuccess) return r;
+    hipLaunchKernelGGL(g2_train_pack_kernel<0>, dim3(tiles), dim3(256), 0, s, tab_dev, n, base, maxima);
+    hipLaunchKernelGGL(g2_train_pack_kernel<1>, dim3(tiles), dim3(256), 0, s, tab_dev, n, base, maxima);
     return hipGetLastError();
 }
 

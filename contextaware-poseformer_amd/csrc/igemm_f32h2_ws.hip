@@ -22,7 +22,7 @@ static bool h2_from_args(const GemmArgs& a, H2Problem* q) {
         a.omap.G != 1 || (a.res && a.rmap.G != 1) || a.M <= 0 || a.H <= 0 || a.W <= 0 || a.M % (a.H * a.W) != 0)
         return false;
     if ((a.omap.S1 & 3) || (a.omap.off & 3) || (a.res && ((a.rmap.S1 & 3) || (a.rmap.off & 3)))) return false;     // 16-byte pieces
-    if ((double)a.M * (double)a.omap.S1 * 4.0 >= 2.0e9 || (a.res && (double)a.M * (double)a.rmap.S1 * 4.0 >= 2.0e9)) return false;
+    if ((double)WS_MAX_P * (double)a.omap.S1 * 4.0 >= 2.0e9 || (a.res && (double)WS_MAX_P * (double)a.rmap.S1 * 4.0 >= 2.0e9)) return false;   // (one tile's rows)
     if (!h2_plan(a.M / (a.H * a.W), a.H, a.W, a.Cin, a.N, 32, q)) return false;
     static const long wide_min = [] { const char* e = diag_env("CAPF_H2_WIDE_MIN_TILES"); return e ? atol(e) : 512L; }();      // (diag builds: A/B runs)
     if (a.N % 64 == 0 && (long)q->g.tiles_m * (a.N / 64) >= wide_min) { q->g.NS = 64; q->g.NSL = a.N / 64; }
@@ -36,6 +36,15 @@ static bool h2_from_args(const GemmArgs& a, H2Problem* q) {
     q->g.ldr = a.res ? (int)a.rmap.S1 : (int)a.omap.S1;
     q->g.relu = a.act == ACT_RELU;
     return true;
+}
+
+bool gemm_f32h2_ok(const GemmArgs& a) {
+    H2Problem q;
+    return h2_from_args(a, &q);
+}
+bool f32h2_shape_ok(int B, int H, int W, int Cin, int Cout) {
+    H2Problem q;
+    return h2_plan(B, H, W, Cin, Cout, 32, &q);
 }
 
 struct H2GroupArgs {

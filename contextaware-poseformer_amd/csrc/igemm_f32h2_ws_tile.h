@@ -52,9 +52,11 @@ inline long h2_piece_elems(int N, int C) { return (long)((N + 31) / 32) * (C / 1
 inline long h2_pack_elems(int N, int C) { return h2_piece_elems(N, C) + 2L * ((N + 31) / 32) * 32; }
 
 inline bool h2_plan(int B, int H, int W, int C, int N, int NS, H2Problem* q) {
-    if (N % 4 != 0 || (NS != 32 && NS != 64)) return false;
-    if ((double)B * H * W * C * 4.0 >= 2.0e9 || (double)B * H * W * N * 4.0 >= 2.0e9) return false;
-    if (!ws_plan(B, H, W, C, (N + 7) & ~7, &q->g)) return false;
+    if (B <= 0 || H <= 0 || W <= 0 || N % 4 != 0 || (NS != 32 && NS != 64)) return false;
+    // the tile addresses its pixels from the first frame it touches and its output rows from its first pixel: tensors of any size (the
+    // 32-bit offsets span one tile -- at most WS_MAX_PP staged pixels of at most WS_MAX_P / (H W) + 1 frames); pixel COUNTS stay ints
+    if ((double)H * W * C * 4.0 * (WS_MAX_P / (H * W) + 2) >= 2.0e9 || (double)WS_MAX_P * N * 4.0 >= 2.0e9) return false;
+    if (!ws_plan(B, H, W, C, (N + 7) & ~7, &q->g, true)) return false;
     q->g.N = N;
     q->g.ldy = q->g.ldr = N;
     q->g.NS = NS;
@@ -117,7 +119,8 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     const int NCC = p.C >> 4;
     const int tm = bid / p.NSL, slice = bid - tm * p.NSL;
 
-    const ws_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)q.x, 0, 0x7FFFFF00u, 0x00020000);
+    const int b_first = ws_div(tm * p.G, p.d_rgpi);         // first frame this tile touches: pixel offsets count from there
+    const ws_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(q.x + (size_t)b_first * p.H * p.W * p.C), 0, 0x7FFFFF00u, 0x00020000);
     // ---- pixel units of this lane.  LDS image of a piece = two HALF-PLANES (channels 0-7 / 8-15 of the chunk), 16 B per staged pixel,
     // pixel-linear (igemm_f32x3_ws_tile.h).  A unit is a QUARTER of a staged pixel's chunk -- 4 channels, one 16-byte load -- and four
     // consecutive lanes take the four quarters of one pixel: a wave's load instruction is 16 requests of 64 contiguous bytes (eight
@@ -139,7 +142,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             const int b = ws_div(sg, p.d_rgpi);
             const int h = (sg - b * p.RGPI) * p.RH + rr - 1, col = ww - 1;
             const bool ok = sg < p.RG && h >= 0 && h < p.H && col >= 0 && col < p.W;
-            a_voff[j] = ok ? (unsigned)((((b * p.H + h) * p.W + col) * p.C + qt * 4) * 4) : OOB;
+            a_voff[j] = ok ? (unsigned)(((((b - b_first) * p.H + h) * p.W + col) * p.C + qt * 4) * 4) : OOB;
         }
     }
     ws_f32x4 ar[NAU];
@@ -255,9 +258,10 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     if (fhalf == 0) { aux_px[frow] = pl_i[0]; aux_px[32 + frow] = pl_i[1]; }      // (read after the barriers of the first chunk)
 
     const int Mi = (int)p.M;
-    const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(q.res ? (void*)q.res : (void*)q.y, 0, q.res ? 0x7FFFFF00u : 0u, 0x00020000);
-    const ws_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)q.y, 0, 0x7FFFFF00u, 0x00020000);
-    const int gp0 = tm * p.G * p.RHW;                      // first flat output pixel of the tile
+    const int gp0 = tm * p.G * p.RHW;                      // first flat output pixel of the tile: row offsets count from there
+    const ws_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(q.res ? (void*)(q.res + (size_t)gp0 * p.ldr) : (void*)q.y, 0, q.res ? 0x7FFFFF00u : 0u,
+                                                               0x00020000);
+    const ws_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(q.y + (size_t)gp0 * p.ldy), 0, 0x7FFFFF00u, 0x00020000);
     // (weight piece, pixel piece) of the three products, smallest first
     constexpr int PW_[3] = {0, 1, 0};
     constexpr int PA_[3] = {1, 0, 0};
@@ -290,7 +294,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     auto row_off = [&](int pl, int j, int q, int ld) -> unsigned {        // quad q (4 channels) of the lane's 8
         const int n = slice * NS + j * 32 + ec + 4 * q;
         const int gp = gp0 + pl;
-        return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(gp * ld + n) * 4u : OOB;
+        return (pl < p.P && gp < Mi && n < p.N) ? (unsigned)(pl * ld + n) * 4u : OOB;
     };
     ws_f32x4 rr[2][TN][4];                                  // [pixel block][channel block][h * 2 + q]
     ws_f16x8 af[2][2][2], bfr[2][2][TN];

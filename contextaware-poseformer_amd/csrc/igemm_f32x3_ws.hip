@@ -34,6 +34,7 @@ static bool x3_from_args(const GemmArgs& a, X3Problem* q) {
 }
 
 bool gemm_f32x3_ok(const GemmArgs& a) {
+    if (a.x3_h2) return gemm_f32h2_ok(a);                  // (the two-piece tile addresses per tile: no 2 GB tensor limit)
     X3Problem q;
     return x3_from_args(a, &q);
 }
@@ -47,9 +48,11 @@ static bool x3_big_enough(int B, int H, int W, int Cin, int Cout) {
     return B >= 6 && 2.0 * (double)B * H * W * Cout * 9.0 * Cin >= min_flop;
 }
 
-bool f32x3_takes(int B, int H, int W, int Cin, int Cout) {
+bool f32x3_takes(int B, int H, int W, int Cin, int Cout, bool h2) {
+    if (!x3_big_enough(B, H, W, Cin, Cout)) return false;
+    if (h2) return f32h2_shape_ok(B, H, W, Cin, Cout);
     X3Problem q;
-    return x3_big_enough(B, H, W, Cin, Cout) && x3_plan(B, H, W, Cin, Cout, X3_NS, &q);
+    return x3_plan(B, H, W, Cin, Cout, X3_NS, &q);
 }
 
 bool gemm_f32x3_wanted(const GemmArgs& a) {            // (one geometry computation: this runs on the launch path)

@@ -211,7 +211,7 @@ hipError_t launch_pack_conv_bf16_ws(const float* w, const float* gamma, const fl
 // bf16 elements), passed as GemmArgs::Wp3
 bool gemm_f32x3_ok(const GemmArgs& a);
 bool gemm_f32x3_wanted(const GemmArgs& a);             // eligible, carries Wp3, and large enough for this tile (a function of the conv alone)
-bool f32x3_takes(int B, int H, int W, int Cin, int Cout);   // the shape half of that rule (what the engine asks before it picks a weight layout)
+bool f32x3_takes(int B, int H, int W, int Cin, int Cout, bool h2);   // the shape half of that rule (what the engine asks before it picks a weight layout)
 long f32x3_pack_elems(int Cout, int Cin);
 hipError_t launch_gemm_f32x3(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f32x3_group(const GemmArgs* list, int n, hipStream_t s);
@@ -225,6 +225,8 @@ hipError_t launch_pack_conv_f32x3(const float* w, const float* gamma, const floa
 // (launch_gemm_f32x3_group forwards them).  Weights packed by launch_pack_conv_f32h2 (f32h2_pack_elems(Cout, Cin) 16-bit elements)
 long f32h2_pack_elems(int Cout, int Cin);
 hipError_t launch_gemm_f32h2_group(const GemmArgs* list, int n, hipStream_t s);
+bool gemm_f32h2_ok(const GemmArgs& a);
+bool f32h2_shape_ok(int B, int H, int W, int Cin, int Cout);     // (tensors of any size: the tile addresses from per-tile bases)
 const char* gemm_f32h2_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_f32h2(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                   void* Wp_f16, float* bias, int Cout, int Cin, hipStream_t s);
@@ -240,6 +242,15 @@ hipError_t launch_pack_f32h2_gemm(const float* w, const float* gamma, const floa
                                   float* Wp, float* bias, int N, int Cin, int ks, int K, int Kpad, hipStream_t s);   // ks = 0: linear [N][K]
 // rows [n0, n0 + n) of an [Ntot][Kpad] pack from one nn.Linear weight [n][K] (several linears concatenated along N share a pack)
 hipError_t launch_pack_f32h2_gemm_rows(const float* w, float* Wp, int n0, int n, int Ntot, int K, int Kpad, hipStream_t s);
+// One matrix of the training step's weight table: W [N][K] (row pitch ld) -> its two-piece pack at base + fwd_off (Kpad = K rounded up to 32)
+// and the pack of W^T [K][N] at base + bwd_off (Kpad = N rounded up to 32); either offset may be -1 (not wanted).  tile_start: first block of
+// this matrix in the launch (ceil(N / 32) * ceil(K / 32) blocks each); max_off: its N row + K column maxima in the scratch
+struct H2TrainW {
+    const float* w;
+    long fwd_off, bwd_off;
+    int N, K, ld, tile_start, max_off, pad_;
+};
+hipError_t launch_pack_f32h2_train(const H2TrainW* tab_dev, int n, int tiles, float* base, int* maxima, long maxima_elems, hipStream_t s);
 bool gemm_bf16_smallc_ok(const GemmArgs& a);            // the stem conv (Cin = 3) with a bf16 result
 hipError_t launch_gemm_bf16_smallc(const GemmArgs& a, hipStream_t s);
 const char* gemm_bf16_smallc_kernel_name(const GemmArgs& a);

@@ -991,14 +991,15 @@ bool Engine::build() {
     // tile's 2 GB tensor limit, so the range is [first batch it accepts, last batch it accepts]
     for (Op& op : ops) {
         if (op.kind != OP_GEMM || !op.wino || !packs[op.pack].x3) continue;
-        const double per_frame = (double)op.H * op.W * (double)std::max(op.Cin, op.N) * 4.0;
-        int hi = (int)std::min(1.0e6, 2.0e9 / per_frame);
-        while (hi >= 1 && hi > (int)(2.0e9 / per_frame) - 4 && !f32x3_takes(hi, op.H, op.W, op.Cin, op.N)) --hi;   // (the limit itself is exclusive)
-        if (hi < 1 || !f32x3_takes(hi, op.H, op.W, op.Cin, op.N)) continue;
+        // (upper end: the three-piece tile addresses whole tensors with 31-bit byte offsets; the two-piece tile only counts pixels)
+        const double cap = x3_h2 ? 2.0e9 / ((double)op.H * op.W) : 2.0e9 / ((double)op.H * op.W * (double)std::max(op.Cin, op.N) * 4.0);
+        int hi = (int)std::min(1.0e6, cap);
+        while (hi >= 1 && hi > (int)cap - 4 && !f32x3_takes(hi, op.H, op.W, op.Cin, op.N, x3_h2)) --hi;   // (the limit itself is exclusive)
+        if (hi < 1 || !f32x3_takes(hi, op.H, op.W, op.Cin, op.N, x3_h2)) continue;
         int lo = 1, top = hi;                       // smallest accepted batch by bisection
         while (lo < top) {
             const int mid = lo + (top - lo) / 2;
-            if (f32x3_takes(mid, op.H, op.W, op.Cin, op.N)) top = mid; else lo = mid + 1;
+            if (f32x3_takes(mid, op.H, op.W, op.Cin, op.N, x3_h2)) top = mid; else lo = mid + 1;
         }
         op.x3_lo = lo; op.x3_hi = hi;
         // the Winograd layout of this conv is dead weight when the tile covers every batch the Winograd kernels could be asked for
@@ -1041,6 +1042,9 @@ bool Engine::build() {
         bias_tab_off = off;
         off += round64(nseg * (sizeof(CopySegment) / sizeof(float)));
     }
+    t_h2_plan();                            // the training step's weight table (train.cpp); its device image lives in the arena
+    t_h2_tab_off = off;
+    off += round64(t_h2_specs.size() * (sizeof(H2TrainW) / sizeof(float)) + 16);
     pack_elems = off;
     return true;
 }

@@ -74,6 +74,8 @@ void Engine::train_layout(int B, TrainLayout& L) const {
     L.slabs = take(0, L.slabs_elems);
     L.red_elems = (size_t)64 * 3 * D;
     L.red = take(0, L.red_elems);
+    L.h2w = take(0, t_h2_elems);
+    L.h2max = take(0, t_h2_max_elems);
     L.total = cur;
 }
 
@@ -86,11 +88,100 @@ size_t Engine::train_elems(int B) const {
 // ---------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------
+// ---- the step's weights as two-fp16-piece packs -------------------------------------------------------------------------------------
+// Which matrices: every nn.Linear the step multiplies by with at least 64 output columns in that product (the 16-wide per-head
+// projections of the deformable blocks are HBM-bound on the fp32 kernel's 256 x 32 tile and stay there).
+void Engine::t_h2_plan() {
+    t_h2_specs.clear();
+    t_h2_tab.clear();
+    t_h2_elems = t_h2_max_elems = 0;
+    t_h2_tiles = 0;
+    if (!use_h2g || bf16() || !cfg.training) return;
+    const std::string V = "volume_net";
+    const int Lv = cfg.levels, L1 = Lv + 1, C = cfg.embed_dim_ratio, D = C * L1;
+    const int NH = cfg.deform_heads, NS = cfg.deform_samples;
+    auto add = [&](const std::string& name, int N, int K, bool fwd, bool bwd) {
+        const auto it = param_index.find(name + ".weight");
+        if (it == param_index.end()) return;
+        if (N < 64) fwd = false;                             // (output columns of y = x W^T ...
+        if (K < 64) bwd = false;                             //  ... and of dX = dY W)
+        if (fwd || bwd) t_h2_specs.push_back(H2TrainSpec{it->second, -1, N, K, K, fwd, bwd});
+    };
+    for (int l = 0; l < Lv; ++l) add(V + ".feat_embed." + std::to_string(l), C, feat_C[l], true, false);
+    for (int i = 0; i < Lv && cfg.context_blocks; ++i) {
+        const std::string p = V + ".context_blocks." + std::to_string(i);
+        if ((size_t)i < ctx_ao_pack.size() && 3 * NH * NS >= 64)
+            t_h2_specs.push_back(H2TrainSpec{-1, ctx_ao_pack[i], 3 * NH * NS, C, packs[ctx_ao_pack[i]].Kpad, true, C >= 64});
+        for (int l = 0; l < Lv; ++l) add(p + ".embed_proj." + std::to_string(l), C / NH, feat_C[l], true, true);
+        add(p + ".mlp.fc1", 2 * C, C, true, true);
+        add(p + ".mlp.fc2", C, 2 * C, true, true);
+    }
+    for (int g = 0; g < 2; ++g)
+        for (int i = 0; i < Lv; ++i) {
+            const std::string p = V + (g == 0 ? ".res_blocks." : ".joint_blocks.") + std::to_string(i);
+            const int dim = g == 0 ? C : D;
+            add(p + ".attn.qkv", 3 * dim, dim, true, true);
+            add(p + ".attn.proj", dim, dim, true, true);
+            add(p + ".mlp.fc1", 2 * dim, dim, true, true);
+            add(p + ".mlp.fc2", dim, 2 * dim, true, true);
+        }
+    size_t off = 0, moff = 0;
+    int tiles = 0;
+    for (const H2TrainSpec& sp : t_h2_specs) {
+        H2TrainW e{};
+        e.N = sp.N; e.K = sp.K; e.ld = sp.ld;
+        e.fwd_off = e.bwd_off = -1;
+        if (sp.fwd) { e.fwd_off = (long)off; off += r64((size_t)f32h2_gemm_pack_elems(sp.N, r32(sp.K))); }
+        if (sp.bwd) { e.bwd_off = (long)off; off += r64((size_t)f32h2_gemm_pack_elems(sp.K, r32(sp.N))); }
+        e.tile_start = tiles;
+        tiles += ((sp.N + 31) / 32) * ((sp.K + 31) / 32);
+        e.max_off = (int)moff;
+        moff += (size_t)sp.N + sp.K;
+        t_h2_tab.push_back(e);
+    }
+    t_h2_elems = off;
+    t_h2_max_elems = r64(moff);
+    t_h2_tiles = tiles;
+}
+
+// pack every matrix of the table from the CURRENT parameters (three launches); the packs live until the next forward_train
+int Engine::t_h2_prepare(hipStream_t s, const TrainLayout& L, float* tw, int B) {
+    t_h2_base = nullptr;
+    t_h2_index.clear();
+    if (t_h2_specs.empty() || B < H2G_MIN_BATCH) return CAPF_OK;
+    bool same = t_h2_on_device;
+    for (size_t i = 0; i < t_h2_specs.size(); ++i) {
+        const H2TrainSpec& sp = t_h2_specs[i];
+        const float* w = sp.param >= 0 ? params[sp.param].ptr : pack_arena + packs[sp.pack].w_off;
+        if (t_h2_tab[i].w != w) { t_h2_tab[i].w = w; same = false; }
+        t_h2_index[w] = (int)i;
+    }
+    H2TrainW* tab_dev = reinterpret_cast<H2TrainW*>(pack_arena + t_h2_tab_off);
+    if (!same) {
+        HIP_TRY(hipMemcpyAsync(tab_dev, t_h2_tab.data(), t_h2_tab.size() * sizeof(H2TrainW), hipMemcpyHostToDevice, s));
+        t_h2_on_device = true;
+    }
+    HIP_TRY(launch_pack_f32h2_train(tab_dev, (int)t_h2_tab.size(), t_h2_tiles, tw + L.h2w, reinterpret_cast<int*>(tw + L.h2max),
+                                    (long)t_h2_max_elems, s));
+    t_h2_base = tw + L.h2w;
+    return CAPF_OK;
+}
+
+const float* Engine::t_h2_pack(const float* W, bool transposed) const {
+    if (!t_h2_base) return nullptr;
+    const auto it = t_h2_index.find(W);
+    if (it == t_h2_index.end()) return nullptr;
+    const long off = transposed ? t_h2_tab[it->second].bwd_off : t_h2_tab[it->second].fwd_off;
+    return off < 0 ? nullptr : t_h2_base + off;
+}
+
 int Engine::t_gemm(hipStream_t s, const float* A, RowMap amap, int M, int N, int K, const float* W, int Kpad,
                    const float* bias, float* out, RowMap omap, const float* res, RowMap rmap, int act,
-                   const float* rscale, int rs_div) {
+                   const float* rscale, int rs_div, const float* Wh2) {
     GemmArgs a{};
     a.A = A; a.Wp = W; a.bias = bias; a.res = res; a.out = out;
+    if (!Wh2) Wh2 = t_h2_pack(W, false);                    // (this step's two-piece copy of W, where the table holds one)
+    if (Wh2 && r32(K) == Kpad) a.Wh2 = Wh2;                 // (the pack's chunks are the fp32 matrix's: same Kpad)
     a.M = M; a.N = N; a.K = K; a.Kpad = Kpad;
     a.amap = amap; a.omap = omap; a.rmap = rmap; a.act = act;
     a.rscale = rscale; a.rs_div = rs_div;
@@ -153,6 +244,16 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
     }
     if (dX) {
         const int Np = r32(N);
+        if (const float* h2t = t_h2_pack(W, true)) {         // W^T is in the step's table as a two-piece pack: no transpose, 16-bit matrix pipe
+            GemmArgs a{};
+            a.A = dY; a.Wp = h2t; a.Wh2 = h2t; a.out = dX; a.res = acc_dx ? dX : nullptr;
+            a.M = rows; a.N = K; a.K = N; a.Kpad = Np;
+            a.amap = dymap; a.omap = dxmap; a.rmap = dxmap; a.act = ACT_NONE;
+            if (gemm_f32h2g_ok(a)) {
+                HIP_TRY(launch_gemm_f32h2g(a, s));
+                return CAPF_OK;
+            }
+        }
         float* wT = tw + L.wT;
         HIP_TRY(launch_transpose_pad(W, row_ld(K), N, K, wT, Np, s));
         int rc = t_gemm(s, dY, dymap, rows, K, N, wT, Np, nullptr, dX, dxmap, acc_dx ? dX : nullptr, dxmap, ACT_NONE,
@@ -181,6 +282,7 @@ int Engine::forward_train(hipStream_t s, int B, const float* masks) {
     const float* m_res = masks ? masks + (size_t)2 * Lv * B : nullptr;
     const float* m_joint = masks ? m_res + (size_t)2 * Lv * B * J : nullptr;
 
+    if (int rc = t_h2_prepare(s, L, tw, B)) return rc;
     HIP_TRY(launch_prep_embed(kcrop, k2d, P(*this, V + ".coord_embed.weight"), P(*this, V + ".coord_embed.bias"),
                               P(*this, V + ".Spatial_pos_embed"), X, B, J, L1, C, s));
     const float* pos = P(*this, V + ".Spatial_pos_embed");

@@ -173,6 +173,10 @@ int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch
 int64_t capf_train_generation(const capf_handle* h);
 int64_t capf_grad_elems(const capf_handle* h);
 int capf_grad_info(const capf_handle* h, int param_index, int64_t* offset);   /* -1: not a lifter parameter */
+/* How many of the lifter's nn.Linear matrices a training step at batch >= 6 multiplies by on the two-fp16-piece GEMM (forward y = x W^T
+ * and / or backward dX = dY W; packs of W and W^T are rebuilt from the current parameters at the start of every capf_forward_train).
+ * 0: every product of the step runs on the fp32 matrix pipe (CAPF_PLAN_NO_F32H2_GEMM, compute_dtype = bf16, training = 0). */
+int capf_train_h2_matrices(const capf_handle* h);
 int capf_mpjpe(void* stream, const float* pred, const float* gt, int rows, float* loss, float* dpred,
                float grad_scale);
 /* the same loss for rows of any width `dim` (MPJPE.forward accepts [..., D]: 2-D keypoints as well, loss.py:16-22) */

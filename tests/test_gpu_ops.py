@@ -1322,3 +1322,46 @@ def test_f32h2g_engine_path_agrees_with_the_fp32_pipe_gemms():
         print(f"two-fp16-piece GEMM plan vs fp32-pipe GEMM plan: relative L2 {rel:.2e}")
         assert rel < 2e-6
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * outs[1].abs().max().item()
+
+
+def test_split_fp32_kernels_take_tensors_beyond_2_gib():
+    """The training bench's batch (512 frames) makes three backbone tensors larger than 2 GiB in fp32 (conv2's input, layer1's output into
+    both transition1 convs).  The two-fp16-piece tile and the two-piece GEMM address from per-tile bases, so they take them -- checked
+    bit for bit against the same frames run as two half batches (a tile of these maps never spans two frames' worth of scale blocks:
+    64 x 64 maps give one tile per four rows; the GEMM's 128-pixel tiles split 4096-pixel frames evenly), and against fp64 on a few frames."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(2026)
+    # transition1.0.0: 256 -> 32, 3x3 stride 1 at 64x64 (pose_hrnet.py:331-356), 544 frames: 2.28e9 bytes of input
+    B, ci, co, hw = 544, 256, 32, 64
+    x8, w, bnp, wp, bias, w_fold, _, xg8, _ = _h2_problem(g, ci, co, hw, hw, 8, 1, False)
+    xg = xg8.repeat(B // 8, 1, 1, 1)                                     # [B, 64, 64, 256] fp32 NHWC
+    xg += torch.arange(B, device="cuda").view(B, 1, 1, 1) * 1e-3          # (every frame different)
+    assert xg.numel() * 4 > 2 ** 31
+    big, = capf.conv_nhwc_f32h2_group([(xg, wp, bias, 1, None, co)])
+    for lo in (0, B // 2):
+        half, = capf.conv_nhwc_f32h2_group([(xg[lo:lo + B // 2].contiguous(), wp, bias, 1, None, co)])
+        assert torch.equal(big[lo:lo + B // 2], half)
+    for b in (0, B - 1):
+        xb = xg[b:b + 1].permute(0, 3, 1, 2).cpu()
+        _x3_check(big[b:b + 1], xb, w_fold, bias, None, 1, f"h2 tile, frame {b} of a 2.3 GB tensor")
+    del xg, big, half
+    # conv2: 64 -> 64, 3x3 stride 2 at 128x128 (pose_hrnet.py:282-284), 544 frames
+    B, ci, co, hw = 544, 64, 64, 128
+    x = torch.randn(8, ci, hw, hw, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    bn_cuda = tuple(t.cuda() for t in (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+                                       torch.rand(co, generator=g) * 0.4 + 0.8))
+    wd, bd = capf.pack_conv(w.cuda(), bn_cuda)
+    wp, bias = capf.pack_f32h2_gemm(w.cuda(), bn_cuda)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().repeat(B // 8, 1, 1, 1)
+    xg += torch.arange(B, device="cuda").view(B, 1, 1, 1) * 1e-3
+    assert xg.numel() * 4 > 2 ** 31
+    big = capf.conv_nhwc_f32h2g(xg, wp, bias, 3, 2, 1, None, co)
+    for lo in (0, B // 2):
+        half = capf.conv_nhwc_f32h2g(xg[lo:lo + B // 2].contiguous(), wp, bias, 3, 2, 1, None, co)
+        assert torch.equal(big[lo:lo + B // 2], half)
+    w_fold = wd.cpu().double()[:, :9 * ci].view(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
+    for b in (0, B - 1):
+        xb = xg[b:b + 1].permute(0, 3, 1, 2).cpu()
+        _h2g_conv_check(big[b:b + 1], xb, w_fold, bd, None, 1, 2, f"h2g conv, frame {b} of a 2.3 GB tensor",
+                        capf.conv_nhwc(xg[b:b + 1].contiguous(), wd, bd, 3, 2, 1, None))

@@ -112,3 +112,41 @@ def test_flat_grad_only_leaves_the_same_gradient_in_the_flat_buffer():
                 off, cnt = layout["volume_net." + n] if ("volume_net." + n) in layout else layout[n]
                 assert torch.equal(p.grad.reshape(-1), flats[0][off: off + cnt])
     assert torch.equal(flats[0], flats[1])
+
+
+@pytest.mark.parametrize("drop_path", [0.0, 0.3])
+def test_training_step_on_the_two_piece_gemm_agrees_with_the_fp32_pipe(drop_path):
+    """From batch 6 the step's nn.Linear products -- forward y = x W^T and backward dX = dY W -- run on the two-fp16-piece GEMM off packs
+    made from the current parameters at the start of every step (csrc/train.cpp t_h2_prepare; W and W^T of 56 matrices in three
+    launches).  Against the same step on the fp32 matrix pipe (CAPF_PLAN_NO_F32H2_GEMM): prediction, loss and every one of the 191
+    gradients, with and without DropPath (the per-row branch scale rides in the GEMM epilogue)."""
+    from capf import synth
+    from capf.lib import PLAN_NO_F32H2_GEMM
+    from mvn.models.loss import MPJPE
+    case = CASES["w32_256x256_b2"]
+    B = 12
+    img, k2d, kc, gt = synth.synth_inputs(B, case["H"], case["W"], seed=4242, crop_range=case["crop"], with_gt=True)
+    got = []
+    for flags in (0, PLAN_NO_F32H2_GEMM):
+        model, _ = make_model(case["backbone"], device="cuda", wseed=case["wseed"], bn=case["bn"], plan_flags=flags)
+        model.train(); model.backbone.eval(); model.volume_net.train()
+        model.drop_path_rate = drop_path
+        torch.manual_seed(7)
+        pred = model(img.cuda(), k2d.cuda(), kc.clone().cuda())
+        loss = MPJPE()(pred, gt.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        eng = model.engine_for(img.cuda())
+        n_h2 = eng.lib.capf_train_h2_matrices(eng.h)
+        assert (n_h2 >= 40) == (flags == 0), n_h2
+        got.append((pred.detach().clone(), loss.item(), {n: p.grad.detach().clone() for n, p in model.volume_net.named_parameters()}))
+    (p1, l1, g1), (p0, l0, g0) = got
+    assert (p1 - p0).abs().max().item() < 2e-6 * max(1.0, p0.abs().max().item())
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0))
+    worst = 0.0
+    for n in g0:
+        scale = max(1e-9, g0[n].abs().max().item())
+        worst = max(worst, (g1[n] - g0[n]).abs().max().item() / scale)
+        assert (g1[n] - g0[n]).abs().max().item() <= 2e-5 * scale, n
+    print(f"two-piece GEMM vs fp32 pipe, batch {B}, drop_path {drop_path}: worst gradient difference {worst:.2e} of the gradient's largest entry")
+    assert len(g0) == 191
