@@ -202,18 +202,19 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
         (double)rows * (double)std::max(dymap.S1, xmap.S1) * 4.0 < 2.0e9) {
         const bool bias_here = gb && gb == gW + (long)N * K;
         if (gb && !bias_here) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
-        const int tiles = (N / 64) * (K / 64), chunks = (rows + 31) / 32;
+        const bool h2 = t_h2_base && N % 128 == 0 && K % 128 == 0;      // (this step runs its products on the 16-bit matrix pipe)
+        const int tiles = h2 ? (N / 128) * (K / 128) : (N / 64) * (K / 64), chunks = (rows + 31) / 32;
         const long slab = (long)N * K + (bias_here ? N : 0);
         // row slices: ~2048 blocks per launch (four rounds of two per CU, so that a tile count that is no multiple of 256 costs a few per
         // cent, not a half-empty round), at least 16 chunks each, as many as the slab buffer holds -- the small layers (128 x 128:
         // four tiles, 43520 rows) ran 64 blocks of 85 chunks
         const long slab_cap = (long)L.slabs_elems;                  // (the layout's own number: train_layout)
-        int splits = std::max(1, (2048 + tiles - 1) / tiles);
+        int splits = std::max(1, ((h2 ? 1024 : 2048) + tiles - 1) / tiles);      // (the two-piece kernel: two rounds of two blocks per CU)
         splits = std::min(splits, std::max(1, chunks / 16));
         splits = (int)std::min<long>(splits, std::max<long>(1, slab_cap / slab));
         const int cps = (chunks + splits - 1) / splits, slices = (chunks + cps - 1) / cps;
         HIP_TRY(launch_wgrad_tn(dY + dymap.off, dymap.S1, Xin + xmap.off, xmap.S1, rows, N, K, slices > 1 ? tw + L.slabs : gW, slab, splits,
-                                bias_here ? 1 : 0, s));
+                                bias_here ? 1 : 0, s, h2));
         if (slices > 1) HIP_TRY(launch_slab_sum(tw + L.slabs, slices, slab, gW, s));
         gW = nullptr;
         gb = nullptr;

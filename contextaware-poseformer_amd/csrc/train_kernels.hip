@@ -6,6 +6,7 @@
 // feature maps come from the frozen backbone, conpose.py:22-25), MPJPE loss + gradient (loss.py:16-22)
 // and a fused AdamW update (train.py:345).  No atomics: every reduction has a fixed order.
 #include <algorithm>
+#include "igemm_f32h2_ws_tile.h"
 #include "kernels.h"
 
 namespace capf {
@@ -462,16 +463,156 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
 #endif
 }
 
+// The same product on the 16-bit matrix pipe (the step's linears with N and K multiples of 128): both operands are ACTIVATIONS, so both are
+// split on the way from LDS to the MFMA -- two fp16 pieces under a power-of-two scale per wave, operand and 32-row chunk, three piece
+// products (igemm_f32h2_ws_tile.h: 2^-21 of a term at worst, below the fp32 accumulation error of a sum over thousands of rows).  A lane's
+// fragment for v_mfma_f32_32x32x16_f16 is eight consecutive m of one column: eight ds_read_b32 down the [32 m][128] tile, 32 consecutive
+// lanes = 32 consecutive dwords.  128 x 128 outputs per block, 64 x 64 per wave: a split fragment feeds two MFMA blocks, 48 VALU
+// instructions per MFMA triple instead of 96 (the split, not the matrix pipe, bounds this kernel).  The scales only ever go DOWN along a
+// slice's chunks (an operand's largest value so far decides): a chunk of small values under a scale made for larger ones loses
+// nothing the fp32 sum it joins would keep (absolute error 2^-39 of that largest value per term), no accumulator ever scales up, and an
+// all-zero chunk (DropPath) costs no rescale.  Two-stage ring of [32][128] fp32 tiles (64 KiB), two blocks per CU.
+__global__ __launch_bounds__(256, 2) void wgrad_tn_h2_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int S = 2, TW = 128, TILE = 32 * TW;
+    __shared__ __attribute__((aligned(16))) float lds[S * 2 * TILE + 256];
+    typedef __attribute__((address_space(3))) void* lptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tk = a.K >> 7;
+    const int tile_n = blockIdx.x / tk, tile_k = blockIdx.x - tile_n * tk;
+    const int n0 = tile_n * TW, k0 = tile_k * TW;
+    const int c_begin = blockIdx.y * a.cps;
+    const int chunks_total = (a.M + 31) >> 5;
+    const int c_end = min(chunks_total, c_begin + a.cps);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + n0), 0, 0x7FFFFF00u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + k0), 0, 0x7FFFFF00u, 0x00020000);
+    // DMA: instruction i (0..15) of a tile covers rows 2 i, 2 i + 1 (32 lanes x 16 B per row); a wave issues i = wave, wave + 4, wave + 8, wave + 12
+    const int drow = lane >> 5, dq = lane & 31;
+    auto fire = [&](int c, int stage) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int i = wave + 4 * h;
+            const long m = (long)c * 32 + 2 * i + drow;
+            const bool ok = c < c_end && m < a.M;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lptr)(lds + (stage * 2) * TILE + i * 256), 16, ok ? (unsigned)((m * a.ldy + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr)(lds + (stage * 2 + 1) * TILE + i * 256), 16, ok ? (unsigned)((m * a.ldx + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
+        }
+    };
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int fi = lane & 31, fh = lane >> 5;
+    float bsum = 0.f;                                      // (tile_k == 0) column n0 + (tid & 127), rows (tid >> 7) * 16 .. + 15 of every chunk
+    int sa = 190, sb = 190;                                // biased exponents of the two operand scales so far (h2_scale_exp's largest: nothing seen yet)
+    fire(c_begin, 0);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int st = (c - c_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // chunk c has landed for everybody; everybody is done reading the other stage
+        fire(c + 1, st ^ 1);
+        const float* ys = lds + (st * 2) * TILE;
+        const float* xs = ys + TILE;
+        float av[2][16], bv[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = (j >> 3) * 16 + 8 * fh + (j & 7);
+                av[t][j] = ys[row * TW + wn + 32 * t + fi];
+                bv[t][j] = xs[row * TW + wk + 32 * t + fi];
+            }
+        float ma = 0.f, mb = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { ma = fmaxf(ma, fabsf(av[t][j])); mb = fmaxf(mb, fabsf(bv[t][j])); }
+        const int na = min(sa, h2_scale_exp(h2_wave_max(ma))), nb = min(sb, h2_scale_exp(h2_wave_max(mb)));
+        if (na + nb != sa + sb) {                          // (wave-uniform) the accumulators move DOWN to the new scales: exact
+            const float f = __int_as_float(max(0, 127 + (na + nb) - (sa + sb)) << 23);     // (below 2^-126: gone, as it would be in the sum)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][u][r] *= f;
+        }
+        sa = na; sb = nb;
+        const float fa = __int_as_float(sa << 23), fb = __int_as_float(sb << 23);
+        ws_f16x8 a1[2][2], a2[2][2], b1[2][2], b2[2][2];   // [32-wide block][16-deep step]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ws_u32x4 pa1, pa2, pb1, pb2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned x1, x2;
+                    h2_split2(av[t][ks * 8 + 2 * q], av[t][ks * 8 + 2 * q + 1], fa, x1, x2);
+                    pa1[q] = x1; pa2[q] = x2;
+                    h2_split2(bv[t][ks * 8 + 2 * q], bv[t][ks * 8 + 2 * q + 1], fb, x1, x2);
+                    pb1[q] = x1; pb2[q] = x2;
+                }
+                a1[t][ks] = __builtin_bit_cast(ws_f16x8, pa1); a2[t][ks] = __builtin_bit_cast(ws_f16x8, pa2);
+                b1[t][ks] = __builtin_bit_cast(ws_f16x8, pb1); b2[t][ks] = __builtin_bit_cast(ws_f16x8, pb2);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[t][ks], b1[u][ks], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t][ks], b2[u][ks], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t][ks], b1[u][ks], acc[t][u], 0, 0, 0);
+                }
+        if (a.want_bias && tile_k == 0) {
+            const int col = tid & 127, r0 = (tid >> 7) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += ys[(r0 + r) * TW + col];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // D[i][j]: lane holds column j = k0 + wk + 32 u + fi, register 4 g + e = row n0 + wn + 32 t + 8 g + 4 fh + e
+    const float inv = __int_as_float((381 - sa - sb) << 23);
+    float* o = a.out + (long)blockIdx.y * a.slab;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[(long)(n0 + wn + 32 * t + 8 * g + 4 * fh + e) * a.K + k0 + wk + 32 * u + fi] = acc[t][u][4 * g + e] * inv;
+    if (a.want_bias && tile_k == 0) {
+        float* red = lds + S * 2 * TILE;
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 128) o[(long)a.N * a.K + n0 + tid] = red[tid] + red[128 + tid];
+    }
+#endif
+}
+
 // slabs: at least splits * (N * K + N) floats; *splits_out slices were written (1: straight into out = dW, bias at out + N * K)
 hipError_t launch_wgrad_tn(const float* dY, long ldy, const float* X, long ldx, int M, int N, int K, float* out, long slab, int splits,
-                           int want_bias, hipStream_t s) {
+                           int want_bias, hipStream_t s, bool h2) {
+    if (h2 && (N % 128 || K % 128)) return hipErrorInvalidValue;
     if (N % 64 || K % 64 || M <= 0 || splits < 1 || (double)M * (double)ldy * 4.0 >= 2.0e9 || (double)M * (double)ldx * 4.0 >= 2.0e9)
         return hipErrorInvalidValue;
     WgradArgs a{dY, ldy, X, ldx, out, slab, M, N, K, 0, want_bias};
     const int chunks = (M + 31) / 32;
     a.cps = (chunks + splits - 1) / splits;
     const int slices = (chunks + a.cps - 1) / a.cps;
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((N / 64) * (K / 64), slices), dim3(256), 0, s, a);
+    if (h2) hipLaunchKernelGGL(wgrad_tn_h2_kernel, dim3((N / 128) * (K / 128), slices), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wgrad_tn_kernel, dim3((N / 64) * (K / 64), slices), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
