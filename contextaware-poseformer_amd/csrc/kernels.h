@@ -372,7 +372,7 @@ hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap
                             float* dst2 = nullptr, size_t scratch_elems = 0);   // dst2: plain column sums of A as well
 hipError_t launch_slab_sum(const float* slabs, int nslab, long n, float* dst, hipStream_t s);
 // dW[n][k] = sum_m dY[m][n] X[m][k] (+ db[n] = sum_m dY[m][n] behind it) from row-major operands, no transposes (train_kernels.hip);
-// N % 64 == 0, K % 64 == 0; slice s of `splits` row ranges writes N * K (+ N) floats at out + s * slab.  h2: both operands as two fp16
+// N % 4 == 0, K % 4 == 0; slice s of `splits` row ranges writes N * K (+ N) floats at out + s * slab.  h2: both operands as two fp16
 // pieces split in the kernel, three piece products on the 16-bit matrix pipe, 128 x 128 tiles (N % 128 == 0, K % 128 == 0)
 hipError_t launch_wgrad_tn(const float* dY, long ldy, const float* X, long ldx, int M, int N, int K, float* out, long slab, int splits,
                            int want_bias, hipStream_t s, bool h2 = false);

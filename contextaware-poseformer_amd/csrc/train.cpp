@@ -196,20 +196,20 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
     float* red = tw + L.red;
     const size_t red_elems = L.red_elems;
     // dW (and db, when it sits right behind dW in the flat gradient -- every nn.Linear's weight / bias pair does) straight from the
-    // row-major dY and X: no transposes, no column-reduction launches (wgrad_tn_kernel; 64-multiples and plain row pitches only)
+    // row-major dY and X: no transposes, no column-reduction launches (wgrad_tn_kernel; multiples of four and plain row pitches only)
     // (its operand tiles are 16-byte LDS-DMA loads: row pitches and offsets must be multiples of four elements)
-    if (gW && N % 64 == 0 && K % 64 == 0 && dymap.G == 1 && xmap.G == 1 && ((dymap.S1 | dymap.off | xmap.S1 | xmap.off) & 3) == 0 &&
+    if (gW && N % 4 == 0 && K % 4 == 0 && dymap.G == 1 && xmap.G == 1 && ((dymap.S1 | dymap.off | xmap.S1 | xmap.off) & 3) == 0 &&
         (double)rows * (double)std::max(dymap.S1, xmap.S1) * 4.0 < 2.0e9) {
         const bool bias_here = gb && gb == gW + (long)N * K;
         if (gb && !bias_here) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
         const bool h2 = t_h2_base && N % 128 == 0 && K % 128 == 0;      // (this step runs its products on the 16-bit matrix pipe)
-        const int tiles = h2 ? (N / 128) * (K / 128) : (N / 64) * (K / 64), chunks = (rows + 31) / 32;
+        const int tiles = h2 ? (N / 128) * (K / 128) : ((N + 63) / 64) * ((K + 63) / 64), chunks = (rows + 31) / 32;
         const long slab = (long)N * K + (bias_here ? N : 0);
         // row slices: ~2048 blocks per launch (four rounds of two per CU, so that a tile count that is no multiple of 256 costs a few per
         // cent, not a half-empty round), at least 16 chunks each, as many as the slab buffer holds -- the small layers (128 x 128:
         // four tiles, 43520 rows) ran 64 blocks of 85 chunks
         const long slab_cap = (long)L.slabs_elems;                  // (the layout's own number: train_layout)
-        int splits = std::max(1, ((h2 ? 1024 : 2048) + tiles - 1) / tiles);      // (the two-piece kernel: two rounds of two blocks per CU)
+        int splits = std::max(1, ((h2 ? 512 : 2048) + tiles - 1) / tiles);       // (the two-piece kernel: one round of two blocks per CU -- its slabs are 128 x 128)
         splits = std::min(splits, std::max(1, chunks / 16));
         splits = (int)std::min<long>(splits, std::max<long>(1, slab_cap / slab));
         const int cps = (chunks + splits - 1) / splits, slices = (chunks + cps - 1) / cps;
@@ -503,7 +503,7 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
         const Pack& pk = packs[ctx_ao_pack[i]];
         const int NA = NH * NS, NO = 2 * NH * NS;
         float* gWcat = tw + L.cat;                      // [48][C]
-        float* gbcat = tw + L.cat + (size_t)64 * C;     // [48]
+        float* gbcat = gWcat + (size_t)(NH * NS * 3) * C;   // [48], right behind the weight gradient: one launch leaves both
         float* dq = tw + L.gC;                          // [R, C]
         rc = t_linear_bwd(s, L, tw, gA, row_ld(64), R, NA + NO, C, tw + c.y1, row_ld(C), pack_arena + pk.w_off, dq,
                           row_ld(C), false, gWcat, gbcat);

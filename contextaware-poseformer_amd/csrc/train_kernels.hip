@@ -380,7 +380,7 @@ hipError_t launch_transpose_pad(const float* in, RowMap imap, int M, int C, floa
 // k-steps (row stride = 64 dwords), 32 consecutive lanes = 32 consecutive dwords: conflict-free.  64 x 64 output tile per block (four
 // waves, 32 x 32 each), three-stage ring, split over m in grid.y (each slice writes a raw slab, summed by slab_sum like before); the blocks
 // of the first k tile also sum their dY tile's columns: the bias gradient, as N more floats behind the slice's N * K slab.
-// Requires N % 64 == 0, K % 64 == 0, plain row pitches (the ctx blocks' strided token maps and the 32 / 48-wide linears keep the old path).
+// Requires N % 4 == 0, K % 4 == 0 (16-byte quads; ragged 64-tiles load zeros) and plain row pitches (the ctx blocks' strided token maps keep the old path).
 struct WgradArgs {
     const float* dY; long ldy;      // [M][ldy], columns 0 .. N - 1
     const float* X; long ldx;       // [M][ldx], columns 0 .. K - 1
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     typedef __attribute__((address_space(3))) void* lptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tk = a.K >> 6;
+    const int tk = (a.K + 63) >> 6;                         // (ragged N / K: columns beyond them load as zeros and are not stored)
     const int tile_n = blockIdx.x / tk, tile_k = blockIdx.x - tile_n * tk;
     const int n0 = tile_n * 64, k0 = tile_k * 64;
     const int c_begin = blockIdx.y * a.cps;
@@ -406,14 +406,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + k0), 0, 0x7FFFFF00u, 0x00020000);
     // DMA: instruction i (0..7) of a tile covers rows 4 i .. 4 i + 3 (16 lanes x 16 B per row); a wave issues i = wave and wave + 4
     const int drow = lane >> 4, dq = lane & 15;
+    const bool y_col = n0 + dq * 4 < a.N, x_col = k0 + dq * 4 < a.K;
     auto fire = [&](int c, int stage) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = wave + 4 * h;
             const long m = (long)c * 32 + 4 * i + drow;
             const bool ok = c < c_end && m < a.M;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lptr)(lds + (stage * 2) * TILE + i * 256), 16, ok ? (unsigned)((m * a.ldy + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr)(lds + (stage * 2 + 1) * TILE + i * 256), 16, ok ? (unsigned)((m * a.ldx + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lptr)(lds + (stage * 2) * TILE + i * 256), 16, ok && y_col ? (unsigned)((m * a.ldy + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr)(lds + (stage * 2 + 1) * TILE + i * 256), 16, ok && x_col ? (unsigned)((m * a.ldx + dq * 4) * 4) : 0x80000000u, 0, 0, 0);
         }
     };
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -452,13 +453,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[(long)(n0 + wn + 8 * g + 4 * fh + e) * a.K + k0 + wk + fi] = acc[4 * g + e];
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn + 8 * g + 4 * fh + e, kk = k0 + wk + fi;
+            if (n < a.N && kk < a.K) o[(long)n * a.K + kk] = acc[4 * g + e];
+        }
     if (a.want_bias && tile_k == 0) {
         float* red = lds + S * 2 * TILE;
         __syncthreads();
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 64) o[(long)a.N * a.K + n0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        if (tid < 64 && n0 + tid < a.N) o[(long)a.N * a.K + n0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
     }
 #endif
 }
@@ -605,14 +609,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_h2_kernel(WgradArgs a) {
 hipError_t launch_wgrad_tn(const float* dY, long ldy, const float* X, long ldx, int M, int N, int K, float* out, long slab, int splits,
                            int want_bias, hipStream_t s, bool h2) {
     if (h2 && (N % 128 || K % 128)) return hipErrorInvalidValue;
-    if (N % 64 || K % 64 || M <= 0 || splits < 1 || (double)M * (double)ldy * 4.0 >= 2.0e9 || (double)M * (double)ldx * 4.0 >= 2.0e9)
+    if (N % 4 || K % 4 || M <= 0 || splits < 1 || (double)M * (double)ldy * 4.0 >= 2.0e9 || (double)M * (double)ldx * 4.0 >= 2.0e9)
         return hipErrorInvalidValue;
     WgradArgs a{dY, ldy, X, ldx, out, slab, M, N, K, 0, want_bias};
     const int chunks = (M + 31) / 32;
     a.cps = (chunks + splits - 1) / splits;
     const int slices = (chunks + a.cps - 1) / a.cps;
     if (h2) hipLaunchKernelGGL(wgrad_tn_h2_kernel, dim3((N / 128) * (K / 128), slices), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(wgrad_tn_kernel, dim3((N / 64) * (K / 64), slices), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(wgrad_tn_kernel, dim3(((N + 63) / 64) * ((K + 63) / 64), slices), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
