@@ -88,8 +88,9 @@ enum capf_plan_flag {
                                      * the accuracy / speed trade bench.py reports as `vs_fp32_oracle`                                    */
     CAPF_PLAN_NO_F32X3 = 128,       /* fp32 3x3 stride-1 convs without either split-fp32 tile (igemm_f32h2_ws.hip / igemm_f32x3_ws.hip):
                                      * the Winograd kernels on the fp32 matrix pipe (from batch 24; the direct kernel below)              */
-    CAPF_PLAN_NO_F32H2_GEMM = 512,  /* every OTHER fp32 conv / linear (1x1, stride 2, lone convs, the lifter's projections) on the fp32 matrix pipe at
-                                     * every batch (igemm_f32.hip) instead of the two-fp16-piece GEMM from batch 6 (igemm_f32h2.hip, inference plans) */
+    CAPF_PLAN_NO_F32H2_GEMM = 512,  /* every OTHER fp32 conv / linear (1x1, stride 2, lone convs, the lifter's projections -- forward, input and weight
+                                     * gradients of a training step included) on the fp32 matrix pipe at every batch (igemm_f32.hip) instead of the
+                                     * two-fp16-piece GEMM from batch 6 (igemm_f32h2.hip)                                                        */
     CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
                                      * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
                                      * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured
@@ -329,7 +330,9 @@ int capf_op_conv_f32x3_group(void* stream, int n, const capf_conv_desc* convs);
  * (absolute error <= 2^-39 of that largest value); scales are kept within 2^+-63: block maxima in [2^-49, 2^77) = 1.8e-15 .. 1.5e23 get
  * their exact scale, smaller ones lose precision gradually (all-zero blocks are exact), a block maximum of 2^77 or more overflows fp16
  * (Inf, then NaN); Inf / NaN inputs give NaN for their whole block and chunk (CAPF_PLAN_NO_F32X3 keeps the fp32 pipe's IEEE behaviour).  Same shapes
- * as above; w_packed holds capf_op_conv_f32h2_pack_elems(Cout, Cin) 16-bit elements (pieces, then the fp32 inverse channel scales).      */
+ * as above; w_packed holds capf_op_conv_f32h2_pack_elems(Cout, Cin) 16-bit elements (pieces, then the fp32 inverse channel scales).
+ * Tensor sizes: a tile addresses its pixels and its output rows from per-tile bases, so x / y / residual may exceed 2 GiB (only B * H * W
+ * has to stay below 2^31): conv2 and both transition1 convs at 512 frames (2.1 GB of fp32 each) run here.                                  */
 int64_t capf_op_conv_f32h2_pack_elems(int Cout, int Cin);
 int capf_op_pack_conv_f32h2(void* stream, const float* w_oihw, const float* gamma, const float* beta, const float* mean,
                             const float* var, float eps, void* w_packed_f16, float* bias, int Cout, int Cin);
@@ -343,7 +346,11 @@ int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* convs);
  * [N][Kpad] geometry (Kpad = K rounded up to 32; conv: ks >= 1, w OIHW, K = ks * ks * Cin, BatchNorm folded, bias written if not NULL;
  * linear: ks = 0, Cin ignored, w [N][K], bias untouched) holding [piece 0: 32 fp16 | piece 1: 32 fp16] per 32-deep chunk, then the N
  * fp32 inverse channel scales.  capf_op_conv_f32h2g / capf_op_linear_f32h2g: capf_op_conv / capf_op_linear on that pack (Cin % 4 == 0,
- * Cout % 4 == 0, ks <= 5; K % 32 == 0, N % 4 == 0); capf_op_conv_f32h2g_group: up to 8 such convs in one grid.                          */
+ * Cout % 4 == 0, ks <= 5; K % 32 == 0, N % 4 == 0); capf_op_conv_f32h2g_group: up to 8 such convs in one grid.  A conv's input may exceed
+ * 2 GiB (offsets count from the tile's first input pixel); outputs and rows-mode operands below 4e9 elements / bytes as for capf_op_conv.
+ * The training step uses the same kernel for y = x W^T and dX = dY W (packs of W and W^T rebuilt from the parameters at the start of every
+ * capf_forward_train, DropPath's per-row branch scale in the epilogue) and its sibling wgrad_tn_h2_kernel for dW = dY^T x (both operands
+ * split in the kernel): capf_train_h2_matrices().                                                                                       */
 int64_t capf_op_f32h2_gemm_pack_elems(int N, int K);
 int capf_op_pack_f32h2_gemm(void* stream, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                             float eps, float* w_packed, float* bias, int N, int Cin, int ks, int K);
