@@ -731,8 +731,20 @@ __device__ __forceinline__ const float* pixptr_t(const float* base, long pixel_i
     return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + pixel_index * C);
 }
 
+template <bool BF>
+__device__ __forceinline__ f32x4 ld4_t(const float* pix, int q) {      // channels 4 q .. 4 q + 3 of a pixel
+    if (!BF) return *reinterpret_cast<const f32x4*>(pix + 4 * q);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(pix) + 4 * q);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+}
+
+// One block per (b, p); wave = level.  A wave works on 64 / G (head, sample) pairs at a time, G lanes per pair with one channel QUAD each
+// (16-byte corner loads; G = the largest power of two <= min(64, C / 4)): at 32 channels eight pairs' corners are in flight per wave
+// instead of one pair on half the lanes, and a pair's three sums reduce over G lanes instead of 64.  The pairs' results meet in 384 bytes
+// of LDS per wave for the softmax backward.
 template <int NS, bool BF>
 __global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd) {
+    __shared__ float part[4][16][6];                  // [level][pair]: dw, gx, gy, softmax weight, tanh(ox), tanh(oy)
     const int bp = blockIdx.x;
     const int l = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -746,66 +758,82 @@ __global__ void deform_bwd_kernel(DeformArgs a, float* __restrict__ dAO, int ldd
     float* dao = dAO + row * ldd;
     const float rx = a.ref[bp * 2 + 0], ry = a.ref[bp * 2 + 1];
     const float* dU = a.dU[l] + (long)bp * a.NH * C;
-    for (int h = 0; h < a.NH; ++h) {
-        float ws[NS], th[NS][2], mx = -INFINITY;
+    const int Q = C >> 2;
+    int G = 64;
+    while (G > Q) G >>= 1;
+    const int grp = lane / G, ql = lane - grp * G, PP = 64 / G;
+    for (int k0 = 0; k0 < nk; k0 += PP) {
+        const bool live = k0 + grp < nk;
+        const int k = live ? k0 + grp : nk - 1;
+        const int h = k / NS, s = k - h * NS;
+        float lg[NS], mx = -INFINITY;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { ws[s] = ao[h * NS + s]; mx = fmaxf(mx, ws[s]); }
-        float den = 0.f;
+        for (int t = 0; t < NS; ++t) { lg[t] = ao[h * NS + t]; mx = fmaxf(mx, lg[t]); }
+        float den = 0.f, mine = 0.f;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { ws[s] = expf(ws[s] - mx); den += ws[s]; }
-        float dw[NS], gx[NS], gy[NS];
+        for (int t = 0; t < NS; ++t) { const float e = expf(lg[t] - mx); den += e; if (t == s) mine = e; }
+        const float wsk = mine / den;
+        const float th0 = tanhf(ao[nk + 2 * k + 0]), th1 = tanhf(ao[nk + 2 * k + 1]);
+        const float ux = ((th0 + rx + 1.0f) / 2.0f) * (float)(W - 1);
+        const float uy = ((th1 + ry + 1.0f) / 2.0f) * (float)(H - 1);
+        const float mxk = (ux <= 0.f || ux >= (float)(W - 1)) ? 0.f : 1.f;
+        const float myk = (uy <= 0.f || uy >= (float)(H - 1)) ? 0.f : 1.f;
+        const float x = fminf((float)(W - 1), fmaxf(ux, 0.f)), y = fminf((float)(H - 1), fmaxf(uy, 0.f));
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool vx = x0 + 1 <= W - 1, vy = y0 + 1 <= H - 1;       // +1 corner inside the map
+        const int xb = vx ? x0 + 1 : x0, yb = vy ? y0 + 1 : y0;
+        const float* p00 = pixptr_t<BF>(feat, (long)y0 * W + x0, C);
+        const float* p01 = pixptr_t<BF>(feat, (long)y0 * W + xb, C);
+        const float* p10 = pixptr_t<BF>(feat, (long)yb * W + x0, C);
+        const float* p11 = pixptr_t<BF>(feat, (long)yb * W + xb, C);
+        const float c00 = wx0 * wy0, c01 = wx1 * wy0, c10 = wx0 * wy1, c11 = wx1 * wy1;
+        float a_dw = 0.f, a_gx = 0.f, a_gy = 0.f;
+        for (int q = ql; q < Q; q += G) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dU + (long)h * C + 4 * q);
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 f00 = ld4_t<BF>(p00, q), f01 = vx ? ld4_t<BF>(p01, q) : zero, f10 = vy ? ld4_t<BF>(p10, q) : zero,
+                        f11 = (vx && vy) ? ld4_t<BF>(p11, q) : zero;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            ws[s] /= den;
-            const int k = h * NS + s;
-            th[s][0] = tanhf(ao[nk + 2 * k + 0]);
-            th[s][1] = tanhf(ao[nk + 2 * k + 1]);
-            const float ux = ((th[s][0] + rx + 1.0f) / 2.0f) * (float)(W - 1);
-            const float uy = ((th[s][1] + ry + 1.0f) / 2.0f) * (float)(H - 1);
-            const float mxk = (ux <= 0.f || ux >= (float)(W - 1)) ? 0.f : 1.f;
-            const float myk = (uy <= 0.f || uy >= (float)(H - 1)) ? 0.f : 1.f;
-            const float x = fminf((float)(W - 1), fmaxf(ux, 0.f)), y = fminf((float)(H - 1), fmaxf(uy, 0.f));
-            const float xf = floorf(x), yf = floorf(y);
-            const int x0 = (int)xf, y0 = (int)yf;
-            const float wx1 = x - xf, wy1 = y - yf, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-            const bool vx = x0 + 1 <= W - 1, vy = y0 + 1 <= H - 1;       // +1 corner inside the map
-            const int xb = vx ? x0 + 1 : x0, yb = vy ? y0 + 1 : y0;
-            const float* p00 = pixptr_t<BF>(feat, (long)y0 * W + x0, C);
-            const float* p01 = pixptr_t<BF>(feat, (long)y0 * W + xb, C);
-            const float* p10 = pixptr_t<BF>(feat, (long)yb * W + x0, C);
-            const float* p11 = pixptr_t<BF>(feat, (long)yb * W + xb, C);
-            float a_dw = 0.f, a_gx = 0.f, a_gy = 0.f;
-            for (int c = lane; c < C; c += 64) {
-                const float g = dU[(long)h * C + c];
-                const float f00 = ldf_t<BF>(p00, c), f01 = vx ? ldf_t<BF>(p01, c) : 0.f, f10 = vy ? ldf_t<BF>(p10, c) : 0.f,
-                            f11 = (vx && vy) ? ldf_t<BF>(p11, c) : 0.f;
-                a_dw += g * (((f00 * (wx0 * wy0) + f01 * (wx1 * wy0)) + f10 * (wx0 * wy1)) + f11 * (wx1 * wy1));
-                a_gx += g * ((f01 - f00) * wy0 + (f11 - f10) * wy1);
-                a_gy += g * ((f10 - f00) * wx0 + (f11 - f01) * wx1);
+            for (int e = 0; e < 4; ++e) {
+                a_dw += g[e] * (((f00[e] * c00 + f01[e] * c01) + f10[e] * c10) + f11[e] * c11);
+                a_gx += g[e] * ((f01[e] - f00[e]) * wy0 + (f11[e] - f10[e]) * wy1);
+                a_gy += g[e] * ((f10[e] - f00[e]) * wx0 + (f11[e] - f01[e]) * wx1);
             }
-            dw[s] = wave_sum_t(a_dw);
-            gx[s] = wave_sum_t(a_gx) * ws[s] * 0.5f * (float)(W - 1) * mxk;
-            gy[s] = wave_sum_t(a_gy) * ws[s] * 0.5f * (float)(H - 1) * myk;
         }
-        float dotw = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) dotw += ws[s] * dw[s];
-        if (lane == 0) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int k = h * NS + s;
-                dao[k] = ws[s] * (dw[s] - dotw);
-                dao[nk + 2 * k + 0] = gx[s] * (1.f - th[s][0] * th[s][0]);
-                dao[nk + 2 * k + 1] = gy[s] * (1.f - th[s][1] * th[s][1]);
-            }
+        for (int o = G >> 1; o > 0; o >>= 1) {            // (G is a power of two: the xor partners stay inside the pair's lanes)
+            a_dw += __shfl_xor(a_dw, o, 64);
+            a_gx += __shfl_xor(a_gx, o, 64);
+            a_gy += __shfl_xor(a_gy, o, 64);
+        }
+        if (live && ql == 0) {
+            float* pk = part[l][k];
+            pk[0] = a_dw;
+            pk[1] = a_gx * wsk * 0.5f * (float)(W - 1) * mxk;
+            pk[2] = a_gy * wsk * 0.5f * (float)(H - 1) * myk;
+            pk[3] = wsk; pk[4] = th0; pk[5] = th1;
         }
     }
-    if (lane == 0)
-        for (int k = 3 * nk; k < ldd; ++k) dao[k] = 0.f;      // padding columns of the 64-wide row
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                      // (a wave reads back only what it wrote itself)
+    if (lane < nk) {
+        const int k = lane, h = k / NS;
+        float dotw = 0.f;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) dotw += part[l][h * NS + t][3] * part[l][h * NS + t][0];
+        const float* pk = part[l][k];
+        dao[k] = pk[3] * (pk[0] - dotw);
+        dao[nk + 2 * k + 0] = pk[1] * (1.f - pk[4] * pk[4]);
+        dao[nk + 2 * k + 1] = pk[2] * (1.f - pk[5] * pk[5]);
+    }
+    for (int k = 3 * nk + lane; k < ldd; k += 64) dao[k] = 0.f;      // padding columns of the 64-wide row
 }
 
 hipError_t launch_deform_bwd(const DeformArgs& a, float* dAO, int ldd, hipStream_t s) {
-    if (a.NS != 4 || a.L > 4) return hipErrorInvalidValue;
+    if (a.NS != 4 || a.L > 4 || a.NH * a.NS > 16) return hipErrorInvalidValue;
+    for (int l = 0; l < a.L; ++l)
+        if (a.C[l] < 4 || (a.C[l] & 3)) return hipErrorInvalidValue;
     if (a.feat_bf16) hipLaunchKernelGGL((deform_bwd_kernel<4, true>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a, dAO, ldd);
     else hipLaunchKernelGGL((deform_bwd_kernel<4, false>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a, dAO, ldd);
     return hipGetLastError();
