@@ -198,6 +198,13 @@ hipError_t launch_layernorm(const float* in, RowMap imap, const float* add, RowM
 // so only U = sum_s w_s v_s  [(b,p,h), C_l] is produced here and the projection is a GEMM with
 // M = B*17*4 rows instead of B*17*16 (the [B,17,16,C_l] tensor is never materialised).
 // One block per (b, p); wave w handles level w; lanes stride over channels.
+template <bool BF>
+__device__ __forceinline__ f32x4 ldq(const float* pix, int q) {       // channels 4 q .. 4 q + 3 of a pixel
+    if (!BF) return *reinterpret_cast<const f32x4*>(pix + 4 * q);
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(pix) + 4 * q);
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+
 template <int NS, bool BF>
 __global__ void deform_sample_kernel(DeformArgs a) {
     const int bp = blockIdx.x;
@@ -211,7 +218,15 @@ __global__ void deform_sample_kernel(DeformArgs a) {
     const float* ao = a.AO + ((long)bp * a.L + l) * (a.ld_ao ? a.ld_ao : 3 * nk);
     const float rx = a.ref[bp * 2 + 0], ry = a.ref[bp * 2 + 1];
     float* U = a.U[l] + (long)bp * a.NH * C;
-    for (int h = 0; h < a.NH; ++h) {
+    // G lanes per head, one channel QUAD each (16-byte corner loads; G = the largest power of two <= min(64, C / 4)), 64 / G heads at a
+    // time: at 32 channels all four heads' 64 corner loads are in flight at once.  Per channel the same expression as before, same bits.
+    const int Q = C >> 2;
+    int G = 64;
+    while (G > Q) G >>= 1;
+    const int grp = lane / G, ql = lane - grp * G, PP = 64 / G;
+    for (int h0 = 0; h0 < a.NH; h0 += PP) {
+        const bool live = h0 + grp < a.NH;
+        const int h = live ? h0 + grp : a.NH - 1;
         float lg[NS], mx = -INFINITY;
 #pragma unroll
         for (int s = 0; s < NS; ++s) { lg[s] = ao[h * NS + s]; mx = fmaxf(mx, lg[s]); }
@@ -227,7 +242,7 @@ __global__ void deform_sample_kernel(DeformArgs a) {
             const float px = tanhf(ao[nk + 2 * k + 0]) + rx;
             const float py = tanhf(ao[nk + 2 * k + 1]) + ry;
             const Corner q = corner_of<true>(px, py, H, W);
-            if (a.cidx && lane == 0) {                      // debug taps (capf_set_debug): positions and NW corners
+            if (a.cidx && live && ql == 0) {                // debug taps (capf_set_debug): positions and NW corners
                 const long t = ((((long)bp * a.L + l) * nk) + k) * 2;
                 a.cpos[t] = px; a.cpos[t + 1] = py;
                 a.cidx[t] = q.x0; a.cidx[t + 1] = q.y0;
@@ -241,18 +256,24 @@ __global__ void deform_sample_kernel(DeformArgs a) {
             p00[s] = pixptr<BF>(feat, (long)q.y0 * W + q.x0, C); p01[s] = pixptr<BF>(feat, (long)q.y0 * W + xb, C);
             p10[s] = pixptr<BF>(feat, (long)yb * W + q.x0, C);   p11[s] = pixptr<BF>(feat, (long)yb * W + xb, C);
         }
-        for (int c = lane; c < C; c += 64) {
-            float u = 0.f;
+        if (!live) continue;
+        for (int cq = ql; cq < Q; cq += G) {
+            f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                u += ((ldf<BF>(p00[s], c) * w00[s] + ldf<BF>(p01[s], c) * w01[s]) + ldf<BF>(p10[s], c) * w10[s]) + ldf<BF>(p11[s], c) * w11[s];
-            U[(long)h * C + c] = u;
+            for (int s = 0; s < NS; ++s) {
+                const f32x4 f00 = ldq<BF>(p00[s], cq), f01 = ldq<BF>(p01[s], cq), f10 = ldq<BF>(p10[s], cq), f11 = ldq<BF>(p11[s], cq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] += ((f00[e] * w00[s] + f01[e] * w01[s]) + f10[e] * w10[s]) + f11[e] * w11[s];
+            }
+            *reinterpret_cast<f32x4*>(U + (long)h * C + 4 * cq) = u;
         }
     }
 }
 
 hipError_t launch_deform_sample(const DeformArgs& a, hipStream_t s) {
     if (a.NS != 4 || a.L > 4) return hipErrorInvalidValue;
+    for (int l = 0; l < a.L; ++l)
+        if (a.C[l] < 4 || (a.C[l] & 3)) return hipErrorInvalidValue;
     if (a.feat_bf16) hipLaunchKernelGGL((deform_sample_kernel<4, true>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a);
     else hipLaunchKernelGGL((deform_sample_kernel<4, false>), dim3(a.B * a.J), dim3(64 * a.L), 0, s, a);
     return hipGetLastError();
