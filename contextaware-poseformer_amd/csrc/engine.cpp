@@ -1154,7 +1154,7 @@ int capf_op_executed_flops(const capf_handle* h, int index, int batch, double* f
     if (op.conv && e.wino_now(op, batch) && pk.x3 && capf::gemm_f32x3_wanted(e.gemm_args(op, batch)))
         *flops = (e.x3_h2 ? 3.0 : 6.0) * MN * op.K;               // split-fp32 tiles: three fp16 / six bf16 piece products per fp32 product, on the 16-bit pipe
     else if (op.conv && e.wino_now(op, batch)) *flops = MN * op.Cin * (pk.Kpad == 18 * pk.Cin ? 4.5 : 6.0);
-    else if (const capf::GemmArgs ga = e.gemm_args(op, batch); !op.bf16 && capf::gemm_f32h2g_ok(ga) && !capf::gemm_f32_pw_ok(ga))
+    else if (const capf::GemmArgs ga = e.gemm_args(op, batch); !op.bf16 && capf::gemm_f32_on_h2g(ga))
         *flops = 3.0 * MN * pk.KpadH;                              // two-fp16-piece GEMM: three piece products per fp32 product, on the 16-bit pipe
     else if (op.wino) *flops = MN * pk.Kpad2;                      // small batch: the direct kernel on the direct layout
     else if (pk.rh && op.conv) *flops = MN * op.K;                 // row-halo layout has no K padding (decided per launch; lower bound)

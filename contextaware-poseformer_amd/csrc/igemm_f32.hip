@@ -999,6 +999,13 @@ static bool stem_on_bf16(const GemmArgs& a) {
     return on && gemm_bf16_smallc_ok(a);
 }
 
+// The pointwise kernel or the two-fp16-piece GEMM for a 1x1 conv that both take?  A function of the conv alone (every schedule must pick
+// the same kernel): the pointwise kernel keeps the channel EXPANSIONS (N >= 4 K: layer1's 64 -> 256, bound by their writes -- 2.6-3.1 TB/s on
+// either kernel, tools/bench_pw_h2.py), everything else with a two-piece pack leaves the fp32 pipe (256 -> 64: 106 -> 75 us at batch 64,
+// 687 -> 524 at 512; the fuse layers' 1x1 convs at batch 512, which as a GROUP never reached the pointwise kernel anyway)
+static bool pw_preferred(const GemmArgs& a) { return gemm_f32_pw_ok(a) && (!gemm_f32h2g_ok(a) || a.N >= 4 * a.K); }
+bool gemm_f32_on_h2g(const GemmArgs& a) { return gemm_f32h2g_ok(a) && !pw_preferred(a); }
+
 const char* gemm_f32_kernel_name(const GemmArgs& a) {
     static char buf[N_TILES][2][48];
     static bool init = false;
@@ -1010,7 +1017,7 @@ const char* gemm_f32_kernel_name(const GemmArgs& a) {
     }
     if (a.conv && a.Cin % 4 != 0)
         return stem_on_bf16(a) ? gemm_bf16_smallc_kernel_name(a) : (stem_stream_f32_ok(a) ? "igemm_f32_stem_stream<w4,64x64>" : "igemm_f32_smallc<w4,128x64>");
-    if (gemm_f32_pw_ok(a)) return gemm_f32_pw_kernel_name();
+    if (pw_preferred(a)) return gemm_f32_pw_kernel_name();
     if (gemm_f32h2g_ok(a)) return gemm_f32h2g_kernel_name(a, false);
     if (gemm_f32_rows_splitk(a)) return "igemm_f32_rows_splitk";
     return buf[pick_tile(a)][a.conv ? 1 : 0];
@@ -1111,7 +1118,7 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
         GemmArgs h2[MAXG], rest[MAXG];
         int nh = 0, nr = 0;
         for (int i = 0; i < n; ++i) {
-            if (gemm_f32h2g_ok(list[i]) && !gemm_f32_pw_ok(list[i])) h2[nh++] = list[i];
+            if (gemm_f32_on_h2g(list[i])) h2[nh++] = list[i];
             else rest[nr++] = list[i];
         }
         if (nh) {
@@ -1213,7 +1220,7 @@ hipError_t launch_gemm_f32_group(const GemmArgs* list, int n, hipStream_t s) {
 hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0 || a_in.N <= 0) return hipSuccess;
     if (a_in.Kpad % BK != 0) return hipErrorInvalidValue;
-    if (gemm_f32_pw_ok(a_in)) return launch_gemm_f32_pw(a_in, s);
+    if (pw_preferred(a_in)) return launch_gemm_f32_pw(a_in, s);
     if (gemm_f32h2g_ok(a_in)) return launch_gemm_f32h2g(a_in, s);
     if (a_in.splits <= 1 && worth_splitting(a_in)) return launch_gemm_f32_group(&a_in, 1, s);
     GemmArgs a = a_in;

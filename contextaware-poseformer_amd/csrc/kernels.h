@@ -235,6 +235,7 @@ hipError_t launch_pack_conv_f32h2(const float* w, const float* gamma, const floa
 // 32 rows and 32-deep chunk); weights packed by launch_pack_f32h2_gemm over the fp32 pack's geometry (GemmArgs::Wh2)
 long f32h2_gemm_pack_elems(int N, int Kpad);            // floats
 bool gemm_f32h2g_ok(const GemmArgs& a);
+bool gemm_f32_on_h2g(const GemmArgs& a);               // ... and launch_gemm_f32 / _group send it there (igemm_f32.hip: not the pointwise kernel's expansions)
 hipError_t launch_gemm_f32h2g(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f32h2g_group(const GemmArgs* list, int n, hipStream_t s);     // convs with plain row maps, one grid
 const char* gemm_f32h2g_kernel_name(const GemmArgs& a, bool grouped);
