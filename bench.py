@@ -125,7 +125,7 @@ def workload_string(a, tag):
     head = f"configs[{tag}]" if tag is not None else "custom (not a BASELINE.json configuration)"
     per = (f"batch {a.batch}/GPU" if getattr(a, "scaling", "weak") == "weak" or a.gpus == 1 else
            f"GLOBAL batch {a.batch} split over {a.gpus} GPUs ({a.batch // a.gpus}/GPU, strong scaling)")
-    arith = (("fp32 tensors, fp32 accumulation; 3x3 stride-1 convs from batch 6: " +
+    arith = (("fp32 tensors, fp32 accumulation; 3x3 stride-1 convs from batch 5: " +
               ("fp32 matrix pipe (Winograd / direct; CAPF_PLAN_NO_F32X3)" if getattr(a, "no_f32x3", False) else
                "each operand split exactly into three bf16 pieces, six piece products on the bf16 matrix pipe (CAPF_PLAN_F32X3_EXACT)" if getattr(a, "x3_exact", False) else
                "each operand as two fp16 pieces under exact power-of-two block scales (to 2^-23), three piece products on the 16-bit matrix pipe -- same "

@@ -107,7 +107,7 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
     return CAPF_OK;
 }
 
-// The lifter's linears as two fp16 pieces (igemm_f32h2.hip), rebuilt on the forward's stream when an inference forward of batch >= 6 finds
+// The lifter's linears as two fp16 pieces (igemm_f32h2.hip), rebuilt on the forward's stream when an inference forward of batch >= 5 finds
 // them stale: several linears concatenated along N are packed on their own rows, the inverse scales of all rows follow the whole matrix
 int Engine::ensure_h2g_lifter(hipStream_t s) {
     if (!h2g_lifter_dirty) return CAPF_OK;
@@ -143,7 +143,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
     if (pk.ws || pk.x3) a.Wp3 = pack_arena + pk.w3_off;
     a.x3_h2 = pk.x3 && x3_h2;
-    // the plain fp32 MFMA kernels' problems on the two-fp16-piece GEMM from batch 6 (launch_gemm_f32 / _group route them; below, the fp32
+    // the plain fp32 MFMA kernels' problems on the two-fp16-piece GEMM from batch 5 (launch_gemm_f32 / _group route them; below, the fp32
     // kernels with split-K win); not in a training forward (DropPath row scales), not with a LayerNorm fold
     if (pk.h2g && batch >= H2G_MIN_BATCH && op.ln_w < 0 && !op.bf16 && !op.pw_pair && !(op.wino && wino_now(op, batch))) a.Wh2 = pack_arena + pk.wh_off;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights

@@ -204,9 +204,9 @@ struct Engine {
     std::vector<int> last_variants;   // capf_forward_profile_launches: grouped-bf16 kernel variant per leader op
     bool use_rh = true;            // plan: row-halo layout + kernel for the bf16 3x3 stride-1 convs (CAPF_BF16_RH=0: off, A/B runs)
     bool use_x3 = true;            // plan: split-fp32 tile for the Winograd-eligible fp32 3x3 stride-1 convs (plan_flags & CAPF_PLAN_NO_F32X3 clears it)
-    bool use_h2g = true;           // plan: every other fp32 conv / linear of an inference batch >= 6 on the two-fp16-piece GEMM (igemm_f32h2.hip; plan_flags &
+    bool use_h2g = true;           // plan: every other fp32 conv / linear of an inference batch >= 5 on the two-fp16-piece GEMM (igemm_f32h2.hip; plan_flags &
                                    // CAPF_PLAN_NO_F32H2_GEMM clears it)
-    static constexpr int H2G_MIN_BATCH = 6;
+    static constexpr int H2G_MIN_BATCH = 5;
     bool h2g_lifter_dirty = true;  // the linear packs' two-piece copies are stale (parameters changed since they were packed)
     int ensure_h2g_lifter(hipStream_t s);
     bool x3_h2 = true;             // ... the two-fp16-piece tile (three piece products per MAC); plan_flags & CAPF_PLAN_F32X3_EXACT: the three-bf16-piece tile (six)

@@ -1,6 +1,6 @@
 // fp32 implicit GEMM on the 16-bit matrix pipe for everything that is NOT a 3x3 / stride-1 conv: the 1x1 and stride-2 convs of the HRNet
 // fuse / transition layers (pose_hrnet.py:225-303), lone backbone convs, and the lifter's nn.Linear layers (pose_dformer.py:15-59) from
-// batch 6 up.  Same arithmetic as the two-fp16-piece conv tile (igemm_f32h2_ws_tile.h): an fp32 operand a travels as a1 = fp16(s a),
+// batch 5 up.  Same arithmetic as the two-fp16-piece conv tile (igemm_f32h2_ws_tile.h): an fp32 operand a travels as a1 = fp16(s a),
 // a2 = fp16(s a - a1) under an exact power-of-two scale s, |s a - a1 - a2| <= 2^-23 |s a|, and a1 w1 + a1 w2 + a2 w1 is accumulated in fp32
 // (dropped: a2 w2 <= 2^-22 |a w|) -- three v_mfma_f32_32x32x16_f16 for what igemm_f32.hip issues as eight v_mfma_f32_32x32x2_f32 at 1/16
 // of the rate.  What differs from the conv tile is WHERE the activation is split:

@@ -40,12 +40,14 @@ bool gemm_f32x3_ok(const GemmArgs& a) {
 }
 
 // As for the bf16 tile (igemm_bf16_ws.hip): which kernel a conv runs on is a function of the conv ALONE, so that every schedule of
-// the engine produces the same bits.  From 400 MFLOP and batch 6 up (the HRNet-32 branch convs from batch 6, measured in ms per forward
+// the engine produces the same bits.  From 370 MFLOP and batch 5 up (the HRNet-32 branch convs -- 75.5 MFLOP per frame -- from batch 5:
+// round 5's sweep with the two-piece tile, ms per forward at batch 4 / 5 / 6 / 7 / 8: 2.89 (direct kernels) / 2.79 / 2.85 / 2.96 / 3.01; the rule
+// of rounds 4-5, 400 MFLOP and batch 6, left batch 5 on the direct kernels at 3.62.  Round 4's numbers for the three-piece tile, ms per forward
 // against the direct kernel with split-K / the Winograd kernels: batch 6 3.67 / 3.80 / -, 8 3.76 / 3.90 / 5.47, 16 4.27 / 4.75 / 5.86,
 // 24 4.90 / 6.08 / 6.37; below, the direct kernel wins: batch 4 3.49 / 2.92).  (diag builds: CAPF_F32X3_MIN_MFLOP)
 static bool x3_big_enough(int B, int H, int W, int Cin, int Cout) {
-    static const double min_flop = [] { const char* e = diag_env("CAPF_F32X3_MIN_MFLOP"); return (e ? atof(e) : 400.0) * 1e6; }();
-    return B >= 6 && 2.0 * (double)B * H * W * Cout * 9.0 * Cin >= min_flop;
+    static const double min_flop = [] { const char* e = diag_env("CAPF_F32X3_MIN_MFLOP"); return (e ? atof(e) : 370.0) * 1e6; }();
+    return B >= 5 && 2.0 * (double)B * H * W * Cout * 9.0 * Cin >= min_flop;
 }
 
 bool f32x3_takes(int B, int H, int W, int Cin, int Cout, bool h2) {

@@ -132,10 +132,10 @@ Tensor Engine::conv_bn(const std::string& conv, const std::string& bn, const Ten
     // ... and in the layout of the 2-D halo tile (igemm_bf16_ws.hip), which takes them from 512 tiles per launch
     if (use_bf16 && use_ws && ks == 3 && stride == 1 && x.C % 16 == 0 && Cout % 8 == 0) pk.ws = true;
     // fp32: the Winograd-eligible convs also keep their weights as three bf16 pieces for the split-fp32 tile (igemm_f32x3_ws.hip), which
-    // takes them from 400 MFLOP per conv and batch 6 up (f32x3_takes)
+    // takes them from 370 MFLOP per conv and batch 5 up (f32x3_takes)
     if (use_wino && use_x3 && x.W <= 256) pk.x3 = true;
     // fp32: every conv with 16-byte-aligned channel counts also keeps its weights as two block-scaled fp16 pieces in the direct layout's
-    // geometry (igemm_f32h2.hip): what runs on the plain fp32 MFMA kernel at batch < 6 runs there from batch 6 (1x1 / stride-2 fuse and
+    // geometry (igemm_f32h2.hip): what runs on the plain fp32 MFMA kernel at batch < 5 runs there from batch 5 (1x1 / stride-2 fuse and
     // transition convs, lone convs; the HBM-bound pointwise kernels of layer1 keep theirs)
     if (!use_bf16 && use_h2g && x.C % 4 == 0 && Cout % 4 == 0) { pk.h2g = true; pk.KpadH = use_wino ? pk.Kpad2 : pk.Kpad; }
     packs.push_back(pk);

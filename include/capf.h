@@ -90,7 +90,7 @@ enum capf_plan_flag {
                                      * the Winograd kernels on the fp32 matrix pipe (from batch 24; the direct kernel below)              */
     CAPF_PLAN_NO_F32H2_GEMM = 512,  /* every OTHER fp32 conv / linear (1x1, stride 2, lone convs, the lifter's projections -- forward, input and weight
                                      * gradients of a training step included) on the fp32 matrix pipe at every batch (igemm_f32.hip) instead of the
-                                     * two-fp16-piece GEMM from batch 6 (igemm_f32h2.hip)                                                        */
+                                     * two-fp16-piece GEMM from batch 5 (igemm_f32h2.hip)                                                        */
     CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
                                      * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
                                      * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured
@@ -174,7 +174,7 @@ int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch
 int64_t capf_train_generation(const capf_handle* h);
 int64_t capf_grad_elems(const capf_handle* h);
 int capf_grad_info(const capf_handle* h, int param_index, int64_t* offset);   /* -1: not a lifter parameter */
-/* How many of the lifter's nn.Linear matrices a training step at batch >= 6 multiplies by on the two-fp16-piece GEMM (forward y = x W^T
+/* How many of the lifter's nn.Linear matrices a training step at batch >= 5 multiplies by on the two-fp16-piece GEMM (forward y = x W^T
  * and / or backward dX = dY W; packs of W and W^T are rebuilt from the current parameters at the start of every capf_forward_train).
  * 0: every product of the step runs on the fp32 matrix pipe (CAPF_PLAN_NO_F32H2_GEMM, compute_dtype = bf16, training = 0). */
 int capf_train_h2_matrices(const capf_handle* h);
@@ -307,7 +307,7 @@ int capf_op_pack_conv_bf16_ws(void* stream, const float* w_oihw, const float* ga
 int capf_op_conv_bf16_ws_group(void* stream, int n, const capf_conv_desc* convs);
 
 /* Split-fp32 tile of the 3x3 / stride-1 / pad-1 fp32 conv (csrc/igemm_f32x3_ws.hip; what capf_forward runs for the BasicBlock convs of
- * an fp32 model, pose_hrnet.py:66-95, from 400 MFLOP per conv and batch 6): fp32 tensors in and out; every operand is split, exactly, into three
+ * an fp32 model, pose_hrnet.py:66-95, from 370 MFLOP per conv and batch 5): fp32 tensors in and out; every operand is split, exactly, into three
  * bf16 numbers and the six piece products of weight >= 2^-18 run on the bf16 matrix pipe with fp32 accumulation -- the dropped
  * products are below the rounding of one fp32 multiply, so results agree with the direct fp32 kernel to accumulation order.
  * (Non-finite / denormal operands: an infinite input gives NaN -- Inf - Inf in the split -- where the fp32 pipe gives +-Inf; fp32 denormals are
@@ -338,7 +338,7 @@ int capf_op_pack_conv_f32h2(void* stream, const float* w_oihw, const float* gamm
                             const float* var, float eps, void* w_packed_f16, float* bias, int Cout, int Cin);
 int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* convs);
 
-/* The two-fp16-piece arithmetic for every OTHER fp32 conv / linear (csrc/igemm_f32h2.hip; what capf_forward runs from batch 6 for the 1x1 and
+/* The two-fp16-piece arithmetic for every OTHER fp32 conv / linear (csrc/igemm_f32h2.hip; what capf_forward runs from batch 5 for the 1x1 and
  * stride-2 convs of the fuse / transition layers, pose_hrnet.py:225-303, lone convs, and -- in inference plans -- the lifter's nn.Linear layers,
  * pose_dformer.py:15-59): the activation tile is staged as fp32 and split by the wave that consumes it (one power-of-two scale per wave,
  * 32 rows and 32-deep K chunk), the weights are split at pack time (one scale per output channel); same ranges and the same accuracy

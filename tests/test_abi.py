@@ -148,7 +148,7 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     from capf.lib import PLAN_NO_F32H2_GEMM
     eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
     table = {name: kern for name, kern, _ in eng.op_table(64)}
-    # round 5: from batch 6 the lifter's plain projections run the two-fp16-piece GEMM (64 x 64 tiles as well); the LayerNorm-folded ones
+    # round 5: from batch 5 the lifter's plain projections run the two-fp16-piece GEMM (64 x 64 tiles as well); the LayerNorm-folded ones
     # (K = 128: res blocks' qkv / fc1, context blocks' fc1) and every batch below 6 stay on the fp32 MFMA kernel
     assert table["joint0.qkv"] == "igemm_f32h2g<64x64,rows>" and table["joint0.fc2"] == "igemm_f32h2g<64x64,rows>"
     assert table["res0.qkv"] == "igemm_f32<w4,64x64,rows>"
@@ -158,8 +158,8 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     assert table_f["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
     assert table_f["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
     assert not any(k.startswith("igemm_f32h2g") for k in table_f.values())
-    # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below batch 6 and
-    # the split-fp32 tile from 400 MFLOP per conv (batch 6 for these branches); a plan without that tile (CAPF_PLAN_NO_F32X3) runs them on
+    # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below batch 5 and
+    # the split-fp32 tile from 370 MFLOP per conv (batch 5 for these branches); a plan without that tile (CAPF_PLAN_NO_F32X3) runs them on
     # the Winograd kernel from batch 24
     assert table["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32h2_group_ws"       # (round 5: two fp16 pieces, three products)
     assert {name: kern for name, kern, _ in eng.op_table(6)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_f32h2_group_ws"
@@ -169,7 +169,7 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     assert [k for _, k, _ in eng_x.op_table(64) if not k.startswith("igemm_f32x3")] == [k for _, k, _ in eng.op_table(64) if not k.startswith("igemm_f32h2_")]
     eng_w = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3), device=None)
     assert {name: kern for name, kern, _ in eng_w.op_table(24)}["backbone.stage2.0.branches.0.0.conv1"] == "igemm_wino43_group"   # F(4,3): row length 64 is a multiple of 4
-    # (between batch 6 and the Winograd kernels' batch 24 the direct route is the two-fp16-piece GEMM; the whole fp32-pipe plan of round 3
+    # (between batch 5 and the Winograd kernels' batch 24 the direct route is the two-fp16-piece GEMM; the whole fp32-pipe plan of round 3
     # is CAPF_PLAN_NO_F32X3 | CAPF_PLAN_NO_F32H2_GEMM)
     assert {name: kern for name, kern, _ in eng_w.op_table(16)}["backbone.stage2.0.branches.0.0.conv1"].startswith("igemm_f32h2g<")
     eng_p = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM), device=None)

@@ -53,7 +53,7 @@ def test_forward_matches_reference_golden(name):
 
 def test_reference_golden_frames_at_batch_8_run_the_large_batch_kernels():
     """The reference goldens are batch 2; the kernels the benchmark configurations run -- the split-fp32 conv tile (fp32 3x3 convs on the
-    bf16 matrix pipe, from batch 6), grouped launches without split-K -- start above that.  The two golden frames repeated four times make a
+    bf16 matrix pipe, from batch 5), grouped launches without split-K -- start above that.  The two golden frames repeated four times make a
     batch of 8 whose every replica must reproduce the REFERENCE's joints, context-map slices and token buffers (frames are independent)."""
     name = "w32_256x256_b2"
     case = CASES[name]

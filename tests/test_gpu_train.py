@@ -116,7 +116,7 @@ def test_flat_grad_only_leaves_the_same_gradient_in_the_flat_buffer():
 
 @pytest.mark.parametrize("drop_path", [0.0, 0.3])
 def test_training_step_on_the_two_piece_gemm_agrees_with_the_fp32_pipe(drop_path):
-    """From batch 6 the step's nn.Linear products -- forward y = x W^T and backward dX = dY W -- run on the two-fp16-piece GEMM off packs
+    """From batch 5 the step's nn.Linear products -- forward y = x W^T and backward dX = dY W -- run on the two-fp16-piece GEMM off packs
     made from the current parameters at the start of every step (csrc/train.cpp t_h2_prepare; W and W^T of 56 matrices in three
     launches).  Against the same step on the fp32 matrix pipe (CAPF_PLAN_NO_F32H2_GEMM): prediction, loss and every one of the 191
     gradients, with and without DropPath (the per-row branch scale rides in the GEMM epilogue)."""
