@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256, 3) void igemm_f32h2g_kernel(GemmArgs p, int cf
     __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS];
     const int bid = g2_xcd_remap(blockIdx.x, gridDim.x);
     if (cfg == 0) igemm_h2_tile<128, 64, 64, 32, 2, CONV, PLAIN>(p, bid, lds);
+    else if (cfg == 2) igemm_h2_tile<128, 32, 32, 32, 2, CONV, PLAIN>(p, bid, lds);
     else igemm_h2_tile<64, 64, 32, 32, 3, CONV, PLAIN>(p, bid, lds);
 #endif
 }
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256, 3) void igemm_f32h2g_group_kernel(G2GroupArgs 
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
     if (ga.cfg[pi] == 0) igemm_h2_tile<128, 64, 64, 32, 2, 1, true>(ga.g[pi], bid, lds);
+    else if (ga.cfg[pi] == 2) igemm_h2_tile<128, 32, 32, 32, 2, 1, true>(ga.g[pi], bid, lds);
     else igemm_h2_tile<64, 64, 32, 32, 3, 1, true>(ga.g[pi], bid, lds);
 #endif
 }
@@ -352,11 +354,17 @@ bool gemm_f32h2g_ok(const GemmArgs& a) {
     return true;
 }
 
-static int g2_cfg(const GemmArgs& a) {                      // 128 x 64 tiles once they still give every CU three blocks
+static int g2_cfg(const GemmArgs& a) {                      // 128 x 64 tiles once they give every CU two blocks (512; transition1.1.0.0 at batch 64: 123 -> 116 us)
+    // at most 32 output columns (the fuse layers' convs into the 32-channel branch): 128 x 32 -- four waves along M instead of two waves
+    // multiplying columns that do not exist; the split blocks (32 rows x chunk) are those of the other tiles: same bits
+    if (a.N <= 32 && a.M >= 128) return 2;
     const long big = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-    return big >= 768 ? 0 : 1;
+    return big >= 512 ? 0 : 1;
 }
-static int g2_tiles(const GemmArgs& a, int cfg) { return ((a.M + (cfg == 0 ? 127 : 63)) / (cfg == 0 ? 128 : 64)) * ((a.N + 63) / 64); }
+static int g2_tiles(const GemmArgs& a, int cfg) {
+    if (cfg == 2) return (a.M + 127) / 128;
+    return ((a.M + (cfg == 0 ? 127 : 63)) / (cfg == 0 ? 128 : 64)) * ((a.N + 63) / 64);
+}
 
 static void g2_fill(GemmArgs& a) {
     if (a.conv) {
@@ -419,8 +427,9 @@ hipError_t launch_gemm_f32h2g_group(const GemmArgs* list, int n, hipStream_t s) 
 
 const char* gemm_f32h2g_kernel_name(const GemmArgs& a, bool grouped) {
     if (grouped) return "igemm_f32h2g_group";
-    return a.conv ? (g2_cfg(a) == 0 ? "igemm_f32h2g<128x64,conv>" : "igemm_f32h2g<64x64,conv>")
-                  : (g2_cfg(a) == 0 ? "igemm_f32h2g<128x64,rows>" : "igemm_f32h2g<64x64,rows>");
+    const int cfg = g2_cfg(a);
+    return a.conv ? (cfg == 0 ? "igemm_f32h2g<128x64,conv>" : (cfg == 2 ? "igemm_f32h2g<128x32,conv>" : "igemm_f32h2g<64x64,conv>"))
+                  : (cfg == 0 ? "igemm_f32h2g<128x64,rows>" : (cfg == 2 ? "igemm_f32h2g<128x32,rows>" : "igemm_f32h2g<64x64,rows>"));
 }
 
 // ---- pack: fold (conv: BatchNorm as launch_pack_conv; linear: none) -> one power-of-two scale per output channel -> two fp16 pieces;
