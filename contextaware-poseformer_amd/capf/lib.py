@@ -25,7 +25,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_op_conv_f32h2_pack_elems", "capf_op_pack_conv_f32h2", "capf_op_conv_f32h2_group",
     "capf_abi_version", "capf_op_describe_sized",
     "capf_jpeg_info", "capf_jpeg_coefficients", "capf_jpeg_decode",
-    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g",
+    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g", "capf_op_linear_ln_f32h2g",
 ]
 
 
@@ -146,6 +146,7 @@ def load_library():
     lib.capf_op_pack_f32h2_gemm.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int, c_int]
     lib.capf_op_conv_f32h2g.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     lib.capf_op_linear_f32h2g.argtypes = [P, P, P, P, P, P] + [c_int] * 4
+    lib.capf_op_linear_ln_f32h2g.argtypes = [P, P, P, P, c_float, P, P, P, P] + [c_int] * 4
     lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -785,6 +786,18 @@ def conv_nhwc_f32h2g_group(problems):
     if rc:
         raise CapfError(f"capf_op_conv_f32h2g_group failed ({rc})")
     return outs
+
+
+def linear_ln_f32h2g(x, gamma, beta, eps, wp, bias, n, act=0, residual=None):
+    """y[M, N] = act(LayerNorm(x[M, K]; gamma, beta, eps) @ W^T + bias (+ residual)) on the two-fp16-piece GEMM (K % 32 == 0, K <= 256, N % 4 == 0)."""
+    import torch
+    lib = load_library()
+    M, K = x.shape
+    y = torch.empty(M, n, device=x.device, dtype=torch.float32)
+    rc = lib.capf_op_linear_ln_f32h2g(_stream(x), _p(x), _p(gamma), _p(beta), float(eps), _p(wp), _p(bias), _p(residual), _p(y), M, n, K, act)
+    if rc:
+        raise CapfError(f"capf_op_linear_ln_f32h2g failed ({rc})")
+    return y
 
 
 def linear_f32h2g(x, wp, bias, n, act=0, residual=None):

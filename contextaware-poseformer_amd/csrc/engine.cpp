@@ -144,8 +144,8 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     if (pk.ws || pk.x3) a.Wp3 = pack_arena + pk.w3_off;
     a.x3_h2 = pk.x3 && x3_h2;
     // the plain fp32 MFMA kernels' problems on the two-fp16-piece GEMM from batch 5 (launch_gemm_f32 / _group route them; below, the fp32
-    // kernels with split-K win); not in a training forward (DropPath row scales), not with a LayerNorm fold
-    if (pk.h2g && batch >= H2G_MIN_BATCH && op.ln_w < 0 && !op.bf16 && !op.pw_pair && !(op.wino && wino_now(op, batch))) a.Wh2 = pack_arena + pk.wh_off;
+    // kernels with split-K win); LayerNorm folds of up to 256 columns included (igemm_f32h2.hip, LNA)
+    if (pk.h2g && batch >= H2G_MIN_BATCH && !op.bf16 && !op.pw_pair && !(op.wino && wino_now(op, batch))) a.Wh2 = pack_arena + pk.wh_off;
     if (op.wino && !wino_now(op, batch)) {           // small batch: the direct kernel on the direct-layout copy of the weights
         a.Wp = pack_arena + pk.w2_off;
         a.Kpad = pk.Kpad2;
@@ -874,6 +874,19 @@ int capf_op_linear_f32h2g(void* stream, const float* x, const float* wp, const f
     a.M = M; a.N = N; a.K = K; a.Kpad = K;
     a.amap = capf::row_ld(K); a.omap = capf::row_ld(N); a.rmap = capf::row_ld(N);
     a.act = act;
+    if (!capf::gemm_f32h2g_ok(a)) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_gemm_f32h2g(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
+}
+
+int capf_op_linear_ln_f32h2g(void* stream, const float* x, const float* ln_gamma, const float* ln_beta, float eps, const float* wp,
+                             const float* bias, const float* residual, float* y, int M, int N, int K, int act) {
+    if (K % 32 != 0 || !ln_gamma || !ln_beta) return CAPF_ERR_UNSUPPORTED;
+    capf::GemmArgs a{};
+    a.A = x; a.Wh2 = wp; a.bias = bias; a.res = residual; a.out = y;
+    a.M = M; a.N = N; a.K = K; a.Kpad = K;
+    a.amap = capf::row_ld(K); a.omap = capf::row_ld(N); a.rmap = capf::row_ld(N);
+    a.act = act;
+    a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = eps;
     if (!capf::gemm_f32h2g_ok(a)) return CAPF_ERR_UNSUPPORTED;
     return capf::launch_gemm_f32h2g(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }

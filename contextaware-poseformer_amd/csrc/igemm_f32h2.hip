@@ -24,6 +24,8 @@ namespace capf {
 typedef float g2_f32x4 __attribute__((ext_vector_type(4)));
 typedef float g2_f32x16 __attribute__((ext_vector_type(16)));
 static constexpr int G2_BK = 32;
+static constexpr int G2_LDS_FLOATS = 2 * (128 + 64) * G2_BK;        // the ring, 48 KiB: three blocks per CU for every tile
+static constexpr int G2_LNK = 256;                         // largest LayerNorm'ed width (gamma, beta, 2 x 128 row statistics: 3 KiB behind the 48 KiB ring, still three blocks per CU)
 
 long f32h2_gemm_pack_elems(int N, int Kpad) { return (long)N * Kpad + ((N + 3) & ~3); }      // floats: pieces, then 1 / channel scale
 
@@ -40,7 +42,11 @@ __device__ __forceinline__ long g2_rowmap(const RowMap& r, int m) {
 __device__ __forceinline__ int g2_div(int n, FastDiv d) { return (int)((__umulhi((unsigned)n, d.mul) + (unsigned)n) >> d.shift); }
 
 // one output tile (logical id bid) with the calling 256-thread block; lds: S * (BM + BN) * 32 floats
-template <int BM, int BN, int WM, int WN, int S, int CONV, bool PLAIN>
+// LNA (rows mode): LayerNorm of the A rows over their K <= G2_LNK columns on the way from LDS to the split, as igemm_f32.hip's LNA path has it --
+// row statistics in a prologue (two passes over the row in global memory, while the first chunks' DMA flies), gamma / beta in LDS behind the
+// ring (zeros beyond K), x_hat = ((x - mean) * rstd) * gamma + beta in the same order -- so that the fp32 LayerNorm'ed operand is what gets
+// split: the res / context blocks' qkv and fc1 projections (pose_dformer.py:62-79, 115-138) leave the fp32 matrix pipe too.
+template <int BM, int BN, int WM, int WN, int S, int CONV, bool PLAIN, bool LNA = false>
 __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, float* __restrict__ lds) {
     constexpr int BK = G2_BK;
     constexpr int WAVES_N = BN / WN;
@@ -157,6 +163,53 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
     for (int s = 0; s < S - 1; ++s) {
         if (s < nchunks) { prepare(s); fire_all(s); }
     }
+    float* const ln_g = lds + G2_LDS_FLOATS;                // [G2_LNK] | beta [G2_LNK] | mean [128] | rstd [128]
+    float* const ln_b = ln_g + G2_LNK;
+    float mu_f[TM], rs_f[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { mu_f[i] = 0.f; rs_f[i] = 1.f; }
+    if (LNA) {
+        float* const st_mu = ln_b + G2_LNK;
+        float* const st_rs = st_mu + 128;
+        for (int k = tid * 4; k < p.Kpad; k += 256 * 4) {
+            const bool in = k < p.K;
+            *reinterpret_cast<g2_f32x4*>(ln_g + k) = in ? *reinterpret_cast<const g2_f32x4*>(p.ln_g + k) : g2_f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<g2_f32x4*>(ln_b + k) = in ? *reinterpret_cast<const g2_f32x4*>(p.ln_b + k) : g2_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int TPR = 256 / BM;                       // threads per row (adjacent lanes)
+        const int r = tid / TPR, part = tid % TPR;
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const float* x = p.A + (ok ? g2_rowmap(p.amap, m) : 0);
+        float sum = 0.f;
+        if (ok)
+            for (int k = part * 4; k < p.K; k += TPR * 4) {
+                const g2_f32x4 v = *reinterpret_cast<const g2_f32x4*>(x + k);
+                sum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)p.K;
+        float sq = 0.f;
+        if (ok)
+            for (int k = part * 4; k < p.K; k += TPR * 4) {
+                const g2_f32x4 v = *reinterpret_cast<const g2_f32x4*>(x + k);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) sq += __shfl_xor(sq, o, 64);
+        if (part == 0) {
+            st_mu[r] = ok ? mean : 0.f;
+            st_rs[r] = ok ? 1.0f / sqrtf(sq / (float)p.K + p.ln_eps) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            mu_f[i] = st_mu[wm0 + i * 32 + frow];
+            rs_f[i] = st_rs[wm0 + i * 32 + frow];
+        }
+    }
     int st_read = 0, st_fill = S - 1;
     for (int c = 0; c < nchunks; ++c) {
         // chunk c has landed (the S - 2 youngest chunks may still fly), and every wave is done with the stage chunk c + S - 1 goes into
@@ -181,6 +234,19 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc)
                     bw[j][pc][st] = __builtin_bit_cast(ws_f16x8, *reinterpret_cast<const g2_f32x4*>(&Bs[(wn0 + j * 32 + frow) * BK + (((4 * pc + 2 * st + fhalf) ^ fsw) * 4)]));
+        }
+        if (LNA) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int kq = c * BK + 16 * st + 8 * fhalf + 4 * h;
+                    const g2_f32x4 gq = *reinterpret_cast<const g2_f32x4*>(ln_g + kq), bq = *reinterpret_cast<const g2_f32x4*>(ln_b + kq);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ar[i][st][h][e] = ((ar[i][st][h][e] - mu_f[i]) * rs_f[i]) * gq[e] + bq[e];
+                }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -292,18 +358,17 @@ __device__ __forceinline__ int g2_xcd_remap(int b, int nblk) {
 }
 #endif
 
-static constexpr int G2_LDS_FLOATS = 2 * (128 + 64) * G2_BK;        // 48 KiB: three blocks per CU for both tiles
 static_assert(3 * (64 + 64) * G2_BK <= G2_LDS_FLOATS, "h2 gemm LDS");
 
 // cfg 0: 128 x 64 tile, two stages;  1: 64 x 64, three stages
-template <int CONV, bool PLAIN>
+template <int CONV, bool PLAIN, bool LNA = false>
 __global__ __launch_bounds__(256, 3) void igemm_f32h2g_kernel(GemmArgs p, int cfg) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS + (LNA ? 2 * G2_LNK + 256 : 0)];
     const int bid = g2_xcd_remap(blockIdx.x, gridDim.x);
-    if (cfg == 0) igemm_h2_tile<128, 64, 64, 32, 2, CONV, PLAIN>(p, bid, lds);
-    else if (cfg == 2) igemm_h2_tile<128, 32, 32, 32, 2, CONV, PLAIN>(p, bid, lds);
-    else igemm_h2_tile<64, 64, 32, 32, 3, CONV, PLAIN>(p, bid, lds);
+    if (cfg == 0) igemm_h2_tile<128, 64, 64, 32, 2, CONV, PLAIN, LNA>(p, bid, lds);
+    else if (cfg == 2) igemm_h2_tile<128, 32, 32, 32, 2, CONV, PLAIN, LNA>(p, bid, lds);
+    else igemm_h2_tile<64, 64, 32, 32, 3, CONV, PLAIN, LNA>(p, bid, lds);
 #endif
 }
 
@@ -335,10 +400,11 @@ __global__ __launch_bounds__(256, 3) void igemm_f32h2g_group_kernel(G2GroupArgs 
 static bool g2_plain(const GemmArgs& a) { return a.omap.G == 1 && (!a.res || a.rmap.G == 1); }
 
 // What this kernel takes (a function of the problem alone): fp32 conv (any ks <= 5 / stride / pad, NHWC) or rows-mode GEMM with
-// K % 32 == 0 staged rows, N % 4 == 0, 16-byte aligned output / residual rows, no LayerNorm fold, no split-K
+// K % 32 == 0 staged rows, N % 4 == 0, 16-byte aligned output / residual rows, LayerNorm fold up to 256 columns (plain rows), no split-K
 bool gemm_f32h2g_ok(const GemmArgs& a) {
-    if (!a.Wh2 || a.out_bf16 || a.ln_g || a.splits > 1 || a.M <= 0 || a.N <= 0 || (a.N & 3) || a.Kpad % G2_BK != 0) return false;
+    if (!a.Wh2 || a.out_bf16 || a.splits > 1 || a.M <= 0 || a.N <= 0 || (a.N & 3) || a.Kpad % G2_BK != 0) return false;
     if (a.act == ACT_GELU && a.conv) return false;
+    if (a.ln_g && (a.conv || !a.ln_b || a.K > G2_LNK || a.Kpad > G2_LNK || (a.K & 3) || a.amap.G < 1 || !g2_plain(a))) return false;   // (LNA: plain output rows)
     if (a.conv) {
         if (a.ks < 1 || a.ks > 5 || a.Cin % 4 != 0 || a.K != a.ks * a.ks * a.Cin || a.Ho <= 0 || a.Wo <= 0) return false;
         if ((double)a.H * a.W * a.Cin * 4.0 * 3.0 >= 2.0e9) return false;    // (input offsets count from the tile's first pixel: one tile spans < 2 frames)
@@ -387,6 +453,8 @@ hipError_t launch_gemm_f32h2g(const GemmArgs& a_in, hipStream_t s) {
     if (a.conv) {
         if (!plain) return hipErrorInvalidValue;
         hipLaunchKernelGGL((igemm_f32h2g_kernel<1, true>), dim3(tiles), dim3(256), 0, s, a, cfg);
+    } else if (a.ln_g) {
+        hipLaunchKernelGGL((igemm_f32h2g_kernel<0, true, true>), dim3(tiles), dim3(256), 0, s, a, cfg);
     } else if (plain) {
         hipLaunchKernelGGL((igemm_f32h2g_kernel<0, true>), dim3(tiles), dim3(256), 0, s, a, cfg);
     } else {

@@ -359,6 +359,11 @@ int capf_op_conv_f32h2g(void* stream, const float* x_nhwc, const float* w_packed
 int capf_op_conv_f32h2g_group(void* stream, int n, const capf_conv_desc* convs);
 int capf_op_linear_f32h2g(void* stream, const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                           int M, int N, int K, int act);
+/* ... with LayerNorm(x rows over their K <= 256 columns; gamma, beta [K], eps) folded in front of the product -- Block.norm1 -> attn.qkv and
+ * norm2 -> mlp.fc1 of the res blocks, norm2 -> mlp.fc1 of the DeformableBlocks (pose_dformer.py:62-79, 137-138): statistics in fp32 per row
+ * (two passes), x_hat = ((x - mean) * rstd) * gamma + beta in fp32, and THAT value is split into the two fp16 pieces.                  */
+int capf_op_linear_ln_f32h2g(void* stream, const float* x, const float* ln_gamma, const float* ln_beta, float eps, const float* w_packed,
+                             const float* bias, const float* residual, float* y, int M, int N, int K, int act);
 
 /* Up to 8 independent bf16 convs in one grid (what capf_forward issues per dependency level of the HRNet branches of a bf16 model):
  * capf_conv_desc with bf16 x / w_packed / residual / y.  w_row_halo[i] (optional array, entries may be NULL): the same weights

@@ -148,10 +148,11 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     from capf.lib import PLAN_NO_F32H2_GEMM
     eng = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256), device=None)
     table = {name: kern for name, kern, _ in eng.op_table(64)}
-    # round 5: from batch 5 the lifter's plain projections run the two-fp16-piece GEMM (64 x 64 tiles as well); the LayerNorm-folded ones
-    # (K = 128: res blocks' qkv / fc1, context blocks' fc1) and every batch below 6 stay on the fp32 MFMA kernel
+    # round 5: from batch 5 the lifter's projections run the two-fp16-piece GEMM (64 x 64 tiles as well), the LayerNorm-folded ones
+    # (K = 128: res blocks' qkv / fc1, context blocks' fc1) included; every batch below 5 stays on the fp32 MFMA kernel
     assert table["joint0.qkv"] == "igemm_f32h2g<64x64,rows>" and table["joint0.fc2"] == "igemm_f32h2g<64x64,rows>"
-    assert table["res0.qkv"] == "igemm_f32<w4,64x64,rows>"
+    assert table["res0.qkv"] == "igemm_f32h2g<64x64,rows>" and table["ctx0.fc1"] == "igemm_f32h2g<64x64,rows>"
+    assert {name: kern for name, kern, _ in eng.op_table(4)}["res0.qkv"].startswith("igemm_f32<")
     assert {name: kern for name, kern, _ in eng.op_table(4)}["joint0.qkv"].startswith("igemm_f32<")
     eng_f = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32H2_GEMM), device=None)
     table_f = {name: kern for name, kern, _ in eng_f.op_table(64)}

@@ -1292,6 +1292,36 @@ def test_f32h2g_linear_matches_fp64(M, K, N, act, res):
     assert err <= 1.2e-6 and err <= 2.0 * err32 + 5e-8
 
 
+@pytest.mark.parametrize("M,K,N,act,res,ragged", [(5440, 128, 384, 0, False, False), (5440, 128, 256, 2, False, False), (4352, 128, 256, 2, False, False),
+                                                  (43520, 128, 384, 0, False, False), (201, 96, 52, 0, True, True), (1000, 256, 128, 2, True, False)])
+def test_f32h2g_layernorm_fold_matches_fp64(M, K, N, act, res, ragged):
+    """LayerNorm folded in front of a projection on the two-fp16-piece GEMM (res blocks' norm1 -> qkv and norm2 -> fc1 at batch 64 / 512, the
+    context blocks' norm2 -> fc1; pose_dformer.py:62-79, 137-138; and a ragged problem): rows with offsets and scales far from a standard
+    normal, so that a LayerNorm computed in the wrong place or order would show.  Against fp64 of LayerNorm + Linear (+ GELU), error in units of
+    sum |x_hat| |w| + |b|: 2e-6 (the fp32 LayerNorm itself costs eps_fp32 * |mean| / sigma of x_hat: rows here have |mean| / sigma up to ~8;
+    with offsets of 30 sigma the same kernel measures 3.6e-6, which is the LayerNorm's cancellation, not the split)."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(M + 3 * K + N)
+    x = torch.randn(M, K, generator=g) * (torch.rand(M, 1, generator=g) * 2 + 0.5) + torch.randn(M, 1, generator=g)
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    eps = 1e-6
+    wp, _ = capf.pack_f32h2_gemm(w.cuda())
+    got = capf.linear_ln_f32h2g(x.cuda(), gamma.cuda(), beta.cuda(), eps, wp, b.cuda(), N, act, r.cuda() if res else None).cpu().double()
+    xd = x.double()
+    xh = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * gamma.double() + beta.double()
+    pre = xh @ w.double().t() + b.double()
+    mass = xh.abs() @ w.double().abs().t() + b.double().abs()
+    if res:
+        pre, mass = pre + r.double(), mass + r.double().abs()
+    want = F.gelu(pre) if act == 2 else pre
+    err = ((got - want).abs() / mass).max().item()
+    print(f"h2g LayerNorm + linear {M}x{K}->{N} act {act} res {res}: {err:.2e} of the sum of |terms|")
+    assert err <= 2e-6
+
+
 def test_f32h2g_engine_path_agrees_with_the_fp32_pipe_gemms():
     """Batch 32 HRNet-32 fp32: the product plan runs the fuse / transition / lone convs and the lifter's projections on igemm_f32h2g, a plan
     with CAPF_PLAN_NO_F32H2_GEMM on igemm_f32 (fp32 matrix pipe).  Context maps and poses agree to fp32 roundoff."""
