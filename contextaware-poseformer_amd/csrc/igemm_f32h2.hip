@@ -360,13 +360,15 @@ __device__ __forceinline__ int g2_xcd_remap(int b, int nblk) {
 
 static_assert(3 * (64 + 64) * G2_BK <= G2_LDS_FLOATS, "h2 gemm LDS");
 
-// cfg 0: 128 x 64 tile, two stages;  1: 64 x 64, three stages
+// cfg 0: 128 x 64 tile, two stages, four waves ALONG M (32 rows x 64 columns each: a row block is split by one wave, not by the two of a
+// 2 x 2 grid -- the split's VALU work, not the matrix pipe, bounds this kernel: cfg3 57.6 -> 56.9 ms on one box, same bits);  1: 64 x 64, three
+// stages, 2 x 2 waves;  2: 128 x 32
 template <int CONV, bool PLAIN, bool LNA = false>
 __global__ __launch_bounds__(256, 3) void igemm_f32h2g_kernel(GemmArgs p, int cfg) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float lds[G2_LDS_FLOATS + (LNA ? 2 * G2_LNK + 256 : 0)];
     const int bid = g2_xcd_remap(blockIdx.x, gridDim.x);
-    if (cfg == 0) igemm_h2_tile<128, 64, 64, 32, 2, CONV, PLAIN, LNA>(p, bid, lds);
+    if (cfg == 0) igemm_h2_tile<128, 64, 32, 64, 2, CONV, PLAIN, LNA>(p, bid, lds);
     else if (cfg == 2) igemm_h2_tile<128, 32, 32, 32, 2, CONV, PLAIN, LNA>(p, bid, lds);
     else igemm_h2_tile<64, 64, 32, 32, 3, CONV, PLAIN, LNA>(p, bid, lds);
 #endif
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void igemm_f32h2g_group_kernel(G2GroupArgs 
     const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
     const int bid = (l & 7) * per_xcd + (l >> 3);
     if (bid >= ga.tiles[pi]) return;
-    if (ga.cfg[pi] == 0) igemm_h2_tile<128, 64, 64, 32, 2, 1, true>(ga.g[pi], bid, lds);
+    if (ga.cfg[pi] == 0) igemm_h2_tile<128, 64, 32, 64, 2, 1, true>(ga.g[pi], bid, lds);
     else if (ga.cfg[pi] == 2) igemm_h2_tile<128, 32, 32, 32, 2, 1, true>(ga.g[pi], bid, lds);
     else igemm_h2_tile<64, 64, 32, 32, 3, 1, true>(ga.g[pi], bid, lds);
 #endif
