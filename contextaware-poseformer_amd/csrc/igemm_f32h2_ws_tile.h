@@ -27,6 +27,9 @@
 // THREE blocks per CU at TN = 1 (the three-piece tile: two), so that a block's split phase between its two barriers is covered by
 // two others' MFMAs; 6 VALU instructions per pair of values instead of 11; 4 + 2 TN fragment reads feed 6 TN MFMAs per tap.
 #pragma once
+#ifndef H2_EXPERIMENT
+#define H2_EXPERIMENT 0      // (tools/f32h2_ws.hip knock-outs: timing only)
+#endif
 #include "igemm_bf16_ws_tile.h"
 
 namespace capf {
@@ -156,6 +159,9 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     float* const aux_b = aux_w + 64;                             // [NS] their biases
     int* const aux_px = reinterpret_cast<int*>(aux_b + 64) + wave * 64;   // [2][32] this wave's column -> tile pixel table
     auto publish_max = [&]() {                             // this wave's maximum of the loaded chunk -> aux[wave]
+#if (H2_EXPERIMENT & 1)
+        return;
+#endif
         float m = 0.f;
 #pragma unroll
         for (int j = 0; j < NAU; ++j)
@@ -165,6 +171,9 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
         if (lane == 0) aux[wave] = wm;
     };
     auto block_scale_exp = [&]() -> int {                  // (after the barrier behind publish_max)
+#if (H2_EXPERIMENT & 1)
+        return 127;
+#endif
         const ws_u32x4 v = *reinterpret_cast<const ws_u32x4*>(aux);
         const int m = max(max((int)v[0], (int)v[1]), max((int)v[2], (int)v[3]));
         return __builtin_amdgcn_readfirstlane(h2_scale_exp(m));
@@ -173,6 +182,12 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
             ws_u32x2 u1, u2;
+#if (H2_EXPERIMENT & 1)
+            u1[0] = __float_as_uint(ar[j][0]); u1[1] = __float_as_uint(ar[j][1]); u2[0] = __float_as_uint(ar[j][2]); u2[1] = __float_as_uint(ar[j][3]);
+            *reinterpret_cast<ws_u32x2*>(lds + a_lds[j]) = u1;
+            *reinterpret_cast<ws_u32x2*>(lds + 2 * HP + a_lds[j]) = u2;
+            continue;
+#endif
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 unsigned s1, s2;
@@ -299,7 +314,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     ws_f32x4 rr[2][TN][4];                                  // [pixel block][channel block][h * 2 + q]
     ws_f16x8 af[2][2][2], bfr[2][2][TN];
     for (int cc = 0; cc < NCC; ++cc) {
-        if (cc == NCC - 1) {
+        if (cc == NCC - 1 && !(H2_EXPERIMENT & 32)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -313,6 +328,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
                 }
         }
         auto read_frags = [&](int t, int buf) {            // (in the order the products below consume them)
+            if ((H2_EXPERIMENT & 16) && (t > 0 || cc > 0)) return;
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
                 const int pw = PW_[o], pa = PA_[o];
@@ -335,7 +351,8 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[t & 1][PW_[k]][j], af[t & 1][PA_[k]][i], acc[i][j], 0, 0, 0);
+                        if (!(H2_EXPERIMENT & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[t & 1][PW_[k]][j], af[t & 1][PA_[k]][i], acc[i][j], 0, 0, 0);
+                        else acc[i][j][0] += (float)bfr[t & 1][PW_[k]][j][0] + (float)af[t & 1][PA_[k]][i][0];
             if (t < 8) {                                   // the next tap's 4 + 2 TN fragment reads one at a time behind this tap's MFMAs
 #pragma unroll
                 for (int x = 0; x < 4 + 2 * TN; ++x) {
@@ -350,7 +367,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             publish_max();                                 // chunk cc + 1's pixels were requested a chunk ago
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // everybody is done reading the stage; the four maxima are in place
-            fire_w(cc + 1);
+            if (!(H2_EXPERIMENT & 2)) fire_w(cc + 1);
             const int sn = block_scale_exp();
             if (sn != sb) {                                // (block-uniform) the accumulators move to the new scale: exact
                 const float f = __int_as_float((127 + sn - sb) << 23);
@@ -364,11 +381,22 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             }
             split_a(__int_as_float(sb << 23));
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (cc + 2 < NCC) load_a(cc + 2);
+            if (cc + 2 < NCC && !(H2_EXPERIMENT & 4)) load_a(cc + 2);
             __builtin_amdgcn_s_barrier();
         }
     }
 
+    if (H2_EXPERIMENT & 32) {                              // (timing only: one store per lane that keeps the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 1234.5678f) q.y[tid] = t;
+        return;
+    }
     // ---- epilogue: y = acc / (pixel scale * the channel's weight scale) + bias (+ residual), ReLU
     // (accumulator register 4 g + e of channel block j = channel slice * NS + 32 j + 8 g + 4 fhalf + e of the lane's pixel)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

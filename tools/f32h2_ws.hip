@@ -191,7 +191,7 @@ static double run(int B, int H, int W, int C, int N, bool with_res, bool check, 
 // priorities as knobs (timing only: random operands, no check):  level B policy prio_mask [reps]
 //   policy 0: longest K loop first (the product's order)     1: every problem at the same relative pace (proportional interleave)
 //          2: 256- and 128-channel tiles first, then the 64- and 32-channel tiles interleaved     3: ... then all 32-channel tiles, then the 64-channel ones
-struct LvlArgs { H2Problem g[4]; };
+struct LvlArgs { H2Problem g[8]; };
 __global__ __launch_bounds__(256, 3) void lvl_kernel(LvlArgs ga, const int2* __restrict__ map, int prio_mask) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -204,37 +204,49 @@ __global__ __launch_bounds__(256, 3) void lvl_kernel(LvlArgs ga, const int2* __r
 
 static void level(int B, int policy, int prio_mask, int reps) {
     LvlArgs ga{};
-    int tiles[4];
+    int tiles[8];
+    // LVL_SPLITK: bit i = problem i as TWO problems of half the K depth (what a split-K = 2 of its tiles would cost in this grid, without
+    // the hand-over); LVL_DROP: bit i = leave problem i out
+    const int splitk = getenv("LVL_SPLITK") ? atoi(getenv("LVL_SPLITK")) : 0, drop = getenv("LVL_DROP") ? atoi(getenv("LVL_DROP")) : 0;
+    struct Pd { int R, C, N; };
+    std::vector<Pd> pd;
+    for (int i = 0; i < 4; ++i) {
+        if ((drop >> i) & 1) continue;
+        const int C = 256 >> i, R = 8 << i;
+        if ((splitk >> i) & 1) { pd.push_back({R, C / 2, C}); pd.push_back({R, C / 2, C}); }
+        else pd.push_back({R, C, C});
+    }
+    const int NP = (int)pd.size();
     srand(2);
     auto rnd = [] { return ((rand() & 0xFFFF) * 65536.0 + (rand() & 0xFFFF)) / 4294967296.0 * 2.0 - 1.0; };
     double gf = 0, mb = 0;
-    for (int i = 0; i < 4; ++i) {                          // problem 0 = 256 ch 8x8 (longest K) .. problem 3 = 32 ch 64x64
-        const int C = 256 >> i, R = 8 << i;
+    for (int i = 0; i < NP; ++i) {                          // problem 0 = 256 ch 8x8 (longest K) .. problem 3 = 32 ch 64x64
+        const int C = pd[i].C, R = pd[i].R, N = pd[i].N;
         H2Problem& p = ga.g[i];
-        if (!h2_plan(B, R, R, C, C, 32, &p)) { printf("not eligible\n"); return; }
-        const long nx = (long)B * R * R * C;
-        std::vector<float> hx(nx), hr(nx);
+        if (!h2_plan(B, R, R, C, N, 32, &p)) { printf("not eligible\n"); return; }
+        const long nx = (long)B * R * R * C, ny = (long)B * R * R * N;
+        std::vector<float> hx(nx), hr(ny);
         for (auto& v : hx) v = (float)rnd();
         for (auto& v : hr) v = (float)rnd();
-        std::vector<unsigned short> hp((size_t)h2_pack_elems(C, C));
-        const long np = h2_piece_elems(C, C);
+        std::vector<unsigned short> hp((size_t)h2_pack_elems(N, C));
+        const long np = h2_piece_elems(N, C);
         for (long k = 0; k < np; ++k) hp[k] = f2h_host((float)(rnd() * ((k / (9 * 32 * 16)) & 1 ? 8.0 : 16384.0)));      // piece 0 large, piece 1 small
         float* hinv = reinterpret_cast<float*>(hp.data() + np);
-        for (int n = 0; n < C; ++n) hinv[n] = 1.f / 16384.f / 64.f;
-        std::vector<float> hb(C, 0.1f);
+        for (int n = 0; n < N; ++n) hinv[n] = 1.f / 16384.f / 64.f;
+        std::vector<float> hb(N, 0.1f);
         float *dx, *dres, *dy, *db; unsigned short* dp;
-        hipMalloc(&dx, nx * 4); hipMalloc(&dres, nx * 4); hipMalloc(&dy, nx * 4); hipMalloc(&db, C * 4); hipMalloc(&dp, hp.size() * 2);
-        hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(dres, hr.data(), nx * 4, hipMemcpyHostToDevice);
-        hipMemcpy(db, hb.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(dp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice);
+        hipMalloc(&dx, nx * 4); hipMalloc(&dres, ny * 4); hipMalloc(&dy, ny * 4); hipMalloc(&db, N * 4); hipMalloc(&dp, hp.size() * 2);
+        hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(dres, hr.data(), ny * 4, hipMemcpyHostToDevice);
+        hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice); hipMemcpy(dp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice);
         p.x = dx; p.res = dres; p.y = dy; p.g.bias = db; p.g.wp = dp; p.winv = reinterpret_cast<const float*>(dp + np); p.g.relu = 1;
         tiles[i] = p.g.tiles_m * p.g.NSL;
-        gf += 2.0 * B * R * R * (double)C * 9 * C / 1e9; mb += 3.0 * nx * 4 / 1e6;
+        gf += 2.0 * B * R * R * (double)N * 9 * C / 1e9; mb += (nx + 2.0 * ny) * 4 / 1e6;
     }
     // per XCD x: its contiguous eighth of every problem's tiles, in the policy's order; block b = k * 8 + x
     std::vector<std::vector<int2>> seq(8);
     for (int x = 0; x < 8; ++x) {
-        std::vector<std::vector<int2>> cls(4);
-        for (int i = 0; i < 4; ++i) {
+        std::vector<std::vector<int2>> cls(8);
+        for (int i = 0; i < NP; ++i) {
             const int per = (tiles[i] + 7) / 8;
             for (int k = 0; k < per; ++k) { const int bid = x * per + k; if (bid < tiles[i]) cls[i].push_back(int2{i, bid}); }
         }
@@ -244,7 +256,7 @@ static void level(int B, int policy, int prio_mask, int reps) {
             std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
             for (auto& e : all) seq[x].push_back(e.second);
         };
-        if (policy == 0) { for (int i = 0; i < 4; ++i) for (auto& e : cls[i]) seq[x].push_back(e); }
+        if (policy == 0) { for (int i = 0; i < NP; ++i) for (auto& e : cls[i]) seq[x].push_back(e); }
         else if (policy == 1) interleave({0, 1, 2, 3});
         else if (policy == 2) { for (int i = 0; i < 2; ++i) for (auto& e : cls[i]) seq[x].push_back(e); interleave({2, 3}); }
         else if (policy == 3) { for (int i : {0, 1, 3, 2}) for (auto& e : cls[i]) seq[x].push_back(e); }
