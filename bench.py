@@ -132,8 +132,8 @@ def workload_string(a, tag):
                "measured distance to fp64 as the direct fp32 MFMA kernel; Inf / NaN / |x| >= 1.5e23 give NaN (igemm_f32h2_ws); the exact-operand and "
                "fp32-pipe plans are timed on the same line (exact_split_plan, fp32_pipe_plan)") +
               ("; every other conv / GEMM: fp32 MFMA" if getattr(a, "no_f32x3", False) else
-               "; the other convs and the lifter's plain projections: the same two-piece arithmetic (igemm_f32h2g); pointwise layer1 convs, stem, "
-               "LayerNorm-folded projections: fp32 MFMA")) if a.dtype == "f32" else
+               "; the other convs and the lifter's projections (LayerNorm-folded ones included): the same two-piece arithmetic (igemm_f32h2g); "
+               "pointwise layer1 convs and the stem: fp32 MFMA")) if a.dtype == "f32" else
              "bf16 MFMA operands, fp32 accumulate (backbone convs; lifter GEMMs fp32: --lifter-fp32)" if getattr(a, "lifter_fp32", False) else
              "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)")
     if a.train:

@@ -1607,7 +1607,7 @@ hipError_t launch_gemm_bf16_rows(const void* A_bf16, const void* W_bf16, const f
 }  // namespace capf
 
 #ifdef CAPF_DIAG
-extern "C" int capf_debug_bf16_timeline(unsigned long long* dst, int blocks) {
+extern "C" __attribute__((visibility("default"))) int capf_debug_bf16_timeline(unsigned long long* dst, int blocks) {
     if (blocks > 8192) blocks = 8192;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_bf16_timeline), (size_t)blocks * 64);
 }

@@ -1276,7 +1276,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a_in, hipStream_t s) {
 
 #ifdef CAPF_DIAG
 // (diagnosis build only, not part of include/capf.h) copy the CAPF_ABLATE=7 block timeline to the host
-extern "C" int capf_debug_timeline(unsigned long long* dst, int blocks) {
+extern "C" __attribute__((visibility("default"))) int capf_debug_timeline(unsigned long long* dst, int blocks) {
     if (blocks > capf::DBG_BLOCKS) blocks = capf::DBG_BLOCKS;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_dbg_timeline), (size_t)blocks * 64);
 }

@@ -156,8 +156,9 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int frow = lane & 31, fsw = (frow >> 1) & 7, fhalf = lane >> 5;
     int sb[TM];                                             // biased exponent of the scale the accumulators of row block i are in
+    int smin[TM];                                           // ... of the smallest scale (largest chunk maximum) so far
 #pragma unroll
-    for (int i = 0; i < TM; ++i) sb[i] = 127;
+    for (int i = 0; i < TM; ++i) { sb[i] = 127; smin[i] = 190; }
 
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) {
@@ -257,7 +258,11 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ar[i][st][h][e]));
-            const int sn = h2_scale_exp(h2_wave_max(m));    // wave-uniform
+            // wave-uniform.  A scale never rises more than 2^80 above the smallest one this row block has used: the accumulators hold up
+            // to 2^35 in units of that scale, and following a chunk of zeros (or of values 2^-90 below an earlier chunk) all the way
+            // up would overflow them -- such a chunk's values are below anything the fp32 sum keeps either way
+            const int sn = min(h2_scale_exp(h2_wave_max(m)), (c > 0 ? smin[i] : 190) + 80);
+            smin[i] = c > 0 ? min(smin[i], sn) : sn;
             if (sn != sb[i]) {
                 if (c > 0) {
                     const float f = __int_as_float((127 + sn - sb[i]) << 23);

@@ -286,6 +286,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int sb = block_scale_exp();
+    int smin = sb;
     split_a(__int_as_float(sb << 23));
 
     ws_f32x16 acc[2][TN];
@@ -368,7 +369,10 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // everybody is done reading the stage; the four maxima are in place
             if (!(H2_EXPERIMENT & 2)) fire_w(cc + 1);
-            const int sn = block_scale_exp();
+            // (a scale never rises more than 2^80 above the smallest one of the tile so far: the accumulators hold up to 2^35 in units of
+            // that scale and must not overflow behind a chunk of zeros; values that far below an earlier chunk are below the fp32 sum)
+            const int sn = min(block_scale_exp(), smin + 80);
+            smin = min(smin, sn);
             if (sn != sb) {                                // (block-uniform) the accumulators move to the new scale: exact
                 const float f = __int_as_float((127 + sn - sb) << 23);
 #pragma unroll

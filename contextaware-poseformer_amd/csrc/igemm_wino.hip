@@ -1553,11 +1553,11 @@ hipError_t launch_gemm_wino_group(const GemmArgs* list, int n, hipStream_t s) {
 }  // namespace capf
 
 #ifdef CAPF_DIAG
-extern "C" int capf_debug_wino_timeline(unsigned long long* dst, int blocks) {
+extern "C" __attribute__((visibility("default"))) int capf_debug_wino_timeline(unsigned long long* dst, int blocks) {
     if (blocks > 8192) blocks = 8192;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_wino_timeline), (size_t)blocks * 64);
 }
-extern "C" int capf_debug_wino_phases(unsigned long long* dst, int blocks) {
+extern "C" __attribute__((visibility("default"))) int capf_debug_wino_phases(unsigned long long* dst, int blocks) {
     if (blocks > 8192) blocks = 8192;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capf::capf_wino_phases), (size_t)blocks * 64);
 }

@@ -81,6 +81,17 @@ static int jpeg_parse(const unsigned char* d, size_t n, JpegHeader& h) {
                 h.bits[tc][th][0] = 0;
                 for (int i = 1; i <= 16; ++i) { h.bits[tc][th][i] = s[q + i]; cnt += s[q + i]; }
                 if (cnt > 256 || q + 17 + cnt > sl) return CAPF_ERR_INVALID;
+                // the counts must form a prefix code (jdhuff.c jpeg_make_d_derived_tbl): after the codes of length l the next code may not
+                // exceed 2^l -- an oversubscribed table would index past the decoder's lookup arrays
+                for (int l = 1, code = 0; l <= 16; ++l) {
+                    code += h.bits[tc][th][l];
+                    if (code > (1 << l)) return CAPF_ERR_INVALID;
+                    code <<= 1;
+                }
+                // symbols: a DC symbol is a magnitude category (<= 11 for 8-bit baseline; <= 15 checked here, the decoder refuses > 11),
+                // an AC symbol's low nibble likewise (<= 10)
+                for (int i = 0; i < cnt; ++i)
+                    if (tc == 0 ? s[q + 17 + i] > 15 : (s[q + 17 + i] & 15) > 10) return CAPF_ERR_INVALID;
                 memcpy(h.vals[tc][th], s + q + 17, cnt);
                 h.have_ht[tc][th] = true;
                 q += 17 + cnt;
@@ -216,6 +227,7 @@ static int jpeg_entropy_decode(const unsigned char* d, size_t n, const JpegHeade
                     for (int bx = 0; bx < c.h; ++bx) {
                         short* blk = coef + c.coef_off + ((size_t)(my * c.v + by) * c.bw + (mx * c.h + bx)) * 64;
                         int s = huff_decode(br, dc[c.td]);
+                        if (s > 11) return CAPF_ERR_INVALID;       // (8-bit baseline: DC differences have at most 11 magnitude bits)
                         if (s) { const int r = br.get(s); pred[ci] += extend(r, s); }
                         blk[0] = (short)pred[ci];
                         for (int k = 1; k < 64;) {
@@ -228,6 +240,7 @@ static int jpeg_entropy_decode(const unsigned char* d, size_t n, const JpegHeade
                             }
                             k += r;
                             if (k > 63) break;
+                            if (sz > 10) return CAPF_ERR_INVALID;
                             blk[kZigzag[k]] = (short)extend(br.get(sz), sz);
                             ++k;
                         }

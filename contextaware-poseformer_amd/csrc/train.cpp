@@ -150,15 +150,21 @@ int Engine::t_h2_prepare(hipStream_t s, const TrainLayout& L, float* tw, int B) 
     t_h2_index.clear();
     if (t_h2_specs.empty() || B < H2G_MIN_BATCH) return CAPF_OK;
     bool same = t_h2_on_device;
+    std::vector<const float*> now(t_h2_specs.size());
     for (size_t i = 0; i < t_h2_specs.size(); ++i) {
         const H2TrainSpec& sp = t_h2_specs[i];
-        const float* w = sp.param >= 0 ? params[sp.param].ptr : pack_arena + packs[sp.pack].w_off;
-        if (t_h2_tab[i].w != w) { t_h2_tab[i].w = w; same = false; }
-        t_h2_index[w] = (int)i;
+        now[i] = sp.param >= 0 ? params[sp.param].ptr : pack_arena + packs[sp.pack].w_off;
+        if (t_h2_tab[i].w != now[i]) same = false;
+        t_h2_index[now[i]] = (int)i;
     }
     H2TrainW* tab_dev = reinterpret_cast<H2TrainW*>(pack_arena + t_h2_tab_off);
     if (!same) {
+        // the table is pageable host memory that an earlier step's upload may still be reading, and the device copy may still be in use by
+        // that step's pack kernels: drain the stream before either changes (parameters are re-bound once in a blue moon, not per step)
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t i = 0; i < t_h2_specs.size(); ++i) t_h2_tab[i].w = now[i];
         HIP_TRY(hipMemcpyAsync(tab_dev, t_h2_tab.data(), t_h2_tab.size() * sizeof(H2TrainW), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
         t_h2_on_device = true;
     }
     HIP_TRY(launch_pack_f32h2_train(tab_dev, (int)t_h2_tab.size(), t_h2_tiles, tw + L.h2w, reinterpret_cast<int*>(tw + L.h2max),

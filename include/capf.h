@@ -24,6 +24,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libcapf.so is built with -fvisibility=hidden: the functions declared in this header are its whole dynamic symbol table */
+#pragma GCC visibility push(default)
 
 typedef struct capf_handle capf_handle;
 
@@ -170,7 +172,9 @@ int capf_backward(capf_handle* h, void* stream, const float* grad_out, int batch
 /* Saved activations live in the workspace: ANY later capf_forward* / capf_backbone_forward / capf_lifter_forward /
  * capf_set_workspace invalidates them, and capf_backward then returns CAPF_ERR_STATE instead of differentiating the
  * wrong step.  capf_train_generation changes with every such run: a host autograd node records it after its
- * capf_forward_train and compares before capf_backward (two forwards followed by one combined backward).       */
+ * capf_forward_train and compares before capf_backward (two forwards followed by one combined backward).
+ * The PARAMETERS must not change between a capf_forward_train and its capf_backward either (an optimizer step belongs after the
+ * backward, as in train.py:195-201): the backward multiplies by the packs of W^T that the forward built from the parameters it saw. */
 int64_t capf_train_generation(const capf_handle* h);
 int64_t capf_grad_elems(const capf_handle* h);
 int capf_grad_info(const capf_handle* h, int param_index, int64_t* offset);   /* -1: not a lifter parameter */
@@ -329,7 +333,17 @@ int capf_op_conv_f32x3_group(void* stream, int n, const capf_conv_desc* convs);
  * MFMA kernel on the same problem).  Ranges: values whose magnitude is below 2^-18 of their block's largest lose relative precision
  * (absolute error <= 2^-39 of that largest value); scales are kept within 2^+-63: block maxima in [2^-49, 2^77) = 1.8e-15 .. 1.5e23 get
  * their exact scale, smaller ones lose precision gradually (all-zero blocks are exact), a block maximum of 2^77 or more overflows fp16
- * (Inf, then NaN); Inf / NaN inputs give NaN for their whole block and chunk (CAPF_PLAN_NO_F32X3 keeps the fp32 pipe's IEEE behaviour).  Same shapes
+ * (Inf, then NaN); Inf / NaN inputs give NaN for their whole block and chunk (CAPF_PLAN_NO_F32X3 keeps the fp32 pipe's IEEE behaviour).
+ * THE BOUND, per output y = sum_k a_k w_k, with M_c the largest |a| among the values its block staged for 16-channel chunk c (256 output
+ * pixels + their 1-pixel halo; for capf_op_*_f32h2_gemm: the 32 rows x 32-deep chunk of a wave) and W_c = sum over that chunk of |w_k|:
+ *     |y - exact| <= 1e-6 sum_k |a_k w_k|  +  2^-38 sum_c M_c W_c
+ * -- the first term is what every fp32 evaluation is held to; the second only shows when a block holds values more than 2^18 apart (one
+ * outlier pixel 2^20 above a flat tile costs the flat tile's outputs ~2e-6 of THEIR sum of |terms|).  tests/test_gpu_ops.py
+ * test_f32h2_dynamic_range_inside_a_block asserts exactly this with outliers of 2^8 .. 2^20.  A scale follows the data downwards without limit
+ * and upwards by at most 2^80 above the smallest scale its tile has used (the accumulators must not overflow behind a chunk of zeros).
+ * BATCH COMPOSITION: a block's scale depends on everything the block stages.  Conv tiles never span frames unless H W < 256 (8x8 maps: four
+ * frames per tile); the GEMM's 32-row blocks of the lifter's [B 17, K] operands do.  A frame's output BITS may therefore depend on its
+ * neighbours in the batch (within the bound above); CAPF_PLAN_NO_F32X3 | CAPF_PLAN_NO_F32H2_GEMM gives batch-independent bits.  Same shapes
  * as above; w_packed holds capf_op_conv_f32h2_pack_elems(Cout, Cin) 16-bit elements (pieces, then the fp32 inverse channel scales).
  * Tensor sizes: a tile addresses its pixels and its output rows from per-tile bases, so x / y / residual may exceed 2 GiB (only B * H * W
  * has to stay below 2^31): conv2 and both transition1 convs at 512 frames (2.1 GB of fp32 each) run here.                                  */
@@ -518,6 +532,7 @@ int capf_forward_profile_launches(capf_handle* h, void* stream, const float* ima
                                   float* kcrop_inout, int batch, float* out, float* op_ms, int32_t* op_leader,
                                   int n_ops);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.capf_version()
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + csrc/capf.map: the dynamic symbol table is the header, not the C++ internals (`nm -D` showed
+    capf::launch_* beside the 81 C symbols)."""
+    import shutil
+    import subprocess
+    from capf import lib as capf_lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", capf_lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == _header_symbols()
+
+
 def _cfg(backbone):
     from mvn.utils.cfg import backbone_preset, config
     c = backbone_preset(copy.deepcopy(config), backbone)

@@ -119,6 +119,64 @@ def test_files_outside_the_supported_subset_are_refused_not_misdecoded():
         capf.jpeg_info(good[:40])                                       # truncated inside the tables
 
 
+def _dht_segments(data):
+    """(offset of the table-class byte, counts offset, symbol offset, symbol count) of every Huffman table in the file"""
+    out, p = [], 2
+    while p + 4 <= len(data):
+        m, ln = data[p + 1], (data[p + 2] << 8) | data[p + 3]
+        if m == 0xC4:
+            q = p + 4
+            while q < p + 2 + ln:
+                cnt = sum(data[q + 1:q + 17])
+                out.append((q, q + 1, q + 17, cnt))
+                q += 17 + cnt
+        elif m == 0xDA:
+            break
+        p += 2 + ln
+    return out
+
+
+def test_corrupt_huffman_tables_and_streams_are_refused_or_survived():
+    """a DHT whose code-length counts do not form a prefix code used to index past the decoder's 512-entry lookup tables, and a
+    DC category above 16 reached shifts by >= 64.  The parser now refuses such tables (what libjpeg's jpeg_make_d_derived_tbl does); a stream
+    that is merely garbled decodes to SOMETHING or is refused, without touching memory it does not own."""
+    from capf import lib as capf
+    from capf.lib import CapfError
+    good = bytearray(_golden()["rgb420_q75_odd:jpeg"].tobytes())
+    tabs = _dht_segments(good)
+    assert len(tabs) == 4
+    # oversubscribed: three codes of length 1 (the advisor's example), and 255 codes of length 2
+    for length, n in ((1, 3), (2, 255)):
+        bad = bytearray(good)
+        bad[tabs[0][1] + length - 1] = n
+        with pytest.raises(CapfError):
+            capf.jpeg_info(bytes(bad))
+        with pytest.raises(CapfError):
+            capf.jpeg_coefficients(bytes(bad))
+    # a DC table that names magnitude category 200, an AC table with a 15-bit coefficient
+    for t, sym in ((0, 200), (1, 0x0F)):
+        bad = bytearray(good)
+        tc_off, _, sym_off, cnt = next(x for x in tabs if (good[x[0]] >> 4) == t)
+        assert cnt > 0
+        bad[sym_off] = sym
+        with pytest.raises(CapfError):
+            capf.jpeg_coefficients(bytes(bad))
+    # byte flips anywhere in the file: refused or decoded, never a crash (run under the same process: a wild write would take pytest down)
+    rng = np.random.default_rng(5)
+    refused = 0
+    for _ in range(300):
+        bad = bytearray(good)
+        for pos in rng.integers(2, len(bad), size=int(rng.integers(1, 6))):
+            bad[pos] = int(rng.integers(0, 256))
+        try:
+            capf.jpeg_info(bytes(bad))
+            capf.jpeg_coefficients(bytes(bad))
+        except CapfError:
+            refused += 1
+    assert 0 < refused < 300
+    assert capf.jpeg_coefficients(bytes(good)) is not None               # (and the intact file still decodes)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
 def test_gpu_decode_is_bit_exact_against_the_libjpeg_goldens(name):
