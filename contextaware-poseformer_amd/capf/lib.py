@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.ab
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
 PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512     # capf_plan_flag
-ABI_VERSION = 5        # include/capf.h :: CAPF_ABI_VERSION (checked against capf_abi_version() at load)
+ABI_VERSION = 6        # include/capf.h :: CAPF_ABI_VERSION (checked against capf_abi_version() at load)
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
     "capf_create", "capf_destroy", "capf_last_error", "capf_version", "capf_num_params", "capf_param_info",
@@ -25,7 +25,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_op_conv_f32h2_pack_elems", "capf_op_pack_conv_f32h2", "capf_op_conv_f32h2_group",
     "capf_abi_version", "capf_op_describe_sized",
     "capf_jpeg_info", "capf_jpeg_coefficients", "capf_jpeg_decode",
-    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g", "capf_op_linear_ln_f32h2g",
+    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g", "capf_op_linear_ln_f32h2g", "capf_op_wgrad",
 ]
 
 
@@ -147,6 +147,7 @@ def load_library():
     lib.capf_op_conv_f32h2g.argtypes = [P, P, P, P, P, P] + [c_int] * 8
     lib.capf_op_linear_f32h2g.argtypes = [P, P, P, P, P, P] + [c_int] * 4
     lib.capf_op_linear_ln_f32h2g.argtypes = [P, P, P, P, c_float, P, P, P, P] + [c_int] * 4
+    lib.capf_op_wgrad.argtypes = [P, P, P, c_int, c_int, c_int, P, c_int]
     lib.capf_op_pack_conv_wino.argtypes = [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int]
     lib.capf_op_conv_wino.argtypes = [P, P, P, P, P, P] + [c_int] * 7
     lib.capf_op_linear_bf16.argtypes = [P, P, P, P, P, P] + [c_int] * 4
@@ -810,6 +811,19 @@ def linear_f32h2g(x, wp, bias, n, act=0, residual=None):
     if rc:
         raise CapfError(f"capf_op_linear_f32h2g failed ({rc})")
     return y
+
+
+def wgrad(dy, x, two_piece=True):
+    """(dW[N, K], db[N]) = (dy[M, N]^T @ x[M, K], column sums of dy) through the training step's weight-gradient kernels."""
+    import torch
+    lib = load_library()
+    M, N = dy.shape
+    K = x.shape[1]
+    out = torch.empty(N * K + N, device=x.device, dtype=torch.float32)
+    rc = lib.capf_op_wgrad(_stream(x), _p(dy), _p(x), M, N, K, _p(out), 1 if two_piece else 0)
+    if rc:
+        raise CapfError(f"capf_op_wgrad failed ({rc})")
+    return out[:N * K].view(N, K), out[N * K:]
 
 
 def conv_nhwc_bf16_group(problems):

@@ -878,6 +878,12 @@ int capf_op_linear_f32h2g(void* stream, const float* x, const float* wp, const f
     return capf::launch_gemm_f32h2g(a, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_op_wgrad(void* stream, const float* dY, const float* X, int M, int N, int K, float* dw_db, int two_piece) {
+    if (!dY || !X || !dw_db || M <= 0 || N <= 0 || K <= 0 || N % 4 || K % 4 || (two_piece && (N % 128 || K % 128))) return CAPF_ERR_UNSUPPORTED;
+    return capf::launch_wgrad_tn(dY, N, X, K, M, N, K, dw_db, (long)N * K + N, 1, 1, static_cast<hipStream_t>(stream), two_piece != 0) == hipSuccess
+               ? CAPF_OK : CAPF_ERR_HIP;
+}
+
 int capf_op_linear_ln_f32h2g(void* stream, const float* x, const float* ln_gamma, const float* ln_beta, float eps, const float* wp,
                              const float* bias, const float* residual, float* y, int M, int N, int K, int act) {
     if (K % 32 != 0 || !ln_gamma || !ln_beta) return CAPF_ERR_UNSUPPORTED;

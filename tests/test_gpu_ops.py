@@ -1099,6 +1099,163 @@ def test_f32h2_block_scales_follow_the_data(mode):
     print(f"two-fp16-piece tile, {mode}: {err:.2e} of the sum of |terms|")
 
 
+def _flat_with_outlier(g, shape, kind, e, where):
+    """values of magnitude [0.5, 1) with random signs -- a FLAT block -- and one outlier 2^e above them: `pixel` = every channel of one
+    position, `element` = one value, `channel` = one channel over the whole first sample.  shape = (B, C, ...)."""
+    x = (torch.rand(shape, generator=g) * 0.5 + 0.5) * (torch.randint(0, 2, shape, generator=g).float() * 2 - 1)
+    if kind == "pixel":
+        x[(0, slice(None)) + where] *= 2.0 ** e
+    elif kind == "element":
+        x[(0, 3) + where] *= 2.0 ** e
+    elif kind == "channel":
+        x[0, 20] *= 2.0 ** e
+    return x
+
+
+def _range_check(got, direct, want, mass, slack, what, clean, base=1e-6):
+    """One kernel of the two-piece family on a flat tensor with an outlier, per output:
+      * |got - fp64| <= 2.5 base sum|terms| + 2^-38 slack (include/capf.h, THE BOUND: the first term is what an fp32 accumulation costs when
+        ONE term dominates the sum -- this library's fp32-pipe kernel on the same operands, `direct`, reaches 1 - 2 base there too; the second
+        is the block-scale term, slack = sum_c M_c W_c);
+      * the yardstick of every other test: at most 2 x the fp32-pipe kernel's error (+ the block-scale term);
+      * where `clean` (blocks that hold no outlier): the plain `base` of the fuzz tests.
+    Returns (worst error / sum|terms| over the clean outputs, over the rest, the fp32-pipe kernel's worst)."""
+    rel = (got - want).abs() / mass
+    rel32 = ((direct - want).abs() / mass).max().item()
+    block_term = 2.0 ** -38 * slack / mass
+    assert (rel <= 2.5 * base + block_term).all(), f"{what}: {(rel / (2.5 * base + block_term)).max().item():.2f} of the promised bound"
+    assert (rel <= 2.0 * rel32 + 5e-8 + block_term).all(), f"{what}: {rel.max().item():.3e} vs {rel32:.3e} for the fp32-pipe kernel"
+    worst_clean = rel[clean].max().item() if clean.any() else 0.0
+    assert worst_clean <= base, f"{what}: {worst_clean:.3e} of the sum of |terms| in blocks without an outlier"
+    return worst_clean, rel[~clean].max().item() if (~clean).any() else 0.0, rel32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pixel", "element", "channel"])
+@pytest.mark.parametrize("e", [8, 12, 16, 20])
+def test_f32h2_dynamic_range_inside_a_block(kind, e):
+    """the two-piece arithmetic's error is relative to the BLOCK maximum, and no test had a wide dynamic range INSIDE one block
+    (test_f32h2_block_scales_follow_the_data steps its magnitudes on the kernel's own block / chunk grid).  Here a flat tensor carries one
+    outlier 2^8 .. 2^20 above everything else -- one pixel, one element, one whole channel of the first image -- for the conv tile
+    (igemm_f32h2_ws), the two-piece GEMM as a conv and as a linear (igemm_f32h2g) and the weight gradient (wgrad_tn_h2).  Asserted per output
+    (_range_check): the bound include/capf.h promises with M_c taken over the outlier's whole image (an over-estimate of the block), the
+    fp32-pipe kernel on the same operands as the yardstick, and the plain fuzz-test bound for every output whose blocks hold no outlier (the
+    other images / row blocks / column tiles)."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(1000 * e + len(kind))
+    B, ci, co, H, W = 3, 64, 64, 32, 32
+    # ---- conv tile: 256-pixel tiles are 8 rows of one image; chunks of 16 channels
+    x = _flat_with_outlier(g, (B, ci, H, W), kind, e, (5, 7))
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    bnp = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) * 0.4 + 0.8)
+    bn_cuda = tuple(t.cuda() for t in bnp)
+    wp, bias = capf.pack_conv_f32h2(w.cuda(), bn_cuda)
+    wd, bd = capf.pack_conv(w.cuda(), bn_cuda)
+    w_fold = wd.cpu().double()[:, :9 * ci].view(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
+    r = torch.randn(B, co, H, W, generator=g)
+    xg, rg = x.permute(0, 2, 3, 1).contiguous().cuda(), r.permute(0, 2, 3, 1).contiguous().cuda()
+    got, = capf.conv_nhwc_f32h2_group([(xg, wp, bias, 0, rg, co)])
+    direct = capf.conv_nhwc(xg, wd, bd, 3, 1, 0, rg)
+    assert torch.isfinite(got).all()
+    xd = x.double()
+    want = F.conv2d(xd, w_fold, bias.double().cpu(), 1, 1) + r.double()
+    mass = F.conv2d(xd.abs(), w_fold.abs(), bias.double().abs().cpu(), 1, 1) + r.double().abs()
+    m_c = xd.abs().view(B, ci // 16, 16, H, W).amax(dim=(2, 3, 4))                      # [B, chunk]: largest value of the image's chunk
+    w_c = w_fold.abs().view(co, ci // 16, 16 * 9).sum(dim=2)                            # [co, chunk]
+    slack = (m_c @ w_c.t())[:, :, None, None].expand_as(want)
+    clean = torch.zeros_like(want, dtype=torch.bool)
+    clean[1:] = True
+    nchw = lambda t: t.double().cpu().permute(0, 3, 1, 2)
+    c1, d1, f1 = _range_check(nchw(got), nchw(direct), want, mass, slack, f"conv tile, {kind} 2^{e}", clean)
+    # ---- the two-piece GEMM as a stride-2 conv (chunks of 32 of k = (kh, kw, ci): one half of the channels of one tap)
+    wpg, biasg = capf.pack_f32h2_gemm(w.cuda(), bn_cuda)
+    got2 = capf.conv_nhwc_f32h2g(xg, wpg, biasg, 3, 2, 0, None, co)
+    direct2 = capf.conv_nhwc(xg, wd, bd, 3, 2, 0, None)
+    want2 = F.conv2d(xd, w_fold, biasg.double().cpu(), 2, 1)
+    mass2 = F.conv2d(xd.abs(), w_fold.abs(), biasg.double().abs().cpu(), 2, 1)
+    m_h = xd.abs().view(B, ci // 32, 32, H, W).amax(dim=(2, 3, 4))
+    w_h = w_fold.abs().view(co, ci // 32, 32 * 9).sum(dim=2)
+    slack2 = (m_h @ w_h.t())[:, :, None, None].expand_as(want2)
+    clean2 = torch.zeros_like(want2, dtype=torch.bool)
+    clean2[1:] = True                                                                   # (16 x 16 outputs per image: row blocks of 32 never span images)
+    c2, d2, f2 = _range_check(nchw(got2), nchw(direct2), want2, mass2, slack2, f"two-piece GEMM (conv), {kind} 2^{e}", clean2)
+    # ---- ... as a linear (the lifter's joint-block shape at batch 64): row blocks of 32, chunks of 32 columns -- M_c exactly
+    M, K, N = 1088, 640, 640
+    xl = _flat_with_outlier(g, (1, M, K), "none", 0, ())[0]
+    if kind == "pixel":
+        xl[100, :] *= 2.0 ** e                                                          # a whole row
+    elif kind == "element":
+        xl[100, 7] *= 2.0 ** e
+    else:
+        xl[:, 7] *= 2.0 ** e                                                            # a whole column: every row block holds the outlier
+    wl = torch.randn(N, K, generator=g) / K ** 0.5
+    bl = torch.randn(N, generator=g) * 0.1
+    wpl, _ = capf.pack_f32h2_gemm(wl.cuda())
+    gotl = capf.linear_f32h2g(xl.cuda(), wpl, bl.cuda(), N, 0, None).cpu().double()
+    directl = capf.linear(xl.cuda(), wl.cuda(), bl.cuda(), 0, None).cpu().double()
+    wantl = xl.double() @ wl.double().t() + bl.double()
+    massl = xl.double().abs() @ wl.double().abs().t() + bl.double().abs()
+    m_rc = xl.double().abs().view(M // 32, 32, K // 32, 32).amax(dim=(1, 3))               # [row block, chunk]
+    w_nc = wl.double().abs().view(N, K // 32, 32).sum(dim=2)                            # [N, chunk]
+    slackl = (m_rc @ w_nc.t()).repeat_interleave(32, 0)
+    cleanl = (m_rc.amax(dim=1) < 2.0).repeat_interleave(32, 0)[:, None].expand_as(wantl)
+    c3, d3, f3 = _range_check(gotl, directl, wantl, massl, slackl, f"two-piece GEMM (linear), {kind} 2^{e}", cleanl, 1.2e-6)
+    # ---- the weight gradient: both operands split, scales that only go down along M, so everything BEHIND the outlier runs on its scale
+    # (a 2048-term fp32 sum: base 2e-6, what the fp32-pipe kernel is held to in the training tests)
+    Mw, Nw, Kw = 2048, 256, 128
+    dy = _flat_with_outlier(g, (1, Mw, Nw), "none", 0, ())[0]
+    if kind == "pixel":
+        dy[300, :128] *= 2.0 ** e                                                       # a whole row of the first 128-column tile
+    else:
+        dy[300, 5 if kind == "element" else 70] *= 2.0 ** e                             # one value (the second 128-column tile stays flat)
+    xw = _flat_with_outlier(g, (1, Mw, Kw), "none", 0, ())[0]
+    gw, gb = capf.wgrad(dy.cuda(), xw.cuda(), True)
+    gw32, gb32 = capf.wgrad(dy.cuda(), xw.cuda(), False)
+    wantw = dy.double().t() @ xw.double()
+    massw = dy.double().abs().t() @ xw.double().abs()
+    blk_max = dy.double().abs().view(Mw, Nw // 128, 128).amax(dim=(0, 2))                 # largest dY value a 128-column tile ever sees
+    slackw = (blk_max.repeat_interleave(128)[:, None] * xw.double().abs().sum(dim=0)[None, :]
+              + xw.double().abs().max() * dy.double().abs().sum(dim=0)[:, None])
+    cleanw = (blk_max.repeat_interleave(128) < 2.0)[:, None].expand_as(wantw)
+    c4, d4, f4 = _range_check(gw.cpu().double(), gw32.cpu().double(), wantw, massw, slackw, f"weight gradient, {kind} 2^{e}", cleanw, 2e-6)
+    col_mass = dy.double().abs().sum(dim=0)
+    for b_ in (gb, gb32):                                                               # (the bias column sums: plain fp32 sums in both kernels)
+        assert ((b_.cpu().double() - dy.double().sum(dim=0)).abs() <= 1e-5 * col_mass).all()
+    print(f"outlier 2^{e} ({kind}): error / sum|terms| in blocks without | with the outlier [fp32-pipe kernel, same operands] -- conv tile {c1:.1e} | {d1:.1e} [{f1:.1e}];"
+          f" GEMM conv {c2:.1e} | {d2:.1e} [{f2:.1e}]; GEMM linear {c3:.1e} | {d3:.1e} [{f3:.1e}]; weight gradient {c4:.1e} | {d4:.1e} [{f4:.1e}]")
+
+
+@pytest.mark.gpu
+def test_f32h2_scales_do_not_chase_a_chunk_of_zeros_into_overflow():
+    """an all-zero chunk (padding taps, dead ReLU channels, DropPath rows) used to pull the running scale to its ceiling; behind a
+    chunk whose maximum is ~1e14 the accumulators (2^35 in units of that chunk's scale) were multiplied by 2^90 and overflowed.  Channels 0-31 at
+    1e14, channels 32-63 zero, for the conv tile and the GEMM: finite and within the usual bound."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(99)
+    B, ci, co, H, W = 2, 64, 64, 16, 16
+    x = torch.randn(B, ci, H, W, generator=g) * 1e14
+    x[:, 32:] = 0.0
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    wp, bias = capf.pack_conv_f32h2(w.cuda(), None)
+    w_fold = _x3_fold(capf.pack_conv_f32x3(w.cuda(), None)[0], co, ci)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    got, = capf.conv_nhwc_f32h2_group([(xg, wp, bias, 0, None, co)])
+    assert torch.isfinite(got).all()
+    _x3_check(got, x, w_fold, bias, None, 0, "conv tile behind a chunk of zeros")
+    wpg, biasg = capf.pack_f32h2_gemm(w.cuda(), None)
+    got2 = capf.conv_nhwc_f32h2g(xg, wpg, biasg, 3, 1, 0, None, co)
+    assert torch.isfinite(got2).all()
+    _x3_check(got2, x, w_fold, biasg, None, 0, "two-piece GEMM behind a chunk of zeros")
+    xl = torch.randn(256, 128, generator=g) * 1e14
+    xl[:, 64:] = 0.0
+    wl = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    wpl, _ = capf.pack_f32h2_gemm(wl.cuda())
+    gotl = capf.linear_f32h2g(xl.cuda(), wpl, torch.zeros(128).cuda(), 128, 0, None).cpu().double()
+    wantl = xl.double() @ wl.double().t()
+    assert torch.isfinite(gotl).all()
+    assert ((gotl - wantl).abs() / (xl.double().abs() @ wl.double().abs().t())).max().item() <= 1e-6
+
+
 @pytest.mark.parametrize("chans,B", [((32, 64, 128, 256), 9), ((48, 96, 192, 384), 5), ((64, 128, 256, 512), 3)])
 def test_grouped_f32h2_launch_matches_torch_and_single_launches(chans, B):
     """The four HRNet branch convs as ONE grouped launch of the two-fp16-piece tile against fp64 F.conv2d, bit-identical to the four
