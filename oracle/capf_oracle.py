@@ -88,6 +88,22 @@ class _NoRound(Numerics):
 _NOROUND = _NoRound()
 
 
+class _StreamFP32(Numerics):
+    """The A/B VERDICT r4 / r5 asked about ("bf16 only as MFMA operands, residual stream fp32"): every backbone
+    activation stays fp32 in memory and is rounded to bf16 where a conv reads it as an MFMA operand; weights as in BF16.  Backbone only
+    (ca_pf_forward(emulate_bf16="stream_fp32") keeps the lifter on the engine's bf16 placement)."""
+
+    def __init__(self):
+        super().__init__(True)
+        self.stream = True
+
+    def r(self, x):
+        return x
+
+
+BF16_STREAM_FP32 = _StreamFP32()
+
+
 def _cbr(P, conv, bn, x, stride=1, pad=0, relu=True, res=None, nm=FP32):
     """conv (bias=False) + eval BatchNorm (+ residual) (+ ReLU): ONE launch of the engine (csrc/plan.cpp conv_bn), so in
     bf16 mode ONE rounding at the end.  fp32 mode is literally relu(bn(conv(x)) + res)."""
@@ -98,6 +114,8 @@ def _cbr(P, conv, bn, x, stride=1, pad=0, relu=True, res=None, nm=FP32):
         #   sc = gamma / sqrt(var + eps);  w' = bf16(w * sc);  bias = beta - mean * sc  (fp32)
         sc = P[bn + ".weight"] / torch.sqrt(P[bn + ".running_var"] + BN_EPS)
         w = bf16_round(P[conv + ".weight"] * sc.view(-1, 1, 1, 1))
+        if getattr(nm, "stream", False):
+            x = bf16_round(x)                                 # (fp32 in memory, bf16 as the MFMA operand)
         y = F.conv2d(x, w, P[bn + ".bias"] - P[bn + ".running_mean"] * sc, stride, pad)
     if res is not None:
         y = y + res
@@ -483,12 +501,16 @@ def ca_pf_forward(P, images, k2d, kcrop, backbone="hrnet_32", levels=4, explicit
     nm = BF16 if emulate_bf16 else FP32
     x = images.permute(0, 3, 1, 2).contiguous()
     ref = normalise_crop_keypoints_(kcrop)
-    feats = cpn_forward(P, x, nm=nm, taps=taps) if backbone == "cpn" else hrnet_forward(P, x, nm=nm)
+    if emulate_bf16 == "stream_fp32":
+        assert backbone != "cpn"
+        feats = hrnet_forward(P, x, nm=BF16_STREAM_FP32)
+    else:
+        feats = cpn_forward(P, x, nm=nm, taps=taps) if backbone == "cpn" else hrnet_forward(P, x, nm=nm)
     if taps is not None:
         taps["ref"] = ref.clone()
         taps["features"] = feats
     return lifter_forward(P, k2d, ref, feats, levels=levels, explicit=explicit, taps=taps, drop_masks=drop_masks,
-                          emulate_bf16=emulate_bf16, cells=cells)
+                          emulate_bf16=bool(emulate_bf16), cells=cells)
 
 
 def mpjpe(pred, gt):
