@@ -97,6 +97,9 @@ def parse(argv=None):
                     help="inference, rank 0 at N=1: after the contract's one-batch-at-a-time measurement, ALSO time the same K steps "
                          "issued round-robin over this many engines (own workspaces, own HIP streams) so that consecutive batches "
                          "overlap; reported under \"overlapped_steps\", never as \"value\" (0 / 1 = skip)")
+    ap.add_argument("--sustain", type=float, default=2.5,
+                    help="rank 0 at N=1: after the timed region, loop the same step for at least this many seconds with board power and "
+                         "shader clock sampled (rocm-smi) -- reported under \"sustained\", never as \"value\" (0 = skip)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak (default, the driver's contract) = --batch frames on EVERY GPU; strong (BASELINE.md section 4 item 4) = --batch is the "
                          "GLOBAL batch, split evenly across the ranks (shard_bounds), so total work is fixed as N grows")
@@ -399,6 +402,54 @@ def main():
                         "allreduce_ms": round(acc_ms[2] / nrep, 3), "optimizer_ms": round(acc_ms[3] / nrep, 3),
                         "note": "HIP events on the step's stream over 3 untimed extra steps; optimizer = fused AdamW + the lifter repack"}
 
+    def measure_sustained():
+        # ---- the SAME step looped for >= a.sustain seconds with board power and shader clock sampled from rocm-smi meanwhile: the timed
+        # region above is K steps (0.1 - 1 s) on a part that sits on a 1.4 kW package cap -- this says what rate and clock the step
+        # HOLDS.  Reported under "sustained", never as `value`.
+        if world != 1 or a.sustain <= 0:
+            return None
+        import re
+        import shutil
+        import threading
+        smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                try:
+                    txt = subprocess.run([smi, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                except Exception:
+                    return
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+                ck = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)
+                if pw and ck:
+                    samples.append((time.perf_counter(), float(pw.group(1)), int(ck.group(1))))
+
+        th = threading.Thread(target=sampler, daemon=True)
+        n = 0
+        with (torch.enable_grad() if a.train else torch.no_grad()):
+            torch.cuda.synchronize(dev)
+            th.start()
+            t0 = time.perf_counter()
+            while True:
+                for _ in range(10):
+                    step()
+                n += 10
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                if t1 - t0 >= a.sustain:
+                    break
+        stop.set()
+        th.join(timeout=15)
+        under = sorted((p_, c_) for t_, p_, c_ in samples if t0 + 0.3 <= t_ <= t1)          # (samples taken under load)
+        med = lambda v: v[len(v) // 2] if v else None
+        pw, ck = sorted(x[0] for x in under), sorted(x[1] for x in under)
+        return {"seconds": round(t1 - t0, 2), "steps": n, "frames_per_s": round(n * B / (t1 - t0), 2), "ms_per_step": round((t1 - t0) / n * 1e3, 4),
+                "power_w": {"min": pw[0], "median": med(pw), "max": pw[-1]} if pw else None,
+                "sclk_mhz": {"min": ck[0], "median": med(ck), "max": ck[-1]} if ck else None, "samples": len(under),
+                "note": "the timed step looped back to back (host sync every 10 steps) with rocm-smi --showpower --showclocks sampled in a thread; "
+                        "not `value`"}
+
     def measure_overlapped():
         # ---- consecutive batches in flight on separate HIP streams (a serving loop's option, NOT the contract's step: two batches
         # of B frames are resident at once, so this never becomes `value`).  The lifter's 17-token kernels, the low-resolution
@@ -569,11 +620,15 @@ def main():
             sha_now = csrc_sha()
         except Exception:
             sha_now = None
-        for rnd in ("r05", "r04", "r03", "r02"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
             if traffic is None and tstale is None and tag is not None and os.path.exists(tfile):
                 data = json.load(open(tfile)).get(f"cfg{tag}", {})
-                got = data.get(dname, {}).get("hbm_bytes_per_launch") if isinstance(data.get(dname), dict) else None
+                ent = data.get(dname) if isinstance(data.get(dname), dict) else {}
+                # a "launch" of this line is what `launches_per_step` counts -- one grouped launch of a dependency LEVEL, which at batch
+                # 512 is TWO kernel launches (64- and 32-channel tiles): prefer the file's bytes per FORWARD over this run's levels per
+                # forward; an older file only has the per-kernel-launch average
+                got = (ent["hbm_bytes_per_forward"] / max(1, dn // nprof)) if ent.get("hbm_bytes_per_forward") else ent.get("hbm_bytes_per_launch")
                 if got is None:
                     continue
                 sha_then = data.get("_csrc_sha")
@@ -620,6 +675,7 @@ def main():
                 ex = e[4] / (e[0] * 1e-3) / 1e12 if e[0] > 0 else 0
                 print(f"  {k:34s} {e[2] // nprof:4d} launches/step {e[0] / nprof:9.3f} ms/step {tf:8.2f} TFLOP/s(alg) {ex:8.2f} TFLOP/s(exec) "
                       f"{gb:8.1f} GB/s(alg)", file=sys.stderr)
+        sustained = measure_sustained()
         overlapped = measure_overlapped()                     # (extra measurements run after the per-launch timing passes: they leave the chip warm)
         exact_split_plan = measure_alt_plan(PLAN_F32X3_EXACT, "exact_split_plan", "plan_flags |= CAPF_PLAN_F32X3_EXACT: the 3x3 convs on round 4's tile -- every operand "
                                             "split EXACTLY into three bf16 pieces, six piece products per fp32 product; not the headline")
@@ -639,6 +695,8 @@ def main():
         }
         if dist_info is not None:
             result["distributed"] = dist_info
+        if sustained is not None:
+            result["sustained"] = sustained
         if overlapped is not None:
             result["overlapped_steps"] = overlapped
         if exact_split_plan is not None:

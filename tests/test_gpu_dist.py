@@ -23,15 +23,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", one_device=True):
     for p in (os.path.join(ROOT, "contextaware-poseformer_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0" if one_device else str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from capf import dist as cd, synth
     from conftest import make_model
     from mvn.models.loss import MPJPE
-    cd.init_from_env("gloo")
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(0 if one_device else rank)
+    cd.init_from_env(backend)
     model, _ = make_model("hrnet_32", device="cuda", wseed=11)
     model.train(); model.backbone.eval(); model.drop_path_rate = 0.0
     cd.broadcast_state_(model.volume_net)
@@ -69,6 +71,26 @@ def test_two_ranks_allreduce_the_real_flat_gradient():
         assert p.exitcode == 0
     for rank, err, scale, n in res:
         print(f"rank {rank}: max |mean of shard grads - full-batch grad| = {err:.3e} (grad max {scale:.3e}, {n} elements)")
+        assert n == 14094147 and err <= 2e-5 * scale + 1e-9
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="a REAL multi-rank RCCL all-reduce needs two visible devices (RCCL refuses two ranks on one)")
+def test_two_ranks_allreduce_the_real_flat_gradient_over_rccl():
+    """wherever two devices are visible (the driver's 8-GPU node), the first multi-rank RCCL execution of this repository is a
+    TEST, not the scaling bench: one rank per device, backend nccl (= RCCL, xGMI between the devices), the same check as the gloo test above --
+    the mean of the two half-batch flat gradients that capf_backward wrote equals the full-batch gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl", False)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, scale, n in res:
+        print(f"RCCL rank {rank}: max |mean of shard grads - full-batch grad| = {err:.3e} (grad max {scale:.3e}, {n} elements)")
         assert n == 14094147 and err <= 2e-5 * scale + 1e-9
 
 

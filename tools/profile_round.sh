@@ -10,13 +10,13 @@ TAG=${1:-r2}; KEY=${2:-cfg1}; shift; shift
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --no-cpu-baseline --no-alt-plan $*"     # (the traced passes time the product plan only)
+BENCH="python $PWD/bench.py --no-cpu-baseline --no-alt-plan --sustain 0 $*"     # (the traced passes time the product plan only)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH --steps 10 --overlap 0 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH --steps 2 --warmup 1 --profile-steps 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $BENCH --steps 2 --warmup 1 --profile-steps 1 > $OUT/pmc_write.log 2>&1
 cd - > /dev/null
-python tools/summarize_profiles.py $OUT ${ROUND:-r05} $KEY > $OUT/summarize.log 2>&1
+python tools/summarize_profiles.py $OUT ${ROUND:-r06} $KEY > $OUT/summarize.log 2>&1
 python bench.py --kernel-table $* > $OUT/bench.json 2> $OUT/bench.err
 tail -n 1 $OUT/bench.json | cut -c1-400
 # keep only what summarize_profiles.py reads (the raw traces are hundreds of MB)

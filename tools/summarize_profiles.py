@@ -133,6 +133,13 @@ def main():
             t["read_bytes_per_launch"] = 2.0 * t["FETCH_SIZE_KiB"] * 1024 / n      # gfx950 correction, see docstring
             t["write_bytes_per_launch"] = t["WRITE_SIZE_KiB"] * 1024 / n
             t["hbm_bytes_per_launch"] = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
+        # bytes per FORWARD: the stem kernel runs once per forward in every configuration, so its launch count is the number of forwards the
+        # counters saw -- bench.py divides by ITS count of grouped launches per forward (a level of the two-piece tile is two kernel launches
+        # at batch 512, which made cfg3's per-kernel-launch average read as half a level in round 5)
+        fw = [t["launches"] for k, t in traffic.items() if "stem_stream" in k]
+        if fw and fw[0] > 0:
+            for k, t in traffic.items():
+                t["hbm_bytes_per_forward"] = (2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024 / fw[0]
         dst = os.path.join(out, f"{tag}_hbm_traffic.json")
         if key:           # one file per round, one entry per configuration
             allcfg = json.load(open(dst)) if os.path.exists(dst) else {}
