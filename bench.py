@@ -87,6 +87,7 @@ def parse(argv=None):
     ap.add_argument("--x3-exact", action="store_true", help="fp32 runs: round 4's exact three-bf16-piece tile (six piece products, CAPF_PLAN_F32X3_EXACT) instead of the "
                     "two-fp16-piece tile (three)")
     ap.add_argument("--lifter-fp32", action="store_true", help="bf16 runs: lifter projections on the fp32 kernels (CAPF_PLAN_LIFTER_FP32)")
+    ap.add_argument("--plan-flags", type=int, default=0, help="extra capf_plan_flag bits OR-ed into the plan (A/B runs of one kernel family; named in config.plan_flags)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for smoke tests)")
@@ -318,7 +319,7 @@ def main():
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         from capf.lib import PLAN_F32X3_EXACT, PLAN_LIFTER_FP32, PLAN_NO_F32H2_GEMM, PLAN_NO_F32X3
-        pflags = PLAN_LIFTER_FP32 if (a.lifter_fp32 and a.dtype == "bf16") else 0
+        pflags = (PLAN_LIFTER_FP32 if (a.lifter_fp32 and a.dtype == "bf16") else 0) | a.plan_flags
         if a.no_f32x3:
             pflags |= PLAN_NO_F32X3 | PLAN_NO_F32H2_GEMM
         if a.x3_exact and a.dtype != "bf16":

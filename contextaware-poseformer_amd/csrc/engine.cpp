@@ -158,6 +158,12 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
     a.act = op.act;
     a.out_bf16 = op.out_bf16;
+    if (op.conv && op.in[1] >= 0) {                    // + bilinear_upsample(in[1]) behind the activation (build_cpn: lateral + upsampled path)
+        a.up = ptr(op.in[1]);
+        a.up_H = op.i0; a.up_W = op.i1;
+        a.up_sh = op.Ho > 1 ? (float)(op.i0 - 1) / (float)(op.Ho - 1) : 0.f;
+        a.up_sw = op.Wo > 1 ? (float)(op.i1 - 1) / (float)(op.Wo - 1) : 0.f;
+    }
     static const bool splitk_on = [] { const char* e = diag_env("CAPF_SPLITK"); return !e || atoi(e) != 0; }();   // A/B runs only
     if ((op.conv || (op.kind == OP_GEMM && op.ln_w < 0 && op.res_param < 0)) && !op.bf16 && split_ws && lanes != 1 && splitk_on) {   // one stream: launches use the scratch one after the other
         a.split_ws = on_side_chain ? split_ws_side : split_ws;
@@ -481,7 +487,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~1023) {
+    if (cfg->plan_flags & ~2047) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -1201,7 +1207,8 @@ int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes) {
             b = in_elems * (op.conv && !op.bf16 ? 4.0 : act)                    // fp32 stem reads the fp32 image
                 + (double)pk.N * pk.K * (pk.bf16 ? 2.0 : 4.0) + (double)pk.N * 4.0
                 + M * op.N * (op.out_bf16 ? 2.0 : act)
-                + ((op.aux >= 0 || op.res_param >= 0) ? M * op.N * act : 0.0);
+                + ((op.aux >= 0 || op.res_param >= 0) ? M * op.N * act : 0.0)
+                + ((op.conv && op.in[1] >= 0) ? B * op.i0 * op.i1 * op.N * act : 0.0);      // (the low-resolution map added behind the activation)
             break;
         }
         case capf::OP_FUSE: {
@@ -1315,6 +1322,7 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
         d->conv = op.conv; d->Cin = op.conv ? op.Cin : op.K; d->Cout = op.N;
         d->ks = op.ks; d->stride = op.stride; d->pad = op.pad; d->act = op.act;
         d->has_residual = op.aux >= 0 || op.res_param >= 0;
+        if (op.conv && op.in[1] >= 0) { d->up_H = op.i0; d->up_W = op.i1; }
         d->mfma_bf16 = (op.bf16 || op.out_bf16) ? 1 : 0;
         if (op.conv) {
             d->in_dtype = op.in[0] == -2 ? 0 : (op.bf16 ? 2 : 0);

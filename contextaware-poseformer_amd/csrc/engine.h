@@ -283,6 +283,7 @@ struct Engine {
     // op i and op i + 1 are a 64 -> 256 / 256 -> 64 pointwise conv pair that runs as ONE launch at this batch (igemm_f32_pwchain.hip)
     bool pwchain_head(int i, int batch, int last_op) const;
     bool use_pwchain = true;       // plan_flags & CAPF_PLAN_NO_PWCHAIN clears it
+    bool use_upadd = true;         // plan_flags & CAPF_PLAN_NO_UPADD clears it (CPN bf16: lateral conv + upsampled add in one launch)
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
     GemmArgs gemm_args(const Op& op, int batch) const;
 };

@@ -68,7 +68,7 @@ __device__ __forceinline__ long rowmap_b(const RowMap& r, int m) {
     return (long)q * r.S1 + (long)(m - q * r.G) * r.S2 + r.off;
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false>
+template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false, bool UPADD = false>
 __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid, unsigned short* __restrict__ lds) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -434,8 +434,42 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
             __builtin_amdgcn_wave_barrier();
         };
         if (vec_ok) {
+            // UPADD: + bilinear_upsample(p.up) AFTER the activation (CPN globalNet.py:66, feature = lateral + upsampled path): the four
+            // corners of the row's pixel in the low-resolution map, 8 channels (16 B) per corner and 32-column block, requested for both
+            // rows of a 32-row block before its transposes; ATen's align_corners = True arithmetic, the expression of bilinear_kernel
+            // (elementwise.hip), so that the sum equals what the resize-add launch it replaces computed from the same operands -- except
+            // that the lateral term is no longer rounded to bf16 before the add
+            [[maybe_unused]] rsrc_t rs_up;
+            if constexpr (UPADD) rs_up = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.up), 0, 0x7FFFFF00u, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                [[maybe_unused]] u32x4 uq[2][TN][4];
+                [[maybe_unused]] float ulh[2], ulw[2];
+                if constexpr (UPADD) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int m = m0 + wm0 + i * 32 + h * 16 + er;
+                        const bool ok = m < p.M;
+                        const int b = fast_div_b(ok ? m : 0, p.fd_hw), rem = (ok ? m : 0) - b * p.Ho * p.Wo;
+                        const int ho = fast_div_b(rem, p.fd_wo), wo = rem - ho * p.Wo;
+                        const float fh = p.up_sh * ho, fw = p.up_sw * wo;
+                        const int h0 = (int)fh, w0 = (int)fw;
+                        const int h1 = h0 + (h0 < p.up_H - 1), w1 = w0 + (w0 < p.up_W - 1);
+                        ulh[h] = fh - h0; ulw[h] = fw - w0;
+                        const int rb = b * p.up_H;
+                        const unsigned o00 = (unsigned)(((rb + h0) * p.up_W + w0) * p.N) * 2u, o01 = (unsigned)(((rb + h0) * p.up_W + w1) * p.N) * 2u;
+                        const unsigned o10 = (unsigned)(((rb + h1) * p.up_W + w0) * p.N) * 2u, o11 = (unsigned)(((rb + h1) * p.up_W + w1) * p.N) * 2u;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = n0 + wn0 + j * 32 + ec;
+                            const unsigned cb = (ok && n < p.N) ? (unsigned)n * 2u : OOB_E;
+                            uq[h][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, cb + o00, 0, 0);
+                            uq[h][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, cb + o01, 0, 0);
+                            uq[h][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, cb + o10, 0, 0);
+                            uq[h][j][3] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, cb + o11, 0, 0);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     transpose_block(i, j);
@@ -451,11 +485,21 @@ __device__ __forceinline__ void igemm_bf16_tile(const GemmArgs& p, const int bid
                             const float xa = q < 2 ? x0[2 * q] : x1[2 * q - 4], xb = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
                             const float ba = q < 2 ? bb[j][0][2 * q] : bb[j][1][2 * q - 4];
                             const float bc = q < 2 ? bb[j][0][2 * q + 1] : bb[j][1][2 * q - 3];
-                            o[q] = pack_bf16x2(finish(xa + ba + __uint_as_float(rw << 16)), finish(xb + bc + __uint_as_float(rw & 0xFFFF0000u)));
+                            float va = finish(xa + ba + __uint_as_float(rw << 16)), vb = finish(xb + bc + __uint_as_float(rw & 0xFFFF0000u));
+                            if constexpr (UPADD) {
+                                const float lh1 = ulh[h], lw1 = ulw[h], lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+                                const unsigned q00 = uq[h][j][0][q], q01 = uq[h][j][1][q], q10 = uq[h][j][2][q], q11 = uq[h][j][3][q];
+                                va += lh0 * (lw0 * __uint_as_float(q00 << 16) + lw1 * __uint_as_float(q01 << 16)) +
+                                      lh1 * (lw0 * __uint_as_float(q10 << 16) + lw1 * __uint_as_float(q11 << 16));
+                                vb += lh0 * (lw0 * __uint_as_float(q00 & 0xFFFF0000u) + lw1 * __uint_as_float(q01 & 0xFFFF0000u)) +
+                                      lh1 * (lw0 * __uint_as_float(q10 & 0xFFFF0000u) + lw1 * __uint_as_float(q11 & 0xFFFF0000u));
+                            }
+                            o[q] = pack_bf16x2(va, vb);
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, piece_off(i, j, h, (int)p.omap.S1), 0, 0);
                     }
                 }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -753,12 +797,12 @@ __device__ __forceinline__ int xcd_remap_b(int b, int nblk) {   // see igemm_f32
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false>
+template <int BM, int BN, int WM, int WN, int S, bool OUTF32 = false, bool GELU = false, bool UPADD = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int HALVES = S * (BM + BN) * BKH < 4 * 32 * 36 * 2 ? 4 * 32 * 36 * 2 : S * (BM + BN) * BKH;   // >= the epilogue's 18 KiB
     __shared__ __attribute__((aligned(16))) unsigned short lds[HALVES];
-    igemm_bf16_tile<BM, BN, WM, WN, S, OUTF32, GELU>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
+    igemm_bf16_tile<BM, BN, WM, WN, S, OUTF32, GELU, UPADD>(p, xcd_remap_b(blockIdx.x, gridDim.x), lds);
 #endif
 }
 
@@ -1437,8 +1481,22 @@ static int pp_min_tiles() {
 template <int BM, int BN, int WM, int WN, int S>
 static hipError_t launch_cfg_b(const GemmArgs& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    if (a.up) {          // (+ bilinear_upsample(up) behind the activation: the two tile shapes a 256-channel lateral conv can get)
+        if constexpr ((BM == 128 && BN == 128) || (BM == 64 && BN == 64))
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, S, false, false, true>), dim3(nbm * nbn), dim3(256), 0, s, a);
+        else
+            return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN, S>), dim3(nbm * nbn), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+// the post-activation upsampled add needs the vector epilogue (8-channel pieces) and 32-bit offsets into the low-resolution map
+bool gemm_bf16_upadd_ok(const GemmArgs& a) {
+    return a.conv && a.up && a.N > 64 && a.N % 8 == 0 && a.omap.G == 1 && (a.omap.S1 & 7) == 0 && (a.omap.off & 7) == 0 && !a.rscale &&
+           (!a.res || (a.rmap.G == 1 && (a.rmap.S1 & 7) == 0 && (a.rmap.off & 7) == 0)) && a.up_H > 0 && a.up_W > 0 && a.Ho * a.Wo > 0 &&
+           (double)(a.M / (a.Ho * a.Wo)) * a.up_H * a.up_W * a.N * 2.0 < 2.0e9;
 }
 
 const char* gemm_bf16_kernel_name(const GemmArgs& a) {
@@ -1465,7 +1523,7 @@ static void prep_conv_b(GemmArgs& a) {
     for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
 }
 
-bool gemm_bf16_groupable(const GemmArgs& a) { return bf16_ok(a) && a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale; }
+bool gemm_bf16_groupable(const GemmArgs& a) { return bf16_ok(a) && a.omap.G == 1 && (!a.res || a.rmap.G == 1) && !a.rscale && !a.up; }
 
 hipError_t launch_gemm_bf16_group(const GemmArgs* list, int n, hipStream_t s, int* variant) {
     if (variant) *variant = -1;
@@ -1556,6 +1614,7 @@ hipError_t launch_gemm_bf16(const GemmArgs& a_in, hipStream_t s) {
     a.fd_wo = make_fastdiv((unsigned)a.Wo);
     a.spread = 0ull;
     for (int kh = 0; kh < a.ks && kh * a.ks < 64; ++kh) a.spread |= 1ull << (kh * a.ks);
+    if (a.up && !gemm_bf16_upadd_ok(a)) return hipErrorInvalidValue;
     if (gemm_bf16_ws_wanted(a)) return launch_gemm_bf16_ws(a, s);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
     if (tiles128 >= pp_min_tiles()) {

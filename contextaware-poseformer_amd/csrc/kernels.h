@@ -134,6 +134,12 @@ struct GemmArgs {
     const float* ln_g;      // rows mode: LayerNorm the A rows over their K columns on the fly (gamma, beta [K]); nullptr = off
     const float* ln_b;
     float ln_eps;
+    // bf16 conv mode: out = act(acc + bias (+ res)) + bilinear_upsample(up) -- a map [B][up_H][up_W][N] (bf16, dense) resized to the conv's
+    // Ho x Wo with align_corners = True and added AFTER the activation (CPN globalNet.py:66: lateral + upsampled path), in the epilogue of
+    // igemm_bf16_kernel<..., UPADD>; nullptr = off.  up_sh / up_sw = (up_H - 1) / (Ho - 1), (up_W - 1) / (Wo - 1) as launch_bilinear_resize has them
+    const void* up;
+    int up_H, up_W;
+    float up_sh, up_sw;
 };
 
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
@@ -180,6 +186,7 @@ hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float
 // bf16 conv (igemm_bf16.hip): A / res / out bf16 NHWC, Wp bf16 [N][Kpad], Kpad % 64 == 0, bias fp32
 hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
 bool gemm_bf16_groupable(const GemmArgs& a);
+bool gemm_bf16_upadd_ok(const GemmArgs& a);      // a.up (post-activation upsampled add) can run in igemm_bf16_kernel<.., UPADD>
 // bf16 twin of launch_gemm_f32_group; *variant (optional) = the device kernel it chose: 0 ring (igemm_bf16_group_kernel),
 // 1 ping-pong (igemm_bf16_group_pp_kernel), 2 ping-pong with row-halo tiles (igemm_bf16_group_rh_kernel), 3 the 2-D halo tile
 // (igemm_bf16_group_ws_kernel; problems of the list it cannot take go out as a second, ring / ping-pong launch), -1 single launch

@@ -365,6 +365,23 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
     for (int i = 0; i < 4; ++i) {
         const Tensor& src = c[3 - i];
         const std::string lp = G + ".laterals." + std::to_string(i);
+        if (i > 0 && bf16() && use_upadd) {
+            // bf16: the low-resolution conv of the upsampled path first, then the lateral conv with `+ bilinear_x2(t)` behind its ReLU in the
+            // epilogue (igemm_bf16_kernel<.., UPADD>): no resize-add launch, the lateral map never travels to HBM and back on its own
+            // (lateral: write + read of 453 MB at the largest level and batch 128), and it meets the upsampled term in fp32
+            const std::string upn = G + ".upsamples." + std::to_string(i - 1);
+            Tensor t = conv_bn(upn + ".1", upn + ".2", fms[i - 1], 256, 1, 1, ACT_NONE, nullptr);
+            ops.back().flops_per_frame *= 4.0;
+            fms[i] = conv_bn(lp + ".0", lp + ".1", src, 256, 1, 1, ACT_RELU, nullptr);
+            Op& lop = ops.back();
+            lop.in[1] = t.buf;                       // (OP_GEMM conv: in[1] = the map added, upsampled, behind the activation; i0 x i1 its size)
+            lop.i0 = t.H; lop.i1 = t.W;
+            bufs[t.buf].last_op = std::max(bufs[t.buf].last_op, (int)ops.size() - 1);
+            const std::string pp = G + ".predict." + std::to_string(i);
+            register_unused_conv_bn(*this, pp + ".0", pp + ".1", 256, 256, 1);
+            register_unused_conv_bn(*this, pp + ".3", pp + ".5", 17, 256, 3);
+            continue;
+        }
         Tensor lat = conv_bn(lp + ".0", lp + ".1", src, 256, 1, 1, ACT_RELU, nullptr);
         if (i == 0) {
             fms[i] = lat;
@@ -911,6 +928,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_NO_ROW_HALO) use_rh = false;
     if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_UPADD) use_upadd = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;
     if (cfg.plan_flags & CAPF_PLAN_F32X3_EXACT) x3_h2 = false;

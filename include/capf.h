@@ -93,6 +93,8 @@ enum capf_plan_flag {
     CAPF_PLAN_NO_F32H2_GEMM = 512,  /* every OTHER fp32 conv / linear (1x1, stride 2, lone convs, the lifter's projections -- forward, input and weight
                                      * gradients of a training step included) on the fp32 matrix pipe at every batch (igemm_f32.hip) instead of the
                                      * two-fp16-piece GEMM from batch 5 (igemm_f32h2.hip)                                                        */
+    CAPF_PLAN_NO_UPADD = 1024,      /* compute_dtype = CAPF_BF16, CPN: globalNet's `lateral + upsampled path` (globalNet.py:66) as a resize-add launch behind the
+                                     * lateral conv (round 5's plan) instead of inside the conv's epilogue (igemm_bf16_kernel<.., UPADD>)        */
     CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
                                      * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
                                      * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured
@@ -526,6 +528,10 @@ typedef struct capf_op_desc {
     float eps;
     int32_t attn[4];
     int64_t maps[3][4];
+    /* kind 0, conv: up_H > 0 = the tensor in slot 1, [B, up_H, up_W, Cout] in the output's dtype, is resized to Ho x Wo (bilinear, align_corners =
+     * True) and ADDED BEHIND the activation, in fp32, before the one storage rounding: CPN's `lateral + upsampled path` (globalNet.py:66) inside the
+     * lateral conv's launch (compute_dtype = bf16; CAPF_PLAN_NO_UPADD: a kind-3 op behind the conv instead).  0 otherwise.                          */
+    int32_t up_H, up_W;
 } capf_op_desc;
 int capf_forward_prefix(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,
                         int batch, float* out, int n_ops);

@@ -263,8 +263,10 @@ def cpn_forward(P, x, pre="backbone", out_hw=(64, 48), nm=FP32, taps=None):
         elif i > 0:
             # bf16 emulation follows the ENGINE's order (csrc/plan.cpp build_cpn): a bias-free 1x1 conv + eval BatchNorm is a per-pixel
             # affine map and commutes with the interpolation, so the engine convolves the LOW-resolution map, stores THAT in bf16,
-            # then interpolates, adds the lateral in fp32 and rounds once
+            # and (round 6) adds its interpolation to the lateral conv's fp32 result inside that conv's epilogue: the lateral is never
+            # rounded on its own, the sum is rounded once
             low = _cbr(P, f"{g}.upsamples.{i - 1}.1", f"{g}.upsamples.{i - 1}.2", fms[i - 1], relu=False, nm=nm)
+            f = _cbr(P, f"{g}.laterals.{i}.0", f"{g}.laterals.{i}.1", res_out[i], nm=_NOROUND)
             if taps is not None:
                 taps.setdefault("cpn_lateral", []).append(f)
                 taps.setdefault("cpn_up_low", []).append(low)

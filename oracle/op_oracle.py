@@ -31,7 +31,7 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-def conv_bn_act(P, conv, bn, x_nhwc, residual_nhwc, ks, stride, pad, act, bf16):
+def conv_bn_act(P, conv, bn, x_nhwc, residual_nhwc, ks, stride, pad, act, bf16, up_nhwc=None):
     """x / residual: the engine's own NHWC operands (fp32 or bf16 tensors) -> (NHWC fp32 holding what the engine must store,
     NHWC fp32 `mass` = sum_k |x_k| |w_k| + |bias| + |residual| per output: the scale fp32 summation-order noise is relative to —
     an output that is the small remainder of large cancelling terms cannot be reproduced to a fraction of ITS magnitude)."""
@@ -39,12 +39,20 @@ def conv_bn_act(P, conv, bn, x_nhwc, residual_nhwc, ks, stride, pad, act, bf16):
     x = nm.r(_nchw(x_nhwc))                                  # (the stem rounds the fp32 image on its way into LDS)
     res = _nchw(residual_nhwc) if residual_nhwc is not None else None
     assert act in (0, 1)
-    y = oracle._cbr(P, conv, bn, x, stride, pad, relu=(act == 1), res=res, nm=nm)
+    if up_nhwc is None:
+        y = oracle._cbr(P, conv, bn, x, stride, pad, relu=(act == 1), res=res, nm=nm)
+    else:
+        # + bilinear_upsample(up) BEHIND the activation, in fp32, one storage rounding at the end (capf_op_desc.up_H: CPN's lateral conv with
+        # the upsampled path added in its epilogue, globalNet.py:66; csrc/plan.cpp build_cpn)
+        y = oracle._cbr(P, conv, bn, x, stride, pad, relu=(act == 1), res=res, nm=(oracle._NOROUND if bf16 else nm))
+        y = nm.r(y + F.interpolate(_nchw(up_nhwc), size=y.shape[-2:], mode="bilinear", align_corners=True))
     sc = P[bn + ".weight"] / torch.sqrt(P[bn + ".running_var"] + oracle.BN_EPS)
     w = (P[conv + ".weight"] * sc.view(-1, 1, 1, 1)).abs()
     mass = F.conv2d(x.abs(), w, (P[bn + ".bias"] - P[bn + ".running_mean"] * sc).abs(), stride, pad)
     if res is not None:
         mass = mass + res.abs()
+    if up_nhwc is not None:
+        mass = mass + F.interpolate(_nchw(up_nhwc).abs(), size=mass.shape[-2:], mode="bilinear", align_corners=True)
     # largest single term |x_k w_k| an output can contain (bound: largest |x| in its window times the channel's largest |w|):
     # the scale of ONE folded weight landing on the other side of a bf16 rounding boundary (see compare)
     xmax = F.max_pool2d(x.abs().amax(dim=1, keepdim=True), ks, stride, pad)

@@ -187,15 +187,16 @@ def test_bf16_emulation_rounds_where_the_engine_stores_bf16_and_nowhere_else():
         assert 1e-5 < d < 3e-2, (backbone, d)
         if backbone == "cpn":
             # PLACEMENT of the roundings in globalNet's top-down path = the engine's (csrc/plan.cpp build_cpn: the `upsamples` 1x1 conv
-            # runs on the low-resolution map and is stored in bf16, the resize adds the lateral and rounds once): the low-resolution
-            # conv output is bf16, has the PREVIOUS level's resolution, and each level is exactly round(interp(low) + lateral)
+            # runs on the low-resolution map and is stored in bf16, the lateral conv's epilogue adds its interpolation to the UNROUNDED
+            # lateral and rounds once -- round 6; until round 5 a resize-add launch read a bf16 lateral): the low-resolution conv output is
+            # bf16, has the PREVIOUS level's resolution, the lateral is NOT bf16, and each level is exactly round(interp(low) + lateral)
             import torch.nn.functional as F
             fms, lows, lats = te["cpn_fms"], te["cpn_up_low"], te["cpn_lateral"]
             assert len(lows) == 3 and len(fms) == 4
             for i in range(1, 4):
                 low, lat = lows[i - 1], lats[i - 1]
                 assert low.shape[-2:] == fms[i - 1].shape[-2:] and torch.equal(low, oracle.bf16_round(low))
-                assert not torch.equal(lat + 0.0, lat * 0.0)
+                assert not torch.equal(lat + 0.0, lat * 0.0) and not torch.equal(lat, oracle.bf16_round(lat))
                 want = oracle.bf16_round(F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True) + lat)
                 assert torch.equal(fms[i], want)
             assert "cpn_up_low" not in tf                       # the fp32 path keeps the reference's order (goldens pin it)

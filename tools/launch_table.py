@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--filter", default="")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--plan-flags", type=int, default=0)
     a = ap.parse_args()
     cfg = backbone_preset(copy.deepcopy(config), a.backbone)
     cfg.model.backbone.fix_weights = True
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg, compute_dtype=a.dtype).eval()
+        model = CA_PF(cfg, compute_dtype=a.dtype, plan_flags=a.plan_flags).eval()
     synth.load_synthetic(model, seed=1, bn_mode="random")
     model = model.cuda()
     img, k2d, kc = synth.synth_inputs(a.batch, a.height, a.width, seed=1000, crop_range=(192, 256))
