@@ -119,6 +119,7 @@ int Engine::ensure_h2g_lifter(hipStream_t s) {
             HIP_TRY(launch_pack_f32h2_gemm_rows(params[pk.w[i]].ptr, pack_arena + pk.wh_off, n0, n, pk.N, pk.K, pk.KpadH, s));
             n0 += n;
         }
+        if (pk.chain) HIP_TRY(launch_res_chain_repack(pack_arena + pk.wh_off, pack_arena + pk.wc_off, pk.N, pk.KpadH, s));
     }
     h2g_lifter_dirty = false;
     return CAPF_OK;
@@ -293,6 +294,29 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
         case OP_ATTENTION:
             HIP_TRY(launch_attention(ptr(op.in[0]), ptr(op.out), op.i0 * batch, op.i1, op.i2, op.i3, s, op.out_bf16));
             break;
+        case OP_RES_CHAIN: {
+            ResBlockW blk[8];
+            for (int i = 0; i < op.i2; ++i) {
+                const int* c = &op.chain[8 * i];
+                const Pack *q = &packs[c[0]], *pr = &packs[c[1]], *f1 = &packs[c[2]], *f2 = &packs[c[3]];
+                if (!q->chain || !pr->chain || !f1->chain || !f2->chain || q->KpadH != q->K || f2->KpadH != f2->K) return CAPF_ERR_STATE;
+                blk[i] = ResBlockW{params[c[4]].ptr, params[c[5]].ptr, pack_arena + q->wc_off, params[q->b[0]].ptr, pack_arena + pr->wc_off,
+                                   params[pr->b[0]].ptr, params[c[6]].ptr, params[c[7]].ptr, pack_arena + f1->wc_off, params[f1->b[0]].ptr,
+                                   pack_arena + f2->wc_off, params[f2->b[0]].ptr};
+            }
+            HIP_TRY(launch_res_chain(ptr(op.out), (int)(op.rows_per_frame * batch), op.i0, op.i1, op.eps, blk, op.i2, s));
+            break;
+        }
+        case OP_MLP_CHAIN: {
+            const Pack *f1 = &packs[op.chain[0]], *f2 = &packs[op.chain[1]];
+            if (!f1->chain || !f2->chain || f1->KpadH != f1->K || f2->KpadH != f2->K) return CAPF_ERR_STATE;
+            ResBlockW w{};
+            w.ln2_g = params[op.chain[2]].ptr; w.ln2_b = params[op.chain[3]].ptr;
+            w.wfc1 = pack_arena + f1->wc_off; w.bfc1 = params[f1->b[0]].ptr;
+            w.wfc2 = pack_arena + f2->wc_off; w.bfc2 = params[f2->b[0]].ptr;
+            HIP_TRY(launch_mlp_chain(ptr(op.out), op.amap, (int)(op.rows_per_frame * batch), op.eps, w, s));
+            break;
+        }
         case OP_HEAD:
             HIP_TRY(launch_head(ptr(op.in[0]), params[op.p0].ptr, params[op.p1].ptr, op.eps, params[op.p2].ptr,
                                 params[op.p3].ptr, out, (int)(op.rows_per_frame * batch), op.C, op.i0, s));
@@ -384,7 +408,7 @@ int Engine::run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* 
 // the product schedule (grouped launches included).
 int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t* ev, LaunchLog* log) {
     hipStream_t main_stream = s;
-    if (use_h2g && batch >= H2G_MIN_BATCH && last_op > n_backbone_ops && !bf16()) {
+    if (use_h2g && (batch >= H2G_MIN_BATCH || has_res_chain) && last_op > n_backbone_ops && !bf16()) {      // (the fused res blocks read the packs at every batch)
         const int rc = ensure_h2g_lifter(s);
         if (rc) return rc;
     }
@@ -1147,7 +1171,7 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
     if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0) return CAPF_ERR_INVALID;
     const capf::Op& op = h->e.ops[index];
     static const char* kn[] = {"", "fuse_sum", "maxpool3x3s2", "bilinear_resize", "prep_embed", "sample_ref",
-                               "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn"};
+                               "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn", "res_chain", "mlp_chain"};
     if (name) *name = op.name.c_str();
     const int n_all = (int)h->e.ops.size();
     if (kernel && (h->e.pwchain_head(index, batch, n_all) || h->e.pwchain_head(index - 1, batch, n_all))) {
@@ -1236,6 +1260,12 @@ int capf_op_bytes(const capf_handle* h, int index, int batch, double* bytes) {
             break;
         case capf::OP_HEAD:
             b = (double)op.rows_per_frame * B * (op.C + 3.0) * 4.0;
+            break;
+        case capf::OP_RES_CHAIN:                                                 // the token rows in and out, the blocks' weights once
+            b = (double)op.rows_per_frame * B * op.C * 4.0 * 2.0 + (double)op.i2 * 8.0 * op.C * op.C * 4.0;
+            break;
+        case capf::OP_MLP_CHAIN:
+            b = (double)op.rows_per_frame * B * op.C * 4.0 * 2.0 + 4.0 * op.C * op.C * 4.0;
             break;
         case capf::OP_PREP_EMBED:
             b = B * op.i0 * (op.C + 4.0) * 4.0;

@@ -60,6 +60,8 @@ struct Pack {
                                    // (igemm_f32h2_ws.hip; Engine::x3_h2) or three bf16 pieces (igemm_f32x3_ws.hip)
     size_t w3_off = 0;
     bool h2g = false;              // fp32 conv / linear: a copy as two block-scaled fp16 pieces for igemm_f32h2.hip ([N][KpadH] floats + [N] inverse
+    size_t wc_off = 0;             // chain: the h2g pack in MFMA fragment order for lifter_chain.hip (launch_res_chain_repack)
+    bool chain = false;
     size_t wh_off = 0;             // channel scales) at wh_off; KpadH = the direct fp32 layout's padded K
     int KpadH = 0;
     bool wino = false;             // conv weights in the Winograd F(2,3) layout of igemm_wino.hip (Kpad = 12 * Cin)
@@ -69,7 +71,7 @@ struct Pack {
 
 enum OpKind {
     OP_GEMM = 0, OP_FUSE, OP_MAXPOOL, OP_RESIZE, OP_PREP_EMBED, OP_SAMPLE_REF, OP_LAYERNORM, OP_DEFORM,
-    OP_ATTENTION, OP_HEAD, OP_FORK, OP_JOIN, OP_EMBED, OP_CTX_ATTN
+    OP_ATTENTION, OP_HEAD, OP_FORK, OP_JOIN, OP_EMBED, OP_CTX_ATTN, OP_RES_CHAIN, OP_MLP_CHAIN
 };
 
 struct Op {
@@ -106,6 +108,8 @@ struct Op {
                                   // kernels in every plan (the chained and the two-launch routes are bit-identical; test_pointwise_chain_*)
     int x3_lo = 0, x3_hi = -1;    // batches [x3_lo, x3_hi] at which a split-fp32 tile takes this conv (f32x3_takes; set by build(), empty = never)
     int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
+    std::vector<int> chain;       // OP_RES_CHAIN: per block {pack qkv, proj, fc1, fc2, param norm1.weight, .bias, norm2.weight, .bias};
+                                  // OP_MLP_CHAIN: {pack fc1, fc2, param norm2.weight, .bias}, rows through amap
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
     int region = -1;              // index of the enclosing fork/join region, -1 outside
 };
@@ -283,6 +287,7 @@ struct Engine {
     // op i and op i + 1 are a 64 -> 256 / 256 -> 64 pointwise conv pair that runs as ONE launch at this batch (igemm_f32_pwchain.hip)
     bool pwchain_head(int i, int batch, int last_op) const;
     bool use_pwchain = true;       // plan_flags & CAPF_PLAN_NO_PWCHAIN clears it
+    bool has_res_chain = false;    // the plan holds an OP_RES_CHAIN (lifter_chain.hip): its two-piece packs are needed at every batch
     bool use_upadd = true;         // plan_flags & CAPF_PLAN_NO_UPADD clears it (CPN bf16: lateral conv + upsampled add in one launch)
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
     GemmArgs gemm_args(const Op& op, int batch) const;

@@ -142,6 +142,17 @@ struct GemmArgs {
     float up_sh, up_sw;
 };
 
+// all res blocks of the lifter as one launch (lifter_chain.hip): per block LayerNorm weights, the two-fp16-piece packs of the four projections
+// (launch_pack_f32h2_gemm_rows' [N][K floats] of {piece 0 | piece 1} chunks + [N] inverse scales, through launch_res_chain_repack) and their fp32 biases
+struct ResBlockW {
+    const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wproj, *bproj, *ln2_g, *ln2_b, *wfc1, *bfc1, *wfc2, *bfc2;
+};
+bool res_chain_ok(int dim, int tokens, int heads, int nblk);
+// a projection's two-piece pack re-laid out in MFMA fragment order (same bits; what ResBlockW's w* point at)
+hipError_t launch_res_chain_repack(const float* h2g_pack, float* chain_pack, int N, int K, hipStream_t s);
+hipError_t launch_res_chain(float* X, int rows, int tokens, int heads, float eps, const ResBlockW* blk, int nblk, hipStream_t s);
+hipError_t launch_mlp_chain(float* X, RowMap rows_map, int rows, float eps, const ResBlockW& blk, hipStream_t s);     // the MLP half alone, on mapped rows
+
 hipError_t launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 // several independent fp32 convs in one grid (see igemm_f32.hip "Grouped launch"); n <= MAXG, every problem
 // must satisfy gemm_f32_groupable()

@@ -739,6 +739,29 @@ void Engine::build_lifter(const Tensor feats[4]) {
                           ACT_NONE, X, dst);
             }
             }
+            if (fused_lifter && use_h2g && !lb && !bf16() && res_chain_ok(C, 5, 8, 1)) {
+                // the MLP half as one launch on the context tokens' rows (lifter_chain.hip, ATTN = false): norm2 -> fc1 + GELU -> fc2 + x
+                Op op;
+                op.kind = OP_MLP_CHAIN;
+                op.name = n + ".mlp";
+                op.in[0] = X;
+                op.out = X;
+                op.amap = tok;
+                op.C = C;
+                op.eps = 1e-5f;
+                op.rows_per_frame = (long)J * L;
+                for (const char* lin : {".mlp.fc1", ".mlp.fc2"}) {
+                    op.chain.push_back(make_linear_pack(*this, {p + lin}));
+                    packs.back().chain = true;
+                }
+                op.chain.push_back(pidx(*this, p + ".norm2.weight"));
+                op.chain.push_back(pidx(*this, p + ".norm2.bias"));
+                op.flops_per_frame = 2.0 * J * L * (double)C * (2 * C + 2 * C);
+                use(X);
+                push(op);
+                has_res_chain = true;
+                continue;
+            }
             if (ln_fold) {
                 gemm_rows(*this, n + ".fc1", make_linear_pack(*this, {p + ".mlp.fc1"}), X, tok, (long)J * L, Hb,
                           row_ld(2 * C), ACT_GELU, -1, row_ld(0), -1, p + ".norm2", 1e-5f);
@@ -757,7 +780,34 @@ void Engine::build_lifter(const Tensor feats[4]) {
     auto attn_blocks = [&](const std::string& group, const std::string& tag, int dim, long rows_pf, int tokens,
                            int groups_pf) {
         const bool ln_fold = ln_fold_ok(dim);
-        for (int i = 0; i < (cfg.depth > 0 ? cfg.depth : L); ++i) {
+        const int nblk = cfg.depth > 0 ? cfg.depth : L;
+        // the res blocks (tokens of ONE joint, 128 wide) as one launch: a workgroup takes 6 joints through every block without leaving
+        // the CU (lifter_chain.hip); fp32 lifter on the two-piece packs only -- the bf16 plan and CAPF_PLAN_NO_FUSED_LIFTER /
+        // CAPF_PLAN_NO_F32H2_GEMM keep one launch per op
+        if (fused_lifter && use_h2g && !lb && !bf16() && groups_pf > 1 && res_chain_ok(dim, tokens, cfg.num_heads, nblk)) {
+            Op op;
+            op.kind = OP_RES_CHAIN;
+            op.name = tag + ".chain";
+            op.in[0] = X;
+            op.out = X;
+            op.i0 = tokens; op.i1 = cfg.num_heads; op.i2 = nblk; op.C = dim;
+            op.eps = 1e-6f;
+            op.rows_per_frame = rows_pf;
+            for (int i = 0; i < nblk; ++i) {
+                const std::string p = V + "." + group + "." + std::to_string(i);
+                for (const char* lin : {".attn.qkv", ".attn.proj", ".mlp.fc1", ".mlp.fc2"}) {
+                    op.chain.push_back(make_linear_pack(*this, {p + lin}));
+                    packs.back().chain = true;
+                }
+                for (const char* ln : {".norm1.weight", ".norm1.bias", ".norm2.weight", ".norm2.bias"}) op.chain.push_back(pidx(*this, p + ln));
+                op.flops_per_frame += 2.0 * rows_pf * (double)dim * (3 * dim + dim + 2 * dim + 2 * dim) + 4.0 * groups_pf * tokens * tokens * dim;
+            }
+            use(X);
+            push(op);
+            has_res_chain = true;
+            return;
+        }
+        for (int i = 0; i < nblk; ++i) {
             const std::string p = V + "." + group + "." + std::to_string(i);
             const std::string n = tag + std::to_string(i);
             if (ln_fold) {
@@ -1052,6 +1102,10 @@ bool Engine::build() {
         if (pk.h2g) {
             pk.wh_off = off;
             off += round64((size_t)f32h2_gemm_pack_elems(pk.N, pk.KpadH));
+            if (pk.chain) {
+                pk.wc_off = off;
+                off += round64((size_t)f32h2_gemm_pack_elems(pk.N, pk.KpadH));
+            }
         }
     {   // room for the bias-copy table: one CopySegment per linear of every packed (non-direct) linear pack
         size_t nseg = 0;

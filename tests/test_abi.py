@@ -163,12 +163,16 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     # round 5: from batch 5 the lifter's projections run the two-fp16-piece GEMM (64 x 64 tiles as well), the LayerNorm-folded ones
     # (K = 128: res blocks' qkv / fc1, context blocks' fc1) included; every batch below 5 stays on the fp32 MFMA kernel
     assert table["joint0.qkv"] == "igemm_f32h2g<64x64,rows>" and table["joint0.fc2"] == "igemm_f32h2g<64x64,rows>"
-    assert table["res0.qkv"] == "igemm_f32h2g<64x64,rows>" and table["ctx0.fc1"] == "igemm_f32h2g<64x64,rows>"
-    assert {name: kern for name, kern, _ in eng.op_table(4)}["res0.qkv"].startswith("igemm_f32<")
+    assert table["ctx0.mlp"] == "mlp_chain" and "ctx0.fc1" not in table       # (round 6: a context block's MLP half is one launch)
+    # round 6: the res blocks are ONE launch at every batch (lifter_chain.hip) ...
+    assert table["res.chain"] == "res_chain" and not any(n.startswith("res0.") for n in table)
+    assert {name: kern for name, kern, _ in eng.op_table(1)}["res.chain"] == "res_chain"
     assert {name: kern for name, kern, _ in eng.op_table(4)}["joint0.qkv"].startswith("igemm_f32<")
     eng_f = Engine(_native.make_capf_config(_cfg("hrnet_32"), 256, 256, plan_flags=PLAN_NO_F32H2_GEMM), device=None)
     table_f = {name: kern for name, kern, _ in eng_f.op_table(64)}
     assert table_f["joint0.qkv"] == "igemm_f32<w4,64x64,rows>"
+    assert table_f["res0.qkv"].startswith("igemm_f32<") and "res.chain" not in table_f       # ... unless the plan has no two-piece packs
+    assert table_f["ctx0.fc1"].startswith("igemm_f32<") and "ctx0.mlp" not in table_f
     assert table_f["joint0.fc2"] == "igemm_f32<w4,64x64,rows>"
     assert not any(k.startswith("igemm_f32h2g") for k in table_f.values())
     # the 3x3 stride-1 convs run the direct kernel (tall 256x32 tile for the 32-channel 64x64 branch launched on its own) below batch 5 and
@@ -367,13 +371,16 @@ def test_depth_is_a_plan_parameter_of_the_variant_without_context_blocks():
         c.depth, c.training = depth, training
         eng = Engine(c, device=None)
         names = [n for n, _, _ in eng.op_table(2)]
+        chain_flops.append(sum(f for n, _, f in eng.op_table(2) if n == "res.chain"))
         schema = [s[0] for s in eng.schema()]
         eng.close()
         return names, schema
 
+    chain_flops = []
     for depth, want in ((0, 4), (4, 4), (2, 2), (6, 6)):
         names, schema = plan(depth, False)
-        assert sum(n.endswith(".qkv") and n.startswith("res") for n in names) == want
+        # (round 6: the res blocks of any depth are ONE launch, lifter_chain.hip -- its FLOPs count the blocks)
+        assert names.count("res.chain") == 1 and chain_flops[-1] > 0 and abs(chain_flops[-1] / want - chain_flops[0] / 4) < 1e-6 * chain_flops[0]
         assert sum(n.endswith(".qkv") and n.startswith("joint") for n in names) == want
         assert sum(s.endswith("attn.qkv.weight") for s in schema) == 2 * want
     for bad in ((2, True, 0), (2, False, 1), (9, False, 0), (-1, False, 0)):
