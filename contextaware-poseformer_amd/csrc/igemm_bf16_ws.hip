@@ -50,9 +50,13 @@ int gemm_bf16_ws_tiles(const GemmArgs& a) {
 // FLOPs and very different tile counts (1024 ... 64 at batch 64), so the rule is on the problem's work: the tile takes a conv from
 // 1 GFLOP up -- below that (HRNet-32 under batch ~14, HRNet-48 under ~6) a level is a handful of 256-pixel tiles and the ring
 // kernel's 64 x 64 tiles fill the chip better.  (diag builds: CAPF_BF16_WS_MIN_MFLOP)
+// Round 6 (tools/sweep_thresholds.py, tools/ws_sweep.py -> profiles/r06_threshold_sweep.txt): the FLOP rule alone let the tile in far too
+// early -- HRNet-48 at batch 8 / 16 ran 21 % / 10 % SLOWER with it than on the row-halo / ring kernels, CPN at batch 4 - 16 5 %; the three
+// backbones cross over between batch 16 and 32, where a launch's 256-pixel tiles start to fill the chip's 512 slots.  So: 1 GFLOP AND batch 24.
 bool gemm_bf16_ws_wanted(const GemmArgs& a) {
     static const double min_flop = [] { const char* e = diag_env("CAPF_BF16_WS_MIN_MFLOP"); return (e ? atof(e) : 1000.0) * 1e6; }();
-    return a.Wp3 && 2.0 * (double)a.M * a.N * 9.0 * a.Cin >= min_flop && gemm_bf16_ws_ok(a);
+    static const long min_batch = [] { const char* e = diag_env("CAPF_BF16_WS_MIN_BATCH"); return e ? atol(e) : 24L; }();
+    return a.Wp3 && a.Ho > 0 && a.Wo > 0 && (long)a.M >= min_batch * a.Ho * a.Wo && 2.0 * (double)a.M * a.N * 9.0 * a.Cin >= min_flop && gemm_bf16_ws_ok(a);
 }
 
 // Problems are laid out one after the other, longest K loop first, each padded to a multiple of 8 blocks so that block b of a
