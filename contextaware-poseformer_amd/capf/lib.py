@@ -8,7 +8,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
-PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM, PLAN_NO_UPADD = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024     # capf_plan_flag
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM, PLAN_NO_UPADD, PLAN_H2_PLANES = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048     # capf_plan_flag
 ABI_VERSION = 6        # include/capf.h :: CAPF_ABI_VERSION (checked against capf_abi_version() at load)
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)
@@ -25,7 +25,7 @@ EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.p
     "capf_op_conv_f32h2_pack_elems", "capf_op_pack_conv_f32h2", "capf_op_conv_f32h2_group",
     "capf_abi_version", "capf_op_describe_sized",
     "capf_jpeg_info", "capf_jpeg_coefficients", "capf_jpeg_decode",
-    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g", "capf_op_linear_ln_f32h2g", "capf_op_wgrad",
+    "capf_op_f32h2_gemm_pack_elems", "capf_op_pack_f32h2_gemm", "capf_op_conv_f32h2g", "capf_op_conv_f32h2g_group", "capf_op_linear_f32h2g", "capf_op_linear_ln_f32h2g", "capf_op_wgrad", "capf_op_conv_f32h2_tiles", "capf_op_conv_f32h2_planes", "capf_op_h2_planes",
 ]
 
 
@@ -374,6 +374,30 @@ class Engine:
         if dtype_code == 2:
             return self._ws[off:off + (n + 1) // 2].view(torch.bfloat16)[:n].view(*shape)
         return self._ws[off:off + n].view(*shape)
+
+    def op_h2_planes(self, index, batch):
+        """(role, exps [tiles, C / 16] int32 view, tile_pixels) of op `index` at this batch: role 0 = plain fp32 tensors, 1 = its output holds split
+        fp16 planes, 2 = its input does (capf_op_h2_planes); C = the planes tensor's channels."""
+        import torch
+        ptr, tp = c_void_p(), c_int(0)
+        self.lib.capf_op_h2_planes.argtypes = [c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_int)]
+        role = self.lib.capf_op_h2_planes(self.h, index, batch, byref(ptr), byref(tp))
+        if role <= 0:
+            return 0, None, 0
+        d = self.op_describe(index)
+        C = d.Cout if role == 1 else d.Cin
+        tiles = self.lib.capf_op_conv_f32h2_tiles(batch, d.H, d.W, None)
+        off = (ptr.value - self._ws.data_ptr()) // 4
+        return role, self._ws[off:off + tiles * (C // 16)].view(torch.int32).view(tiles, C // 16), tp.value
+
+    def op_tensor_fp32(self, index, slot, shape, dtype_code):
+        """op_tensor, with a planes tensor (a BasicBlock's conv1 -> conv2 operand where both run the two-fp16-piece tile) decoded to the fp32 values
+        it stands for."""
+        t = self.op_tensor(index, slot, shape, dtype_code)
+        role, exps, tp = self.op_h2_planes(index, shape[0])
+        if (role == 1 and slot == 5) or (role == 2 and slot == 0):
+            return planes_to_fp32(t, exps, tp)
+        return t
 
     def forward_profile(self, images, k2d, kcrop, out, stream):
         """One forward with a HIP event pair around every launch (on `stream`); returns ms per op.
@@ -728,6 +752,49 @@ def conv_nhwc_f32h2_group(problems):
     if rc:
         raise CapfError(f"capf_op_conv_f32h2_group failed ({rc})")
     return outs
+
+
+def conv_nhwc_f32h2_planes(x, wp, bias, act, residual, cout, exps_in=None, planes_out=False):
+    """One 3x3 / stride-1 conv on the two-fp16-piece tile with a PLANES tensor on one side (capf_op_conv_f32h2_planes): exps_in = the int32
+    [tiles, Cin / 16] table of x's planes (x: the float32-typed tensor a planes_out conv returned); planes_out: y comes back as
+    (float32-typed planes tensor, exps).  Use planes_to_fp32 to look at one."""
+    import torch
+    lib = load_library()
+    B, H, W, ci = x.shape
+    y = torch.empty(B, H, W, cout, device=x.device, dtype=torch.float32)
+    d = ConvDesc()
+    d.x, d.w_packed, d.bias, d.y = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr()
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride, d.act = B, H, W, ci, cout, 3, 1, act
+    tiles = lib.capf_op_conv_f32h2_tiles(B, H, W, None)
+    eo = torch.zeros(tiles, cout // 16, device=x.device, dtype=torch.int32) if planes_out else None
+    lib.capf_op_conv_f32h2_planes.argtypes = [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p]
+    rc = lib.capf_op_conv_f32h2_planes(_stream(x), byref(d), _p(exps_in), _p(eo))
+    if rc:
+        raise CapfError(f"capf_op_conv_f32h2_planes failed ({rc})")
+    return (y, eo) if planes_out else y
+
+
+def f32h2_tile_pixels(B, H, W):
+    """output pixels per tile of the two-fp16-piece conv tile at this geometry (flat pixel p belongs to tile p // that)"""
+    lib = load_library()
+    px = c_int(0)
+    lib.capf_op_conv_f32h2_tiles.argtypes = [c_int, c_int, c_int, POINTER(c_int)]
+    if lib.capf_op_conv_f32h2_tiles(B, H, W, byref(px)) <= 0:
+        raise CapfError("geometry not eligible for the two-fp16-piece tile")
+    return px.value
+
+
+def planes_to_fp32(planes, exps, tile_pixels):
+    """Decode a planes tensor [B, H, W, C] (float32-typed storage of [piece 0: 16 fp16 | piece 1: 16 fp16] per 16-channel chunk) with its
+    [tiles, C / 16] exponent table into the fp32 values it stands for; tile_pixels: output pixels per tile (flat pixel p belongs to tile p // tile_pixels)."""
+    import torch
+    B, H, W, C = planes.shape
+    h = planes.contiguous().view(torch.float16).view(B * H * W, C // 16, 2, 16).float()
+    tile = torch.arange(B * H * W, device=planes.device) // tile_pixels
+    scale = torch.exp2((127 - exps[tile].to(torch.float64))).to(torch.float32)                 # [pixels, C / 16]: 1 / 2^(se - 127)
+    v = (h[:, :, 0, :] + h[:, :, 1, :]) * scale[:, :, None]
+    return v.reshape(B, H, W, C)
 
 
 def pack_f32h2_gemm(w, bn=None, eps=1e-5):

@@ -125,7 +125,7 @@ int Engine::ensure_h2g_lifter(hipStream_t s) {
     return CAPF_OK;
 }
 
-GemmArgs Engine::gemm_args(const Op& op, int batch) const {
+GemmArgs Engine::gemm_args(const Op& op, int batch, bool planes) const {
     auto ptr = [&](int buf) -> float* { return (buf >= 0 && ws) ? bptr(buf, batch) : nullptr; };
     const Pack& pk = packs[op.pack];
     GemmArgs a{};
@@ -159,6 +159,17 @@ GemmArgs Engine::gemm_args(const Op& op, int batch) const {
     a.amap = op.amap; a.omap = op.omap; a.rmap = op.rmap;
     a.act = op.act;
     a.out_bf16 = op.out_bf16;
+    if (planes && op.h2_role && a.x3_h2 && a.Wp3 && wino_now(op, batch)) {
+        // planes between a BasicBlock's two convs: only where BOTH launches go to the two-fp16-piece tile at this batch
+        const GemmArgs peer = gemm_args(ops[op.h2_peer], batch, false);
+        GemmArgs me = a;
+        me.conv = op.conv; me.Cin = op.Cin; me.H = op.H; me.W = op.W; me.Ho = op.Ho; me.Wo = op.Wo; me.ks = op.ks; me.stride = op.stride; me.pad = op.pad;
+        me.omap = op.omap; me.rmap = op.rmap; me.act = op.act;
+        if (peer.x3_h2 && peer.Wp3 && wino_now(ops[op.h2_peer], batch) && gemm_f32x3_wanted(me) && gemm_f32x3_wanted(peer)) {
+            int* e = reinterpret_cast<int*>(ptr(op.h2_exps));
+            if (op.h2_role == 1) a.h2_eout = e; else a.h2_ein = e;
+        }
+    }
     if (op.conv && op.in[1] >= 0) {                    // + bilinear_upsample(in[1]) behind the activation (build_cpn: lateral + upsampled path)
         a.up = ptr(op.in[1]);
         a.up_H = op.i0; a.up_W = op.i1;
@@ -511,7 +522,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~2047) {
+    if (cfg->plan_flags & ~4095) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -1086,6 +1097,32 @@ int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* d) {
     return capf::launch_gemm_f32h2_group(g, n, static_cast<hipStream_t>(stream)) == hipSuccess ? CAPF_OK : CAPF_ERR_HIP;
 }
 
+int capf_op_conv_f32h2_tiles(int B, int H, int W, int* tile_pixels) { return capf::f32h2_tiles_m(B, H, W, tile_pixels); }
+
+int capf_op_conv_f32h2_planes(void* stream, const capf_conv_desc* d, const int32_t* exps_in, int32_t* exps_out) {
+    if (!d || d->ks != 3 || d->stride != 1 || (exps_in && exps_out)) return CAPF_ERR_UNSUPPORTED;
+    capf::GemmArgs g{};
+    g.A = static_cast<const float*>(d->x);
+    g.Wp3 = static_cast<const float*>(d->w_packed);
+    g.x3_h2 = 1;
+    g.bias = d->bias;
+    g.res = static_cast<const float*>(d->residual);
+    g.out = static_cast<float*>(d->y);
+    g.M = d->B * d->H * d->W;
+    g.N = d->Cout; g.K = 9 * d->Cin;
+    g.conv = 1;
+    g.Cin = d->Cin; g.H = d->H; g.W = d->W; g.Ho = d->H; g.Wo = d->W;
+    g.ks = 3; g.stride = 1; g.pad = 1;
+    g.omap = capf::row_ld(d->Cout);
+    g.rmap = capf::row_ld(d->Cout);
+    g.act = d->act;
+    g.h2_ein = exps_in;
+    g.h2_eout = exps_out;
+    if (!capf::gemm_f32x3_ok(g)) return CAPF_ERR_UNSUPPORTED;
+    const hipError_t e = capf::launch_gemm_f32h2_group(&g, 1, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? CAPF_OK : (e == hipErrorInvalidValue ? CAPF_ERR_UNSUPPORTED : CAPF_ERR_HIP);
+}
+
 int capf_op_conv_bf16_group(void* stream, int n, const capf_conv_desc* d, const void* const* w_rh, int32_t* variant) {
     if (n <= 0 || n > capf::MAXG || !d) return CAPF_ERR_INVALID;
     capf::GemmArgs g[capf::MAXG];
@@ -1407,6 +1444,20 @@ int capf_op_tensor(const capf_handle* h, int index, int slot, const void** dev_p
     if (buf < 0 || !e.ws || e.last_batch <= 0) return CAPF_ERR_INVALID;
     *dev_ptr = e.bptr(buf, e.last_batch);
     return CAPF_OK;
+}
+
+int capf_op_h2_planes(const capf_handle* h, int index, int batch, const void** exps, int32_t* tile_pixels) {
+    if (!h || index < 0 || index >= (int)h->e.ops.size() || batch <= 0) return CAPF_ERR_INVALID;
+    const Engine& e = h->e;
+    const capf::Op& op = e.ops[index];
+    if (!op.h2_role || !e.ws) return 0;
+    const capf::GemmArgs a = e.gemm_args(op, batch);
+    if (!a.h2_ein && !a.h2_eout) return 0;
+    if (exps) *exps = a.h2_ein ? static_cast<const void*>(a.h2_ein) : static_cast<const void*>(a.h2_eout);
+    int tp = 0;
+    capf::f32h2_tiles_m(batch, op.H, op.W, &tp);
+    if (tile_pixels) *tile_pixels = tp;
+    return op.h2_role;
 }
 
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d, float* kcrop_inout,

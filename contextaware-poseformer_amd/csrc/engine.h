@@ -108,6 +108,8 @@ struct Op {
                                   // kernels in every plan (the chained and the two-launch routes are bit-identical; test_pointwise_chain_*)
     int x3_lo = 0, x3_hi = -1;    // batches [x3_lo, x3_hi] at which a split-fp32 tile takes this conv (f32x3_takes; set by build(), empty = never)
     int out_bf16 = 0;             // fp32 stem conv writing bf16 activations
+    int h2_exps = -1, h2_role = 0, h2_peer = -1;   // a BasicBlock's conv1 (role 1: writes planes + exponents to buffer h2_exps) / conv2 (role 2: reads them);
+                                  // h2_peer = the other op's index: both must run the two-fp16-piece tile at a batch for the pair to use planes
     std::vector<int> chain;       // OP_RES_CHAIN: per block {pack qkv, proj, fc1, fc2, param norm1.weight, .bias, norm2.weight, .bias};
                                   // OP_MLP_CHAIN: {pack fc1, fc2, param norm2.weight, .bias}, rows through amap
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
@@ -290,7 +292,8 @@ struct Engine {
     bool has_res_chain = false;    // the plan holds an OP_RES_CHAIN (lifter_chain.hip): its two-piece packs are needed at every batch
     bool use_upadd = true;         // plan_flags & CAPF_PLAN_NO_UPADD clears it (CPN bf16: lateral conv + upsampled add in one launch)
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
-    GemmArgs gemm_args(const Op& op, int batch) const;
+    GemmArgs gemm_args(const Op& op, int batch, bool planes = true) const;
+    bool use_h2_planes = false;    // plan_flags & CAPF_PLAN_H2_PLANES sets it (opt-in: measured slower, EXPERIMENTS R6.5)
 };
 
 }  // namespace capf

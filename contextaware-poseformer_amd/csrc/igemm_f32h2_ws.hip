@@ -35,12 +35,24 @@ static bool h2_from_args(const GemmArgs& a, H2Problem* q) {
     q->g.ldy = (int)a.omap.S1;
     q->g.ldr = a.res ? (int)a.rmap.S1 : (int)a.omap.S1;
     q->g.relu = a.act == ACT_RELU;
+    // planes (igemm_f32h2_ws_tile.h): the producer's and the consumer's tiles must be the same pixels -- the plan only pairs a BasicBlock's
+    // conv1 / conv2, equal shapes by construction -- chunks of 16 channels must be whole, a producer adds no residual
+    q->ein = a.h2_ein;
+    q->eout = a.h2_eout;
+    if (a.h2_eout && (a.res || a.N % 16 != 0 || a.omap.S1 != a.N)) return false;
+    if (a.h2_ein && a.Cin % 16 != 0) return false;
     return true;
 }
 
 bool gemm_f32h2_ok(const GemmArgs& a) {
     H2Problem q;
     return h2_from_args(a, &q);
+}
+int f32h2_tiles_m(int B, int H, int W, int* tile_pixels) {
+    H2Problem q;
+    if (!h2_plan(B, H, W, 16, 16, 32, &q)) return 0;
+    if (tile_pixels) *tile_pixels = q.g.P;
+    return q.g.tiles_m;
 }
 bool f32h2_shape_ok(int B, int H, int W, int Cin, int Cout) {
     H2Problem q;
@@ -54,7 +66,7 @@ struct H2GroupArgs {
     int n;
 };
 
-template <int TN>
+template <int TN, bool PIN = false, bool POUT = false>
 __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_f32h2_group_ws_kernel(H2GroupArgs ga) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char h2_lds[];
@@ -65,11 +77,11 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_f32h2_group_ws_ker
     const int per_xcd = (ga.start[pi + 1] - ga.start[pi]) >> 3;
     const int bid = (l & 7) * per_xcd + (l >> 3);          // block b of a problem runs on XCD b % 8: that XCD's contiguous eighth of the tiles
     if (bid >= ga.tiles[pi]) return;
-    igemm_f32h2_ws_tile<TN>(ga.g[pi], bid, h2_lds);
+    igemm_f32h2_ws_tile<TN, PIN, POUT>(ga.g[pi], bid, h2_lds);
 #endif
 }
 
-template <int TN>
+template <int TN, bool PIN = false, bool POUT = false>
 static hipError_t h2_launch(const H2Problem* list, int n, hipStream_t s) {
     struct Item { H2Problem q; int cost; };
     Item it[MAXG];
@@ -88,9 +100,9 @@ static hipError_t h2_launch(const H2Problem* list, int n, hipStream_t s) {
     ga.start[n] = start;
     for (int i = n; i < MAXG; ++i) { ga.start[i + 1] = start; ga.tiles[i] = 0; ga.g[i] = ga.g[0]; }
     static DynLdsAttr attr;
-    const hipError_t e = attr.ensure(reinterpret_cast<const void*>(&igemm_f32h2_group_ws_kernel<TN>), h2_lds_bytes(32 * TN));
+    const hipError_t e = attr.ensure(reinterpret_cast<const void*>(&igemm_f32h2_group_ws_kernel<TN, PIN, POUT>), h2_lds_bytes(32 * TN));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(igemm_f32h2_group_ws_kernel<TN>, dim3(start), dim3(256), h2_lds_bytes(32 * TN), s, ga);
+    hipLaunchKernelGGL((igemm_f32h2_group_ws_kernel<TN, PIN, POUT>), dim3(start), dim3(256), h2_lds_bytes(32 * TN), s, ga);
     return hipGetLastError();
 }
 
@@ -99,17 +111,25 @@ static hipError_t h2_launch(const H2Problem* list, int n, hipStream_t s) {
 hipError_t launch_gemm_f32h2_group(const GemmArgs* list, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (n > MAXG) return hipErrorInvalidValue;
-    H2Problem narrow[MAXG], wide[MAXG];
-    int nn = 0, nw = 0;
+    // one grid per (tile width, planes in, planes out) class present in the level: a level's convs are the same kind of BasicBlock conv
+    // almost always, so this is one or two launches as before
+    H2Problem cls[2][3][MAXG];
+    int cnt[2][3] = {{0, 0, 0}, {0, 0, 0}};
     for (int i = 0; i < n; ++i) {
         H2Problem q;
         if (!list[i].Wp3 || !list[i].x3_h2 || !h2_from_args(list[i], &q)) return hipErrorInvalidValue;
-        if (q.g.NS == 64) wide[nw++] = q;
-        else narrow[nn++] = q;
+        if (q.ein && q.eout) return hipErrorInvalidValue;
+        const int w = q.g.NS == 64 ? 1 : 0, k = q.ein ? 1 : (q.eout ? 2 : 0);
+        cls[w][k][cnt[w][k]++] = q;
     }
-    if (nw) { const hipError_t e = h2_launch<2>(wide, nw, s); if (e != hipSuccess) return e; }
-    if (nn) { const hipError_t e = h2_launch<1>(narrow, nn, s); if (e != hipSuccess) return e; }
-    return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (cnt[1][0] && e == hipSuccess) e = h2_launch<2>(cls[1][0], cnt[1][0], s);
+    if (cnt[1][1] && e == hipSuccess) e = h2_launch<2, true, false>(cls[1][1], cnt[1][1], s);
+    if (cnt[1][2] && e == hipSuccess) e = h2_launch<2, false, true>(cls[1][2], cnt[1][2], s);
+    if (cnt[0][0] && e == hipSuccess) e = h2_launch<1>(cls[0][0], cnt[0][0], s);
+    if (cnt[0][1] && e == hipSuccess) e = h2_launch<1, true, false>(cls[0][1], cnt[0][1], s);
+    if (cnt[0][2] && e == hipSuccess) e = h2_launch<1, false, true>(cls[0][2], cnt[0][2], s);
+    return e;
 }
 
 const char* gemm_f32h2_kernel_name(const GemmArgs&) { return "igemm_f32h2_group_ws"; }

@@ -36,7 +36,7 @@ namespace capf {
 
 static constexpr int H2_HP = WS_MAX_PP * 16 + 64;           // one half-plane (16 B per staged pixel) + 64 B: the two halves of a pixel 16 banks apart
 static constexpr int H2_A_BYTES = 4 * H2_HP;
-static constexpr int H2_AUX_BYTES = 16 + 2 * 64 * 4 + 4 * 64 * 4;   // the four wave maxima of the chunk being split; the slice's inverse weight scales and
+static constexpr int H2_AUX_BYTES = 16 + 2 * 64 * 4 + 4 * 64 * 4 + 16;   // the four wave maxima of the chunk being split; the slice's inverse weight scales and
                                                                    // biases; per wave, which tile pixel each of its 2 x 32 MFMA columns is (epilogue)
 inline constexpr int h2_w_bytes(int NS) { return 2 * 9 * NS * 32; }
 inline constexpr int h2_lds_bytes(int NS) { return H2_A_BYTES + h2_w_bytes(NS) + H2_AUX_BYTES; }
@@ -47,6 +47,13 @@ struct H2Problem {
     const float* res;             // [M][ldr] fp32 or nullptr
     float* y;                     // [M][ldy] fp32
     const float* winv;            // [ceil(N / 32) * 32] 1 / (the channel's weight scale)
+    // PLANES (round 6): a tensor that only ever travels from one tile conv to the next (a BasicBlock's conv1 -> conv2, pose_hrnet.py:78-88)
+    // is written by the producer ALREADY SPLIT -- per pixel and 16-channel chunk [piece 0: 16 fp16 | piece 1: 16 fp16], the same 64 bytes
+    // and the same addresses as the fp32 values -- under one power-of-two scale per (producer tile, chunk) whose biased exponent goes to
+    // eout[tile * (N / 16) + chunk]; the consumer stages the pieces as they are (no maximum, no split, no scale exchange) and only moves the
+    // halo rows that came from the neighbouring tiles onto the smallest of the three scales (exact: a power of two).  Same tiling on both sides.
+    const int* ein;               // x holds planes: [tiles_m][C / 16] scale exponents (nullptr: x is fp32)
+    int* eout;                    // y is written as planes: [tiles_m][N / 16] (nullptr: fp32)
 };
 
 // packed weights: [32-channel slice][C / 16][piece 2][tap 9][32][2 swizzled halves][8] fp16, then [slices * 32] fp32 inverse scales.  One
@@ -93,6 +100,13 @@ __device__ __forceinline__ void h2_split2(float x, float y, float s, unsigned& p
     p2 = __builtin_bit_cast(unsigned, b);
 }
 
+// two packed fp16 values times two packed fp16 values (a power of two in both halves here: exact, denormal results included)
+__device__ __forceinline__ unsigned h2_pk_mul(unsigned a, unsigned b) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t r = __builtin_bit_cast(h2_t, a) * __builtin_bit_cast(h2_t, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // maximum of a non-negative value over the wave (bit patterns of non-negative floats order like integers), wave-uniform
 __device__ __forceinline__ int h2_wave_max(float v) {
     int x = __float_as_int(v);
@@ -105,7 +119,8 @@ __device__ __forceinline__ int h2_wave_max(float v) {
 }
 
 // one tile (logical id bid = pixel tile * NSL + channel slice) with the calling 256-thread block; lds: h2_lds_bytes(32 TN) bytes
-template <int TN>
+// PIN: x holds planes (q.ein);  POUT: y is written as planes (q.eout; no residual)
+template <int TN, bool PIN = false, bool POUT = false>
 __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const int bid, unsigned char* __restrict__ lds) {
     constexpr int NS = 32 * TN;
     constexpr int WP_BYTES = 9 * 32 * 32;                  // one piece of a 32-channel slice's chunk
@@ -131,6 +146,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     // not its bandwidth, then bounds three resident blocks -- 2048 cycles per chunk and block against 1728 of MFMAs)
     constexpr int HP = H2_HP;                                // piece pc, half hf at (2 pc + hf) HP
     unsigned a_voff[NAU], a_lds[NAU];
+    [[maybe_unused]] unsigned a_cls = 0;
     const int n_units = 4 * p.PP;
     {
         const int q0 = tm * p.G;
@@ -138,9 +154,11 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
         for (int j = 0; j < NAU; ++j) {
             const int qi = min(j * 256 + tid, n_units - 1);  // (beyond the geometry: the last unit once more, same bytes same place)
             const int px = qi >> 2, qt = qi & 3;
-            a_lds[j] = (unsigned)((qt >> 1) * HP + px * 16 + (qt & 1) * 8);
+            a_lds[j] = PIN ? (unsigned)((2 * (qt >> 1) + (qt & 1)) * HP + px * 16)       // (planes: quarter qt = piece qt >> 1, channels 8 (qt & 1) ..)
+                           : (unsigned)((qt >> 1) * HP + px * 16 + (qt & 1) * 8);
             const int g = ws_div(px, p.d_segp), rem = px - g * p.SEGP;
             const int rr = ws_div(rem, p.d_pw), ww = rem - rr * p.PW;
+            if (PIN) a_cls |= (rr == 0 ? 1u : (rr == p.RH + 1 ? 2u : 0u)) << (2 * j);   // whose scale the unit's row carries: own tile / the one above / below
             const int sg = q0 + g;
             const int b = ws_div(sg, p.d_rgpi);
             const int h = (sg - b * p.RGPI) * p.RH + rr - 1, col = ww - 1;
@@ -158,7 +176,71 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     float* const aux_w = reinterpret_cast<float*>(aux + 4);      // [NS] 1 / weight scale of the slice's channels
     float* const aux_b = aux_w + 64;                             // [NS] their biases
     int* const aux_px = reinterpret_cast<int*>(aux_b + 64) + wave * 64;   // [2][32] this wave's column -> tile pixel table
+    [[maybe_unused]] int* const aux_o = reinterpret_cast<int*>(aux_b + 64) + 4 * 64;      // [2 TN] POUT: largest |output| of the tile's 16-channel chunks
+    // ---- PIN: the scales come with the planes.  A tile with in-image neighbours (one segment of RH < H rows) reads three exponents per chunk,
+    // its own and those of the tiles its two halo rows came from; the chunk's scale is the smallest of them
+    [[maybe_unused]] int e_nb[3] = {190, 190, 190};        // (own, above, below) of the chunk about to be staged
+    [[maybe_unused]] const int* e_row[3] = {nullptr, nullptr, nullptr};
+    if constexpr (PIN) {
+        e_row[0] = q.ein + (size_t)tm * NCC;
+        if (p.G == 1 && p.RH < p.H) {
+            const int k = tm - ws_div(tm, p.d_rgpi) * p.RGPI;                 // row group of the tile inside its image
+            if (k > 0) e_row[1] = q.ein + (size_t)(tm - 1) * NCC;
+            if (k + 1 < p.RGPI) e_row[2] = q.ein + (size_t)(tm + 1) * NCC;
+        }
+    }
+    [[maybe_unused]] int e_raw[3] = {190, 190, 190};       // (requested together with the chunk's pixels, a chunk ahead)
+    auto load_e = [&](int cc) {
+        if constexpr (PIN) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e_raw[k] = e_row[k] ? e_row[k][cc] : 190;
+        }
+    };
+    auto use_e = [&]() {
+        if constexpr (PIN) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e_nb[k] = __builtin_amdgcn_readfirstlane(e_raw[k]);
+        }
+    };
+    // which of the three row classes a wave's unit j holds at all (wave-uniform bit masks, bit j): the rescale below is skipped per unit on
+    // SCALAR conditions -- typically nothing needs moving (equal exponents), or only the units of a halo row do
+    [[maybe_unused]] unsigned has_cls[3] = {0, 0, 0};
+    if constexpr (PIN) {
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            const unsigned c = (a_cls >> (2 * j)) & 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) has_cls[k] |= (__builtin_amdgcn_ballot_w64(c == (unsigned)k) != 0 ? 1u : 0u) << j;
+        }
+    }
+    auto store_planes = [&](int sn) {                      // the loaded units -> LDS, rows of other tiles moved onto the chunk's scale 2^(sn - 127)
+        // classes whose rows are on another scale than the chunk's (a missing neighbour's rows are zeros: never)
+        const unsigned moved = (e_nb[0] != sn ? has_cls[0] : 0u) | ((e_nb[1] != sn && e_nb[1] != 190) ? has_cls[1] : 0u) |
+                               ((e_nb[2] != sn && e_nb[2] != 190) ? has_cls[2] : 0u);
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            const ws_u32x4 src = __builtin_bit_cast(ws_u32x4, ar[j]);
+            unsigned w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            if ((moved >> j) & 1) {                        // (wave-uniform)
+                const int cls = (a_cls >> (2 * j)) & 3;
+                const int en = cls == 0 ? e_nb[0] : (cls == 1 ? e_nb[1] : e_nb[2]);
+                const int r = en == 190 ? 0 : sn - en;     // <= 0
+                // 2^r in one or two fp16 factors: 2^max(r, -14) (normal), then 2^(r + 14) down to 2^-24 as a denormal, i.e. exact scaling down
+                // to 2^-38 -- a first piece of 2^15 is still 2^-23 there; below that everything the row holds is under the fp16 grid (2^-24 in
+                // the chunk's units = 2^-39 of its largest value: the bound of include/capf.h) and becomes zero
+                const int r1 = r >= -14 ? r : -14, r2 = r - r1;
+                const unsigned hb = (unsigned)(15 + r1) << 10, mb = hb | (hb << 16);
+                w0 = h2_pk_mul(w0, mb); w1 = h2_pk_mul(w1, mb); w2 = h2_pk_mul(w2, mb); w3 = h2_pk_mul(w3, mb);
+                if (__builtin_amdgcn_ballot_w64(r2 < 0)) {                      // (rows more than 2^14 below the chunk's scale: rare)
+                    const unsigned gb = r2 >= -14 ? (unsigned)(15 + r2) << 10 : (r2 >= -24 ? 1u << (24 + r2) : 0u), nb = gb | (gb << 16);
+                    w0 = h2_pk_mul(w0, nb); w1 = h2_pk_mul(w1, nb); w2 = h2_pk_mul(w2, nb); w3 = h2_pk_mul(w3, nb);
+                }
+            }
+            *reinterpret_cast<ws_u32x4*>(lds + a_lds[j]) = ws_u32x4{w0, w1, w2, w3};
+        }
+    };
     auto publish_max = [&]() {                             // this wave's maximum of the loaded chunk -> aux[wave]
+        if constexpr (PIN) return;
 #if (H2_EXPERIMENT & 1)
         return;
 #endif
@@ -171,6 +253,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
         if (lane == 0) aux[wave] = wm;
     };
     auto block_scale_exp = [&]() -> int {                  // (after the barrier behind publish_max)
+        if constexpr (PIN) return min(e_nb[0], min(e_nb[1], e_nb[2]));
 #if (H2_EXPERIMENT & 1)
         return 127;
 #endif
@@ -179,6 +262,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
         return __builtin_amdgcn_readfirstlane(h2_scale_exp(m));
     };
     auto split_a = [&](float s) {                          // the loaded chunk, scaled -> two fp16 planes
+        if constexpr (PIN) { store_planes(__float_as_int(s) >> 23); return; }
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
             ws_u32x2 u1, u2;
@@ -212,6 +296,8 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
         }
     };
     load_a(0);
+    load_e(0);
+    if (POUT && tid < 4) aux_o[tid] = 0;
     if (tid < NS) {
         const int n = slice * NS + tid;
         aux_w[tid] = n < ((p.N + 31) & ~31) ? q.winv[n] : 1.f;
@@ -285,6 +371,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     publish_max();                                         // (the compiler waits for the pixel loads; the weight DMA may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    use_e();
     int sb = block_scale_exp();
     int smin = sb;
     split_a(__int_as_float(sb << 23));
@@ -297,7 +384,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (NCC > 1) load_a(1);
+    if (NCC > 1) { load_a(1); load_e(1); }
     __builtin_amdgcn_s_barrier();
 
     // ---- epilogue addressing: lane = 4 consecutive channels (register group g) of its pixel; the residual rows are requested before
@@ -315,7 +402,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     ws_f32x4 rr[2][TN][4];                                  // [pixel block][channel block][h * 2 + q]
     ws_f16x8 af[2][2][2], bfr[2][2][TN];
     for (int cc = 0; cc < NCC; ++cc) {
-        if (cc == NCC - 1 && !(H2_EXPERIMENT & 32)) {
+        if (cc == NCC - 1 && !(H2_EXPERIMENT & 32) && !POUT) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -369,6 +456,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // everybody is done reading the stage; the four maxima are in place
             if (!(H2_EXPERIMENT & 2)) fire_w(cc + 1);
+            use_e();
             // (a scale never rises more than 2^80 above the smallest one of the tile so far: the accumulators hold up to 2^35 in units of
             // that scale and must not overflow behind a chunk of zeros; values that far below an earlier chunk are below the fp32 sum)
             const int sn = min(block_scale_exp(), smin + 80);
@@ -385,7 +473,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             }
             split_a(__int_as_float(sb << 23));
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (cc + 2 < NCC && !(H2_EXPERIMENT & 4)) load_a(cc + 2);
+            if (cc + 2 < NCC && !(H2_EXPERIMENT & 4)) { load_a(cc + 2); load_e(cc + 2); }
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -403,11 +491,38 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     }
     // ---- epilogue: y = acc / (pixel scale * the channel's weight scale) + bias (+ residual), ReLU
     // (accumulator register 4 g + e of channel block j = channel slice * NS + 32 j + 8 g + 4 fhalf + e of the lane's pixel)
+    const float inv_s = __int_as_float((254 - sb) << 23);
+    if constexpr (POUT) {
+        // planes out: the chunk maxima straight from the accumulators (lane = pixel, register 4 g + e = channel 8 g + 4 fhalf + e of column
+        // block j: g = 0, 1 -> chunk 2 j, g = 2, 3 -> chunk 2 j + 1), so that they cross LDS under the barrier the epilogue has anyway
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float m[2] = {0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const ws_f32x4 wv = *reinterpret_cast<const ws_f32x4*>(aux_w + j * 32 + 8 * g + 4 * fhalf);
+                const ws_f32x4 bv = *reinterpret_cast<const ws_f32x4*>(aux_b + j * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(acc[i][j][4 * g + e], wv[e] * inv_s, bv[e]);
+                        m[g >> 1] = fmaxf(m[g >> 1], p.relu ? fmaxf(t, 0.f) : fabsf(t));
+                    }
+            }
+            const int w0 = h2_wave_max(m[0]), w1 = h2_wave_max(m[1]);
+            if (lane == 0) { atomicMax(&aux_o[2 * j], w0); atomicMax(&aux_o[2 * j + 1], w1); }
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // every wave is done with the planes: the scratch below overlays them
     constexpr int EPS = 36;
     float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPS);
-    const float inv_s = __int_as_float((254 - sb) << 23);
+    [[maybe_unused]] const int hi_chunk = (lane >> 1) & 1;  // (coalesced layout: the lane's 8 channels lie in chunk 2 j + hi_chunk)
+    if constexpr (POUT) {
+        const int nck = p.N >> 4;
+        if (tid < 2 * TN && slice * 2 * TN + tid < nck) q.eout[(size_t)tm * nck + slice * 2 * TN + tid] = h2_scale_exp(aux_o[tid]);
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         ws_f32x4 wv[2], bv[2];
@@ -430,16 +545,35 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             for (int h = 0; h < 2; ++h) {
                 const int row = h * 16 + er;
                 const int pl = aux_px[i * 32 + row];
+                [[maybe_unused]] ws_f32x4 ov[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const ws_f32x4 x = *reinterpret_cast<const ws_f32x4*>(&ep[row * EPS + ec + 4 * q]);
                     ws_f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float t = fmaf(x[e], wv[q][e], bv[q][e] + rr[i][j][h * 2 + q][e]);
+                        const float t = POUT ? fmaf(x[e], wv[q][e], bv[q][e]) : fmaf(x[e], wv[q][e], bv[q][e] + rr[i][j][h * 2 + q][e]);
                         o[e] = p.relu ? fmaxf(t, 0.f) : t;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), rs_out, row_off(pl, j, q, p.ldy), 0, 0);
+                    if constexpr (POUT) ov[q] = o;
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, o), rs_out, row_off(pl, j, q, p.ldy), 0, 0);
+                }
+                if constexpr (POUT) {                      // the row's 8 channels -> piece 0 | piece 1 where the fp32 values would have gone
+                    const float sc = __int_as_float(h2_scale_exp(aux_o[2 * j + hi_chunk]) << 23);
+                    ws_u32x4 p0, p1;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            unsigned s1, s2;
+                            h2_split2(ov[qq][2 * k], ov[qq][2 * k + 1], sc, s1, s2);
+                            p0[2 * qq + k] = s1; p1[2 * qq + k] = s2;
+                        }
+                    const int n = slice * NS + j * 32 + ec;
+                    const bool ok = pl < p.P && gp0 + pl < Mi && n < p.N;
+                    const unsigned off = ok ? (unsigned)(pl * p.ldy + (n & ~15)) * 4u + (unsigned)(n & 15) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(p0, rs_out, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(p1, rs_out, ok ? off + 32u : OOB, 0, 0);
                 }
             }
         }

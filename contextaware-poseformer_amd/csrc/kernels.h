@@ -140,6 +140,10 @@ struct GemmArgs {
     const void* up;
     int up_H, up_W;
     float up_sh, up_sw;
+    // the two-fp16-piece conv tile only (igemm_f32h2_ws_tile.h, PLANES): A holds the producer's fp16 planes and h2_ein their [tile][chunk]
+    // scale exponents / out is written as planes and h2_eout receives the exponents.  nullptr = plain fp32 tensors
+    const int* h2_ein;
+    int* h2_eout;
 };
 
 // all res blocks of the lifter as one launch (lifter_chain.hip): per block LayerNorm weights, the two-fp16-piece packs of the four projections
@@ -196,6 +200,7 @@ hipError_t launch_pack_conv_bf16(const float* w, const float* gamma, const float
                                  int Kpad, hipStream_t s);
 // bf16 conv (igemm_bf16.hip): A / res / out bf16 NHWC, Wp bf16 [N][Kpad], Kpad % 64 == 0, bias fp32
 hipError_t launch_gemm_bf16(const GemmArgs& a, hipStream_t s);
+int f32h2_tiles_m(int B, int H, int W, int* tile_pixels = nullptr);            // pixel tiles of the two-fp16-piece conv tile (rows of a planes tensor's exponent table); 0: not eligible
 bool gemm_bf16_groupable(const GemmArgs& a);
 bool gemm_bf16_upadd_ok(const GemmArgs& a);      // a.up (post-activation upsampled add) can run in igemm_bf16_kernel<.., UPADD>
 // bf16 twin of launch_gemm_f32_group; *variant (optional) = the device kernel it chose: 0 ring (igemm_bf16_group_kernel),

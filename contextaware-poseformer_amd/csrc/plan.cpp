@@ -192,7 +192,23 @@ static Tensor fuse_sum(Engine& e, const std::string& name, const Tensor* terms, 
 // ---------------------------------------------------------------------------------------------------
 static Tensor hr_basic_block(Engine& e, const std::string& p, const Tensor& x) {   // :66-95
     Tensor y = e.conv_bn(p + ".conv1", p + ".bn1", x, x.C, 3, 1, ACT_RELU, nullptr);
-    return e.conv_bn(p + ".conv2", p + ".bn2", y, x.C, 3, 1, ACT_RELU, &x);
+    const int i1 = (int)e.ops.size() - 1;
+    Tensor out = e.conv_bn(p + ".conv2", p + ".bn2", y, x.C, 3, 1, ACT_RELU, &x);
+    const int i2 = (int)e.ops.size() - 1;
+    // conv1's output has ONE reader, conv2, and both convs have the same tiles: where both run the two-fp16-piece tile (a matter of the
+    // batch, decided per launch in gemm_args) it travels as split fp16 planes + one scale exponent per (tile, 16-channel chunk) --
+    // igemm_f32h2_ws_tile.h PLANES: the consumer's K loop loses its maximum / split / scale-exchange phase.  Same bytes, same buffer.
+    if (e.use_h2_planes && e.x3_h2 && !e.bf16() && x.C % 16 == 0 && e.packs[e.ops[i1].pack].x3 && e.packs[e.ops[i2].pack].x3) {
+        const int tiles_pf = f32h2_tiles_m(1, x.H, x.W);
+        if (tiles_pf > 0) {
+            const int b = e.new_buffer((size_t)tiles_pf * (x.C / 16) + 16, p + ".conv1.exps");
+            e.bufs[b].def_op = i1;
+            e.bufs[b].last_op = i2;
+            e.ops[i1].h2_exps = b; e.ops[i1].h2_role = 1; e.ops[i1].h2_peer = i2;
+            e.ops[i2].h2_exps = b; e.ops[i2].h2_role = 2; e.ops[i2].h2_peer = i1;
+        }
+    }
+    return out;
 }
 
 static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, int planes, bool down) {  // :98-136
@@ -979,6 +995,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_UPADD) use_upadd = false;
+    if (cfg.plan_flags & CAPF_PLAN_H2_PLANES) use_h2_planes = true;
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;
     if (cfg.plan_flags & CAPF_PLAN_F32X3_EXACT) x3_h2 = false;

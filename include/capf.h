@@ -95,6 +95,8 @@ enum capf_plan_flag {
                                      * two-fp16-piece GEMM from batch 5 (igemm_f32h2.hip)                                                        */
     CAPF_PLAN_NO_UPADD = 1024,      /* compute_dtype = CAPF_BF16, CPN: globalNet's `lateral + upsampled path` (globalNet.py:66) as a resize-add launch behind the
                                      * lateral conv (round 5's plan) instead of inside the conv's epilogue (igemm_bf16_kernel<.., UPADD>)        */
+    CAPF_PLAN_H2_PLANES = 2048,     /* OPT-IN (measured slower, EXPERIMENTS R6.5): a BasicBlock's conv1 output travels to conv2 as split fp16 planes
+                                     * (capf_op_conv_f32h2_planes) where both convs run the two-fp16-piece tile; default: plain fp32 tensors          */
     CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
                                      * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
                                      * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured
@@ -357,6 +359,19 @@ int capf_op_pack_conv_f32h2(void* stream, const float* w_oihw, const float* gamm
                             const float* var, float eps, void* w_packed_f16, float* bias, int Cout, int Cin);
 int capf_op_conv_f32h2_group(void* stream, int n, const capf_conv_desc* convs);
 
+/* PLANES (round 6): a tensor that only travels from one two-fp16-piece tile conv to the next -- a BasicBlock's conv1 -> conv2, pose_hrnet.py:78-88 --
+ * can stay SPLIT in memory: per pixel and 16-channel chunk [piece 0: 16 fp16 | piece 1: 16 fp16], the same 64 bytes at the same addresses as the fp32
+ * values, under one power-of-two scale per (256-pixel tile, chunk) whose biased exponent is kept in a [tiles][channels / 16] int32 table.  The consumer
+ * stages the pieces as they are (no maximum, no split, no scale exchange in its K loop) and only moves the two halo rows that came from the neighbouring
+ * tiles onto the smallest of the three scales (a power of two: exact).  Stored values are fp32 numbers of 22 significant bits (|v - stored| <= 2^-23 |v|,
+ * what the consumer's own split would have made of them); THE BOUND above holds with M_c = the largest value of the three tiles a tile's rows come from.
+ * capf_op_conv_f32h2_planes: one such conv.  exps_in != NULL: conv->x holds planes (Cin % 16 == 0) and exps_in their table; exps_out != NULL: conv->y
+ * is written as planes (Cout % 16 == 0, no residual) and exps_out receives capf_op_conv_f32h2_tiles(B, H, W, ..) x Cout / 16 exponents.  Producer and
+ * consumer must have the same B, H, W (same tiles).  capf_forward uses the pair for every BasicBlock whose two convs run this tile
+ * ONLY under CAPF_PLAN_H2_PLANES: the split moves, it does not disappear, and the forward measured 3 % slower with it (EXPERIMENTS R6.5).                                                                               */
+int capf_op_conv_f32h2_tiles(int B, int H, int W, int* tile_pixels);     /* tiles; *tile_pixels (may be NULL): output pixels per tile, flat pixel p -> tile p / that */
+int capf_op_conv_f32h2_planes(void* stream, const capf_conv_desc* conv, const int32_t* exps_in, int32_t* exps_out);
+
 /* The two-fp16-piece arithmetic for every OTHER fp32 conv / linear (csrc/igemm_f32h2.hip; what capf_forward runs from batch 5 for the 1x1 and
  * stride-2 convs of the fuse / transition layers, pose_hrnet.py:225-303, lone convs, and -- in inference plans -- the lifter's nn.Linear layers,
  * pose_dformer.py:15-59): the activation tile is staged as fp32 and split by the wave that consumes it (one power-of-two scale per wave,
@@ -540,6 +555,10 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* desc);      
  * fields beyond that are dropped, a shorter library struct leaves the caller's tail zeroed.                                            */
 int capf_op_describe_sized(const capf_handle* h, int index, void* desc, size_t desc_bytes);
 int capf_op_tensor(const capf_handle* h, int index, int slot, const void** dev_ptr);
+/* Does op `index` exchange a PLANES tensor (capf_op_conv_f32h2_planes) with its BasicBlock partner at this batch?  Returns 0: no (plain fp32 on both
+ * sides), 1: its OUTPUT (slot 5) holds planes, 2: its INPUT (slot 0) does; *exps: the device pointer of the int32 [tiles][channels / 16] exponent table
+ * (valid after a forward of that batch), *tile_pixels: output pixels per tile.  The layer-wise tests decode the planes with these.                 */
+int capf_op_h2_planes(const capf_handle* h, int index, int batch, const void** exps, int32_t* tile_pixels);
 
 int capf_forward_profile(capf_handle* h, void* stream, const float* images_nhwc, const float* k2d,
                          float* kcrop_inout, int batch, float* out, float* op_ms, int n_ops);

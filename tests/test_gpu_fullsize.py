@@ -28,13 +28,13 @@ def _report(tag, got, want):
     return err, mpj
 
 
-def _model(backbone, dtype, wseed):
+def _model(backbone, dtype, wseed, plan_flags=0):
     from mvn.models.conpose import CA_PF
     from mvn.utils.cfg import backbone_preset, config
     cfg = backbone_preset(copy.deepcopy(config), backbone)
     cfg.model.backbone.fix_weights = True
     with contextlib.redirect_stdout(io.StringIO()):
-        model = CA_PF(cfg, compute_dtype=dtype).eval()
+        model = CA_PF(cfg, compute_dtype=dtype, plan_flags=plan_flags).eval()
     sd = synth.load_synthetic(model, seed=wseed, bn_mode="random")
     return model.cuda(), sd
 

@@ -19,8 +19,8 @@ from test_gpu_fullsize import _model
 pytestmark = pytest.mark.gpu
 
 
-def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
-    model, sd = _model(backbone, dtype, wseed)
+def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72, plan_flags=0):
+    model, sd = _model(backbone, dtype, wseed, plan_flags)
     img, k2d, kc = synth.synth_inputs(B, H, W, seed=iseed, crop_range=(W, H))
     img_d = img.cuda()
     eng = model.engine_for(img_d)
@@ -31,13 +31,14 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
     todo = [i for i, d in enumerate(descs) if d.backbone and d.kind in (0, 1, 2, 3)]
     stream = torch.cuda.current_stream().cuda_stream
     bf = dtype == "bf16"
-    worst, kernels, n_checked, flips, n_up = {}, set(), 0, 0, 0
+    worst, kernels, n_checked, flips, n_up, n_planes = {}, set(), 0, 0, 0, 0
     for cp in sorted(set(descs[i].checkpoint for i in todo)):
         eng.forward_prefix(img_d, cp, stream)
         torch.cuda.synchronize()
         for i in [i for i in todo if descs[i].checkpoint == cp]:
             d = descs[i]
-            take = lambda slot, h, w, c, dt: eng.op_tensor(i, slot, (B, h, w, c), dt)[rows].cpu()
+            take = lambda slot, h, w, c, dt: eng.op_tensor_fp32(i, slot, (B, h, w, c), dt)[rows].cpu()      # (planes between a BasicBlock's convs: decoded)
+            n_planes += eng.op_h2_planes(i, B)[0] == 2
             got = take(5, d.Ho, d.Wo, d.Cout, d.out_dtype)
             out_bf = d.out_dtype == 2
             mass = term = None
@@ -77,12 +78,23 @@ def layerwise(backbone, dtype, B, H, W, rows, wseed=71, iseed=72):
         print(f"    {k:38s} worst error {e:9.2e} ({'of the allowance' if bf else 'of the range'})   largest inexact fraction {f:8.2e}   ({name})")
     assert n_checked == len(todo) and n_checked > 85
     layerwise.fused_upsample_adds = n_up
+    layerwise.planes_consumers = n_planes
     return kernels
 
 
 def test_cfg1_layerwise_hrnet32_fp32_batch64():
     k = layerwise("hrnet_32", "fp32", 64, 256, 256, [0, 21, 42, 63])
     assert any(x.startswith("igemm_f32h2_") for x in k)          # (the branch convs: split-fp32 tile from 370 MFLOP per conv, batch >= 5)
+    assert layerwise.planes_consumers == 0                       # (planes between a BasicBlock's convs are opt-in: CAPF_PLAN_H2_PLANES)
+
+
+def test_layerwise_with_planes_between_the_basic_blocks_convs():
+    """CAPF_PLAN_H2_PLANES (opt-in; EXPERIMENTS R6.5): every BasicBlock conv1 of stages 2-4 writes its output as split fp16 planes + one scale
+    exponent per (tile, 16-channel chunk), every conv2 stages them as they are; the engine's operands are decoded with capf_op_h2_planes and held
+    to the same per-op bound as the fp32-tensor plan."""
+    from capf.lib import PLAN_H2_PLANES
+    k = layerwise("hrnet_32", "fp32", 16, 256, 256, [0, 7, 15], plan_flags=PLAN_H2_PLANES)
+    assert any(x.startswith("igemm_f32h2_") for x in k) and layerwise.planes_consumers == 104
 
 
 def test_cfg3_layerwise_hrnet32_fp32_batch512():

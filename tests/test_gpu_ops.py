@@ -1552,3 +1552,65 @@ def test_split_fp32_kernels_take_tensors_beyond_2_gib():
         xb = xg[b:b + 1].permute(0, 3, 1, 2).cpu()
         _h2g_conv_check(big[b:b + 1], xb, w_fold, bd, None, 1, 2, f"h2g conv, frame {b} of a 2.3 GB tensor",
                         capf.conv_nhwc(xg[b:b + 1].contiguous(), wd, bd, 3, 2, 1, None))
+
+
+# ---- round 6: a BasicBlock's conv1 -> conv2 tensor as split fp16 PLANES (igemm_f32h2_ws_tile.h, capf_op_conv_f32h2_planes) ----------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C", [(3, 64, 64, 32), (2, 32, 32, 64), (3, 16, 16, 128), (9, 8, 8, 256), (2, 24, 18, 64), (2, 64, 48, 32), (5, 12, 9, 128), (1, 96, 72, 48)])
+@pytest.mark.parametrize("spread", [0, 8, 30])
+def test_f32h2_planes_between_two_convs(B, H, W, C, spread):
+    """conv1 (BN, ReLU) writes its output already split -- [piece 0 | piece 1] per pixel and 16-channel chunk, one power-of-two scale per
+    (tile, chunk) -- and conv2 (BN, + residual, ReLU) stages the pieces as they are, moving the halo rows of the neighbouring tiles onto the
+    chunk's scale.  Geometries: part-image tiles with neighbours above and below (64x64, 32x32, 64x48, 96x72), whole images, several images
+    per tile, dealt-out pixel columns (widths off multiples of 16).  `spread`: the input's row bands are scaled by 2^+-spread, so that
+    neighbouring tiles' outputs -- and their scales -- differ by up to 2^(2 spread): the halo rescale's normal, denormal (2^-15 .. 2^-24) and
+    flush-to-zero branches all run.  Held to: the decoded planes == the fp32 route's conv1 output to 2^-22 relative (+ 2^-38 of the tile's
+    largest value); conv2 on planes within 1e-6 of the sum of |terms| of an fp64 evaluation ON THE DECODED conv1 output (+ the block-scale
+    term of include/capf.h's bound), and within 2e-6 of the all-fp32-tensor route."""
+    from capf import lib as capf
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + C + spread)
+    x = torch.randn(B, C, H, W, generator=g) * torch.rand(B, C, H, W, generator=g).pow(2)
+    if spread:
+        band = torch.exp2(torch.randint(-spread, spread + 1, (B, 1, H, 1), generator=g).float())
+        x = x * band
+    convs = []
+    for _ in range(2):
+        w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        bnp = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) * 0.4 + 0.8)
+        bn_cuda = tuple(t.cuda() for t in bnp)
+        wp, bias = capf.pack_conv_f32h2(w.cuda(), bn_cuda)
+        wd, bd = capf.pack_conv(w.cuda(), bn_cuda)
+        fold = wd.cpu().double()[:, :9 * C].view(C, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+        convs.append((wp, bias, fold))
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    # the fp32-tensor route: two launches of the same tile with plain tensors in between
+    y1_f32, = capf.conv_nhwc_f32h2_group([(xg, convs[0][0], convs[0][1], 1, None, C)])
+    y2_f32, = capf.conv_nhwc_f32h2_group([(y1_f32, convs[1][0], convs[1][1], 1, xg, C)])
+    # the planes route
+    y1_pl, exps = capf.conv_nhwc_f32h2_planes(xg, convs[0][0], convs[0][1], 1, None, C, planes_out=True)
+    y2_pl = capf.conv_nhwc_f32h2_planes(y1_pl, convs[1][0], convs[1][1], 1, xg, C, exps_in=exps)
+    assert torch.isfinite(y2_pl).all()
+    tp = capf.f32h2_tile_pixels(B, H, W)
+    dec = capf.planes_to_fp32(y1_pl, exps, tp)
+    # (1) what the planes hold: conv1's fp32 result to 22 bits, tiny values to 2^-38 of their (tile, chunk)'s largest
+    tile = (torch.arange(B * H * W, device="cuda") // tp)
+    tmax = torch.zeros(int(tile.max()) + 1, C // 16, device="cuda")
+    tmax.index_reduce_(0, tile, y1_f32.view(B * H * W, C // 16, 16).abs().amax(dim=2), "amax", include_self=True)
+    tol = 2.0 ** -22 * y1_f32.abs() + 2.0 ** -38 * tmax[tile].repeat_interleave(16, dim=1).view(B, H, W, C)
+    assert ((dec - y1_f32).abs() <= tol).all(), ((dec - y1_f32).abs() / tol).max().item()
+    # (2) conv2 from the planes vs fp64 on the decoded operand
+    dd = dec.cpu().double().permute(0, 3, 1, 2)
+    fold, bias2 = convs[1][2], convs[1][1].double().cpu()
+    want = F.relu(F.conv2d(dd, fold, bias2, 1, 1) + x.double())
+    mass = F.conv2d(dd.abs(), fold.abs(), bias2.abs(), 1, 1) + x.double().abs()
+    # block-scale term: M_c over the image (an over-estimate of the three tiles a tile's rows come from), W_c per 16-channel chunk
+    m_c = dd.abs().view(B, C // 16, 16, H, W).amax(dim=(2, 3, 4))
+    w_c = fold.abs().view(C, C // 16, 16 * 9).sum(dim=2)
+    slack = 2.0 ** -38 * (m_c @ w_c.t())[:, :, None, None]
+    got = y2_pl.double().cpu().permute(0, 3, 1, 2)
+    err = (got - want).abs()
+    assert (err <= 1e-6 * mass + slack).all(), (err / (1e-6 * mass + slack)).max().item()
+    # (3) against the fp32-tensor route (whose conv2 reads conv1's fp32 values: one extra 2^-23 on every operand here)
+    d_routes = ((y2_pl - y2_f32).double().cpu().permute(0, 3, 1, 2).abs() / (mass + slack * 2.0 ** 38 * 2.0 ** -23)).max().item()
+    print(f"planes B={B} {H}x{W} C={C} spread 2^+-{spread}: conv2 vs fp64 on the decoded planes {(err / mass).max().item():.2e} of the sum of |terms|; vs the fp32-tensor route {d_routes:.2e}")
+    assert d_routes <= 2e-6
