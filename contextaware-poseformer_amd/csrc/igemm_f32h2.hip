@@ -25,6 +25,8 @@ typedef float g2_f32x4 __attribute__((ext_vector_type(4)));
 typedef float g2_f32x16 __attribute__((ext_vector_type(16)));
 static constexpr int G2_BK = 32;
 static constexpr int G2_LDS_FLOATS = 2 * (128 + 64) * G2_BK;        // the ring, 48 KiB: three blocks per CU for every tile
+[[maybe_unused]] static constexpr int G2_WIDE_FLOATS = 2 * (128 + 128) * G2_BK;      // the 128 x 128 tile's ring, 64 KiB: two blocks per CU
+static constexpr long G2_WIDE_MIN_TILES = 960;
 static constexpr int G2_LNK = 256;                         // largest LayerNorm'ed width (gamma, beta, 2 x 128 row statistics: 3 KiB behind the 48 KiB ring, still three blocks per CU)
 
 long f32h2_gemm_pack_elems(int N, int Kpad) { return (long)N * Kpad + ((N + 3) & ~3); }      // floats: pieces, then 1 / channel scale
@@ -164,7 +166,7 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
     for (int s = 0; s < S - 1; ++s) {
         if (s < nchunks) { prepare(s); fire_all(s); }
     }
-    float* const ln_g = lds + G2_LDS_FLOATS;                // [G2_LNK] | beta [G2_LNK] | mean [128] | rstd [128]
+    float* const ln_g = lds + ((BM == 128 && BN == 128) ? G2_WIDE_FLOATS : G2_LDS_FLOATS);   // [G2_LNK] | beta [G2_LNK] | mean [128] | rstd [128]
     float* const ln_b = ln_g + G2_LNK;
     float mu_f[TM], rs_f[TM];
 #pragma unroll
@@ -304,6 +306,59 @@ __device__ __forceinline__ void igemm_h2_tile(const GemmArgs& p, const int bid, 
     long o_row[TM], r_row[TM];
     bool m_ok[TM];
     float rs[TM];                                           // per-row scale of the branch output (DropPath keep mask / keep_prob), 1 without
+    if constexpr (TN > 2) {                                 // (the wide tile: one column block at a time -- all of bv / wv / rv at once is 192 registers)
+        bool mk[TM];
+        long orow[TM], rrow[TM];
+        float rsc[TM], inv_s[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 32 + (lane & 31);
+            mk[i] = full || m < p.M;
+            orow[i] = 0; rrow[i] = 0; rsc[i] = 1.0f;
+            inv_s[i] = __int_as_float((254 - sb[i]) << 23);
+            if (mk[i]) {
+                if (p.rscale) rsc[i] = p.rscale[m / p.rs_div];
+                orow[i] = PLAIN ? (long)m * p.omap.S1 + p.omap.off : g2_rowmap(p.omap, m);
+                if (p.res) rrow[i] = PLAIN ? (long)m * p.rmap.S1 + p.rmap.off : g2_rowmap(p.rmap, m);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            g2_f32x4 b4[4], w4[4], r4[TM][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                const bool nk = full || n < p.N;
+                b4[g] = g2_f32x4{0.f, 0.f, 0.f, 0.f};
+                w4[g] = g2_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (nk) {
+                    w4[g] = *reinterpret_cast<const g2_f32x4*>(winv + n);
+                    if (p.bias) b4[g] = *reinterpret_cast<const g2_f32x4*>(p.bias + n);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    r4[i][g] = g2_f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.res && mk[i] && nk) r4[i][g] = *reinterpret_cast<const g2_f32x4*>(p.res + rrow[i] + n);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn0 + j * 32 + 4 * (lane >> 5) + 8 * g;
+                    g2_f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = fmaf(fmaf(acc[i][j][4 * g + e], w4[g][e] * inv_s[i], b4[g][e]), rsc[i], r4[i][g][e]);
+                        if (p.act == ACT_GELU) t = g2_gelu(t);
+                        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+                        v[e] = t;
+                    }
+                    if (mk[i] && (full || n < p.N)) *reinterpret_cast<g2_f32x4*>(p.out + orow[i] + n) = v;
+                }
+        }
+        return;
+    }
     g2_f32x4 bv[TN][4], wv[TN][4], rv[TM][TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -379,6 +434,17 @@ __global__ __launch_bounds__(256, 3) void igemm_f32h2g_kernel(GemmArgs p, int cf
 #endif
 }
 
+// cfg 3: 128 x 128 tile, two stages, four waves along M with 32 rows x 128 columns each -- a split row block feeds FOUR column blocks (24 MFMAs
+// per chunk and wave behind the same 16 values per lane), 64 KiB of LDS, two blocks per CU: the wide projections of the training batch
+// (qkv / fc1 of the joint blocks at batch 512), where the split's VALU work bounds the narrower tiles (profiles/r05_pmc_f32h2g_linear.txt)
+template <int CONV, bool PLAIN, bool LNA = false>
+__global__ __launch_bounds__(256, 2) void igemm_f32h2g_wide_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float lds[G2_WIDE_FLOATS + (LNA ? 2 * G2_LNK + 256 : 0)];
+    igemm_h2_tile<128, 128, 32, 128, 2, CONV, PLAIN, LNA>(p, g2_xcd_remap(blockIdx.x, gridDim.x), lds);
+#endif
+}
+
 struct G2GroupArgs {
     GemmArgs g[MAXG];
     int start[MAXG + 1];
@@ -427,15 +493,19 @@ bool gemm_f32h2g_ok(const GemmArgs& a) {
     return true;
 }
 
-static int g2_cfg(const GemmArgs& a) {                      // 128 x 64 tiles once they give every CU two blocks (512; transition1.1.0.0 at batch 64: 123 -> 116 us)
+static int g2_cfg(const GemmArgs& a, bool grouped = false) {                      // 128 x 64 tiles once they give every CU two blocks (512; transition1.1.0.0 at batch 64: 123 -> 116 us)
     // at most 32 output columns (the fuse layers' convs into the 32-channel branch): 128 x 32 -- four waves along M instead of two waves
     // multiplying columns that do not exist; the split blocks (32 rows x chunk) are those of the other tiles: same bits
     if (a.N <= 32 && a.M >= 128) return 2;
     const long big = (long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+    // 128 x 128 from two full rounds of that tile (two blocks per CU) with no ragged last column block.  Measured at batch 512 (8704 rows, K 640, GELU):
+    // N 1920 (1020 tiles) 107.6 -> 93.1 us; N 1280 (680 tiles: 1.33 rounds) 74.8 -> 76.0; N 640 the same -- EXPERIMENTS R6.7
+    if (!grouped && a.N % 128 == 0 && (long)((a.M + 127) / 128) * (a.N / 128) >= G2_WIDE_MIN_TILES) return 3;
     return big >= 512 ? 0 : 1;
 }
 static int g2_tiles(const GemmArgs& a, int cfg) {
     if (cfg == 2) return (a.M + 127) / 128;
+    if (cfg == 3) return ((a.M + 127) / 128) * ((a.N + 127) / 128);
     return ((a.M + (cfg == 0 ? 127 : 63)) / (cfg == 0 ? 128 : 64)) * ((a.N + 63) / 64);
 }
 
@@ -457,6 +527,19 @@ hipError_t launch_gemm_f32h2g(const GemmArgs& a_in, hipStream_t s) {
     g2_fill(a);
     const int cfg = g2_cfg(a), tiles = g2_tiles(a, cfg);
     const bool plain = g2_plain(a);
+    if (cfg == 3) {
+        if (a.conv) {
+            if (!plain) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((igemm_f32h2g_wide_kernel<1, true>), dim3(tiles), dim3(256), 0, s, a);
+        } else if (a.ln_g) {
+            hipLaunchKernelGGL((igemm_f32h2g_wide_kernel<0, true, true>), dim3(tiles), dim3(256), 0, s, a);
+        } else if (plain) {
+            hipLaunchKernelGGL((igemm_f32h2g_wide_kernel<0, true>), dim3(tiles), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((igemm_f32h2g_wide_kernel<0, false>), dim3(tiles), dim3(256), 0, s, a);
+        }
+        return hipGetLastError();
+    }
     if (a.conv) {
         if (!plain) return hipErrorInvalidValue;
         hipLaunchKernelGGL((igemm_f32h2g_kernel<1, true>), dim3(tiles), dim3(256), 0, s, a, cfg);
@@ -480,7 +563,7 @@ hipError_t launch_gemm_f32h2g_group(const GemmArgs* list, int n, hipStream_t s) 
         it[i].a = list[i];
         it[i].a.Wp = list[i].Wh2;
         g2_fill(it[i].a);
-        it[i].cfg = g2_cfg(it[i].a);
+        it[i].cfg = g2_cfg(it[i].a, true);
         it[i].tiles = g2_tiles(it[i].a, it[i].cfg);
         it[i].cost = it[i].a.Kpad;
     }
@@ -503,6 +586,7 @@ hipError_t launch_gemm_f32h2g_group(const GemmArgs* list, int n, hipStream_t s) 
 const char* gemm_f32h2g_kernel_name(const GemmArgs& a, bool grouped) {
     if (grouped) return "igemm_f32h2g_group";
     const int cfg = g2_cfg(a);
+    if (cfg == 3) return a.conv ? "igemm_f32h2g<128x128,conv>" : "igemm_f32h2g<128x128,rows>";
     return a.conv ? (cfg == 0 ? "igemm_f32h2g<128x64,conv>" : (cfg == 2 ? "igemm_f32h2g<128x32,conv>" : "igemm_f32h2g<64x64,conv>"))
                   : (cfg == 0 ? "igemm_f32h2g<128x64,rows>" : (cfg == 2 ? "igemm_f32h2g<128x32,rows>" : "igemm_f32h2g<64x64,rows>"));
 }

@@ -202,7 +202,7 @@ def test_tile_choice_avoids_a_second_round_for_the_lifter_gemms():
     assert {name: kern for name, kern, _ in eng.op_table(8)}["backbone.layer1.0.conv1"].startswith("igemm_f32h2g<")
     assert {name: kern for name, kern, _ in eng_f.op_table(8)}["backbone.layer1.0.conv1"].startswith("igemm_f32<")
     big = {name: kern for name, kern, _ in eng.op_table(512)}
-    assert big["joint0.qkv"] == "igemm_f32h2g<128x64,rows>"
+    assert big["joint0.qkv"] == "igemm_f32h2g<128x128,rows>" and big["joint0.fc1"] == "igemm_f32h2g<128x64,rows>"     # (1020 / 680 tiles of 128 x 128)
     assert {name: kern for name, kern, _ in eng_f.op_table(512)}["joint0.qkv"] in ("igemm_f32<w4,128x128,rows>", "igemm_f32<w4,128x64,rows>")
 
 

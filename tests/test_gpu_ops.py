@@ -1422,7 +1422,8 @@ def test_f32h2g_grouped_convs_match_single_launches():
 
 
 @pytest.mark.parametrize("M,K,N,act,res", [(1088, 640, 1920, 0, False), (1088, 640, 640, 0, True), (1088, 640, 1280, 2, False), (1088, 1280, 640, 0, True),
-                                           (5440, 128, 128, 0, True), (5440, 256, 128, 0, True), (37, 96, 52, 2, True)])
+                                           (5440, 128, 128, 0, True), (5440, 256, 128, 0, True), (37, 96, 52, 2, True),
+                                           (8704, 640, 1920, 0, False), (8650, 256, 1920, 2, True)])     # (the 128 x 128 tile: joint qkv at batch 512; ragged rows)
 def test_f32h2g_linear_matches_fp64(M, K, N, act, res):
     """The lifter's projections at batch 64 (joint blocks: 17 B rows of 640; res blocks: 85 B rows of 128; pose_dformer.py:15-59) and a ragged
     one: y = act(x W^T + b (+ residual)) on the two-fp16-piece GEMM against fp64 (1e-6 of the sum of |terms|, GELU through its Lipschitz
