@@ -190,6 +190,32 @@ GemmArgs Engine::gemm_args(const Op& op, int batch, bool planes) const {
     return a;
 }
 
+bool Engine::bneck0_head(int i, int batch, int last_op, int m[4]) const {
+    if (!use_bneck || !bf16() || i < 0 || i >= (int)ops.size() || ops[i].kind != OP_FORK || ops[i].i0 != 2 || ops[i].region < 0) return false;
+    const int j = regions[ops[i].region].second;                 // the join; conv3 follows it
+    if (j != i + 4 || j + 1 >= last_op || j + 1 >= (int)ops.size()) return false;
+    int c1 = -1, c2 = -1, ds = -1;
+    for (int k = i + 1; k < j; ++k) {
+        const Op& o = ops[k];
+        if (o.kind != OP_GEMM || !o.conv || o.bf16 != 1) return false;
+        if (o.lane == 1) ds = k; else if (c1 < 0) c1 = k; else c2 = k;
+    }
+    const int c3 = j + 1;
+    if (c1 < 0 || c2 < 0 || ds < 0 || ops[c3].kind != OP_GEMM || !ops[c3].conv || ops[c3].bf16 != 1) return false;
+    if (ops[c2].in[0] != ops[c1].out || ops[ds].in[0] != ops[c1].in[0] || ops[c3].in[0] != ops[c2].out || ops[c3].aux != ops[ds].out) return false;
+    // (from 64 Ki pixels: below, the 256 persistent blocks get fewer than four tiles each and the five launches win)
+    if (ops[c1].rows_per_frame * batch < 65536) return false;
+    m[0] = c1; m[1] = c2; m[2] = ds; m[3] = c3;
+    return bneck0_bf16_ok(gemm_args(ops[c1], batch), gemm_args(ops[c2], batch), gemm_args(ops[ds], batch), gemm_args(ops[c3], batch));
+}
+
+int Engine::bneck0_member(int i, int batch) const {
+    int m[4];
+    for (int f = i - 5; f < i; ++f)
+        if (f >= 0 && bneck0_head(f, batch, (int)ops.size(), m) && (i == m[0] || i == m[1] || i == m[2] || i == m[3])) return f;
+    return -1;
+}
+
 bool Engine::pwchain_head(int i, int batch, int last_op) const {
     if (!use_pwchain || i < 0 || i + 1 >= last_op || i + 1 >= (int)ops.size()) return false;
     const Op& a = ops[i];
@@ -430,7 +456,17 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
         s = (par && op.lane > 0) ? side[op.lane - 1] : main_stream;
         if (ev) HIP_TRY(hipEventRecord(ev[oi], s));
         switch (op.kind) {
-            case OP_FORK:
+            case OP_FORK: {
+                int bm[4];
+                if (!ev && bneck0_head(oi, batch, last_op, bm)) {
+                    // a first bottleneck as one launch; prefix runs (the layer-wise tests' capf_forward_prefix) and debug runs take the variant
+                    // that also stores conv1's / conv2's / the shortcut's outputs where the five launches would have
+                    if (log) HIP_TRY(log->mark(main_stream, bm, 4));
+                    HIP_TRY(launch_bneck0_bf16(gemm_args(ops[bm[0]], batch), gemm_args(ops[bm[1]], batch), gemm_args(ops[bm[2]], batch),
+                                               gemm_args(ops[bm[3]], batch), debug || last_op < (int)ops.size(), main_stream));
+                    oi = bm[3];
+                    break;
+                }
                 if (grouped && regions[op.region].second <= last_op) {
                     // lanes == 3: the lanes of a region as TWO grouped chains on two streams (lanes 0 + 3 on the caller's, 1 + 2 on a
                     // side stream), so that one chain's launch ramp / tail overlaps the other's body.  Measured at batch 64 (one
@@ -461,6 +497,7 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                     for (int l = 1; l < op.i0; ++l) HIP_TRY(hipStreamWaitEvent(side[l - 1], events[op.i1], 0));
                 }
                 break;
+            }
             case OP_JOIN:
                 if (par) {
                     for (int l = 1; l < op.i0; ++l) {
@@ -522,7 +559,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~4095) {
+    if (cfg->plan_flags & ~8191) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;
@@ -1211,6 +1248,11 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
                                "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn", "res_chain", "mlp_chain"};
     if (name) *name = op.name.c_str();
     const int n_all = (int)h->e.ops.size();
+    if (kernel && op.kind == capf::OP_GEMM && h->e.bneck0_member(index, batch) >= 0) {
+        *kernel = capf::bneck0_bf16_kernel_name();                      // (the block's four convs ride in one launch)
+        if (flops) *flops = op.flops_per_frame * batch;
+        return CAPF_OK;
+    }
     if (kernel && (h->e.pwchain_head(index, batch, n_all) || h->e.pwchain_head(index - 1, batch, n_all))) {
         *kernel = op.bf16 ? capf::gemm_bf16_pwchain_kernel_name() : capf::gemm_f32_pwchain_kernel_name();      // (both ops ride in one launch)
         if (name) *name = op.name.c_str();
@@ -1421,7 +1463,7 @@ int capf_op_describe(const capf_handle* h, int index, capf_op_desc* d) {
         for (int i = 0; i < 4; ++i) d->shift[i] = op.shift[i];
         if (op.kind == capf::OP_FUSE) { d->Ho = op.H; d->Wo = op.W; }
     }
-    d->checkpoint = (op.region >= 0 ? e.regions[op.region].second : index) + 1;
+    d->checkpoint = (op.bneck_c3 >= 0 ? op.bneck_c3 : op.region >= 0 ? e.regions[op.region].second : index) + 1;
     return CAPF_OK;
 }
 

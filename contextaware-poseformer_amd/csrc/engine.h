@@ -112,6 +112,7 @@ struct Op {
                                   // h2_peer = the other op's index: both must run the two-fp16-piece tile at a batch for the pair to use planes
     std::vector<int> chain;       // OP_RES_CHAIN: per block {pack qkv, proj, fc1, fc2, param norm1.weight, .bias, norm2.weight, .bias};
                                   // OP_MLP_CHAIN: {pack fc1, fc2, param norm2.weight, .bias}, rows through amap
+    int bneck_c3 = -1;            // conv1 / conv2 / downsample of a first bottleneck that may run as one kernel with its conv3 (that op's index; plan.cpp bneck0_mark)
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
     int region = -1;              // index of the enclosing fork/join region, -1 outside
 };
@@ -290,6 +291,11 @@ struct Engine {
     bool pwchain_head(int i, int batch, int last_op) const;
     bool use_pwchain = true;       // plan_flags & CAPF_PLAN_NO_PWCHAIN clears it
     bool has_res_chain = false;    // the plan holds an OP_RES_CHAIN (lifter_chain.hip): its two-piece packs are needed at every batch
+    bool use_bneck = true;         // plan_flags & CAPF_PLAN_NO_BNECK clears it
+    // op i opens the fork / join region of a first bottleneck (conv1, conv2 | downsample) directly followed by its conv3, and the block runs as
+    // ONE launch at this batch (bneck_bf16.hip); m = {conv1, conv2, downsample, conv3}
+    bool bneck0_head(int i, int batch, int last_op, int m[4]) const;
+    int bneck0_member(int i, int batch) const;       // op i rides in such a launch: index of its fork op, -1 otherwise
     bool use_upadd = true;         // plan_flags & CAPF_PLAN_NO_UPADD clears it (CPN bf16: lateral conv + upsampled add in one launch)
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
     GemmArgs gemm_args(const Op& op, int batch, bool planes = true) const;

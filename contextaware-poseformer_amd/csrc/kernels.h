@@ -175,6 +175,11 @@ const char* gemm_f32_pw_kernel_name();
 bool gemm_f32_pwchain_ok(const GemmArgs& a, const GemmArgs& b);
 hipError_t launch_gemm_f32_pwchain(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 const char* gemm_f32_pwchain_kernel_name();
+// the first bottleneck of a layer1 under compute_dtype = bf16 as one persistent kernel (bneck_bf16.hip): conv1 -> conv2 -> conv3 + downsample
+// shortcut + ReLU, intermediates on chip; tap = also store conv1's, conv2's and the downsample's outputs where the unfused ops write them
+bool bneck0_bf16_ok(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& ds, const GemmArgs& c3);
+hipError_t launch_bneck0_bf16(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& ds, const GemmArgs& c3, bool tap, hipStream_t s);
+const char* bneck0_bf16_kernel_name();
 // the bf16 twin (igemm_bf16_pwchain.hip): CPN's / HRNet's layer1 pairs under compute_dtype = bf16
 bool gemm_bf16_pwchain_ok(const GemmArgs& a, const GemmArgs& b);
 hipError_t launch_gemm_bf16_pwchain(const GemmArgs& a, const GemmArgs& b, hipStream_t s);

@@ -211,7 +211,25 @@ static Tensor hr_basic_block(Engine& e, const std::string& p, const Tensor& x) {
     return out;
 }
 
+// A first bottleneck whose five ops may run as ONE kernel (bneck_bf16.hip; Engine::bneck0_head decides per batch): that kernel reads x while it
+// writes y and -- in the variant the layer-wise tests run -- conv1's, conv2's and the shortcut's outputs too, so all five tensors stay alive
+// (no two of them share workspace) from conv1 to conv3; the ops remember conv3 (capf_op_describe: their checkpoint is the whole block).
+// `fork` = index of the region's fork op: fork, conv1, conv2, downsample, join, conv3.
+static void bneck0_mark(Engine& e, int fork) {
+    if (!e.use_bneck || !e.bf16() || fork + 5 >= (int)e.ops.size()) return;
+    const int c1 = fork + 1, c2 = fork + 2, ds = fork + 3, c3 = fork + 5;
+    const Op &o1 = e.ops[c1], &o3 = e.ops[c3];
+    if (e.ops[fork].kind != OP_FORK || e.ops[fork + 4].kind != OP_JOIN || o1.Cin != 64 || o1.N != 64 || o3.N != 256 || e.ops[c2].stride != 1 || e.ops[c2].ks != 3) return;
+    for (int b : {o1.in[0], o1.out, e.ops[c2].out, e.ops[ds].out, o3.out}) {
+        if (b < 0) continue;
+        e.bufs[b].def_op = std::min(e.bufs[b].def_op, c1);
+        e.bufs[b].last_op = std::max(e.bufs[b].last_op, c3);
+    }
+    for (int k : {c1, c2, ds}) e.ops[k].bneck_c3 = c3;
+}
+
 static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, int planes, bool down) {  // :98-136
+    const int fork_at = (int)e.ops.size();
     if (down) e.fork(2);             // the projection shortcut only reads x: independent of conv1 / conv2
     Tensor y = e.conv_bn(p + ".conv1", p + ".bn1", x, planes, 1, 1, ACT_RELU, nullptr);
     y = e.conv_bn(p + ".conv2", p + ".bn2", y, planes, 3, 1, ACT_RELU, nullptr);
@@ -221,7 +239,9 @@ static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, in
         r = e.conv_bn(p + ".downsample.0", p + ".downsample.1", x, planes * 4, 1, 1, ACT_NONE, nullptr);
         e.join();
     }
-    return e.conv_bn(p + ".conv3", p + ".bn3", y, planes * 4, 1, 1, ACT_RELU, &r);
+    Tensor out = e.conv_bn(p + ".conv3", p + ".bn3", y, planes * 4, 1, 1, ACT_RELU, &r);
+    if (down) bneck0_mark(e, fork_at);
+    return out;
 }
 
 // HighResolutionModule (:139-303).  xs: in/out; branch_out (optional) receives the branch outputs.
@@ -362,6 +382,7 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
         for (int k = 0; k < nblk[li]; ++k) {                                               // :58-93, :119-133
             const std::string p = R + ".layer" + std::to_string(li + 1) + "." + std::to_string(k);
             const int st = (k == 0) ? strides[li] : 1;
+            const int fork_at = (int)ops.size();
             if (k == 0) fork(2);         // projection shortcut: independent of conv1 / conv2
             Tensor y = conv_bn(p + ".conv1", p + ".bn1", x, planes[li], 1, 1, ACT_RELU, nullptr);
             y = conv_bn(p + ".conv2", p + ".bn2", y, planes[li], 3, st, ACT_RELU, nullptr);
@@ -372,6 +393,7 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
                 join();
             }
             x = conv_bn(p + ".conv3", p + ".bn3", y, planes[li] * 4, 1, 1, ACT_RELU, &r);
+            if (k == 0 && st == 1) bneck0_mark(*this, fork_at);
         }
         c[li] = x;
     }
@@ -995,6 +1017,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_WINOGRAD_F23_ONLY) wino_f43 = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_UPADD) use_upadd = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_BNECK) use_bneck = false;
     if (cfg.plan_flags & CAPF_PLAN_H2_PLANES) use_h2_planes = true;
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;

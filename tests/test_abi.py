@@ -314,6 +314,28 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
     assert not any(k in ("ctx_attn", "embed") for _, k in wide) and any(k == "deform_sample" for _, k in wide)
 
 
+def test_first_bottleneck_plan_bf16_without_a_gpu():
+    """bneck_bf16.hip in the plan (no device needed): layer1.0's four convs name one kernel at the baseline batches of the two bf16 configurations,
+    CAPF_PLAN_NO_BNECK / fp32 / small batches keep the five launches, and the five tensors the kernel touches never share workspace."""
+    from capf import Engine
+    from capf.lib import PLAN_NO_BNECK
+    from mvn.models import _native
+    for backbone, H, W, B, blk in (("cpn", 384, 288, 128, "backbone.resnet.layer1.0"), ("hrnet_48", 256, 256, 256, "backbone.layer1.0")):
+        eng = Engine(_native.make_capf_config(_cfg(backbone), H, W, compute_dtype="bf16"), device=None)
+        mem = {n: k for n, k, _ in eng.op_table(B) if n.startswith(blk + ".")}
+        assert len(mem) == 4 and set(mem.values()) == {"bneck0_bf16<8x8>"}, mem
+        assert not any(k == "bneck0_bf16<8x8>" for _, k, _ in eng.op_table(2))
+        off = Engine(_native.make_capf_config(_cfg(backbone), H, W, compute_dtype="bf16", plan_flags=PLAN_NO_BNECK), device=None)
+        assert not any(k == "bneck0_bf16<8x8>" for _, k, _ in off.op_table(B))
+        f32 = Engine(_native.make_capf_config(_cfg(backbone), H, W), device=None)
+        assert not any(k == "bneck0_bf16<8x8>" for _, k, _ in f32.op_table(B))
+        # the block's conv1 / conv2 / shortcut are checkpointed behind its conv3 (the layer-wise tests read them from the TAP kernel's stores)
+        names = [n for n, _, _ in eng.op_table(B)]
+        c3 = names.index(blk + ".conv3")
+        for m in ("conv1", "conv2", "downsample.0"):
+            assert eng.op_describe(names.index(f"{blk}.{m}")).checkpoint == c3 + 1
+
+
 def test_executed_flops_of_winograd_ops_are_half_or_two_thirds_of_the_algorithmic_count():
     from capf import Engine
     from mvn.models import _native
