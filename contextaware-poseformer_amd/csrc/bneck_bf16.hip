@@ -183,17 +183,27 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc2[4 * g + e] = bv[e];
         }
-        {
+        if (!(BN_EXP & 1)) {
+            // one wave per SIMD: nothing hides an LDS round trip but the wave's own instruction stream -- the fragments of step s + 3 are
+            // requested before the MFMA of step s (a ring of four register slots; the compiler alone emits read, read, wait, multiply)
             const unsigned char* w2r = W2s + (32 * wj + frow) * 128;
+            constexpr int DEPTH = 3, NSTEP = 36;
+            bn_u32x4 afr[DEPTH + 1], bfr[DEPTH + 1];
+            auto fetch = [&](int s) {             // step s = chunk s / 9 (16 channels), tap s % 9
+                const int cc = s / 9, tap = s - cc * 9;
+                const int p = (pr + tap / 3) * 10 + pc + tap % 3;
+                afr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(wk + p * 128 + (((2 * cc + fhalf) ^ ((p >> 1) & 7)) * 16));
+                bfr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(w2r + tap * (64 * 128) + (((2 * cc + fhalf) ^ fsw) * 16));
+            };
 #pragma unroll
-            for (int cc = 0; cc < ((BN_EXP & 1) ? 0 : 4); ++cc)
+            for (int s = 0; s < DEPTH; ++s) fetch(s);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int p = (pr + tap / 3) * 10 + pc + tap % 3;
-                    const bn_u32x4 af = *reinterpret_cast<const bn_u32x4*>(wk + p * 128 + (((2 * cc + fhalf) ^ ((p >> 1) & 7)) * 16));
-                    const bn_u32x4 bf = *reinterpret_cast<const bn_u32x4*>(w2r + tap * (64 * 128) + (((2 * cc + fhalf) ^ fsw) * 16));
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, bf), __builtin_bit_cast(bn_bf16x8, af), acc2, 0, 0, 0);
-                }
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + DEPTH < NSTEP) fetch(s + DEPTH);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, bfr[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, afr[s & DEPTH]), acc2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         bn_u32x2 t2p[4];
 #pragma unroll
@@ -224,16 +234,27 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { z[i][4 * g + e] = b3v[e]; d[i][4 * g + e] = bdv[e]; }
             }
-#pragma unroll
-        for (int st = 0; st < ((BN_EXP & 2) ? 0 : 4); ++st)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        if (!(BN_EXP & 2)) {
+            constexpr int DEPTH = 3, NSTEP = 16;   // step s = (k-step s / 4, channel block s % 4): the same ring as conv2's
+            bn_u32x4 f3r[DEPTH + 1], fdr[DEPTH + 1];
+            auto fetch = [&](int s) {
+                const int st = s >> 2, i = s & 3;
                 const unsigned wo = (unsigned)((32 * (4 * wj + i) + frow) * 128 + (((2 * st + fhalf) ^ fsw) * 16));
-                const bn_u32x4 f3 = *reinterpret_cast<const bn_u32x4*>(W3s + wo);
-                const bn_u32x4 fd = *reinterpret_cast<const bn_u32x4*>(Wds + wo);
-                z[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, f3), __builtin_bit_cast(bn_bf16x8, a2[st]), z[i], 0, 0, 0);
-                d[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, fd), __builtin_bit_cast(bn_bf16x8, xc[st]), d[i], 0, 0, 0);
+                f3r[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(W3s + wo);
+                fdr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(Wds + wo);
+            };
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) fetch(s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int st = s >> 2, i = s & 3;
+                if (s + DEPTH < NSTEP) fetch(s + DEPTH);
+                z[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, f3r[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, a2[st]), z[i], 0, 0, 0);
+                d[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, fdr[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, xc[st]), d[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
         request_xc(tile + per);
         // ---- y = relu(acc3 + bf16(acc_d)), one 32 x 32 block at a time through this wave's scratch
         const bn_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + frame_px * 256), 0, 0x7FFFFF00u, 0x00020000);

@@ -222,6 +222,7 @@ bool Engine::pwchain_head(int i, int batch, int last_op) const {
     const Op& b = ops[i + 1];
     if (a.kind != OP_GEMM || !a.conv || b.kind != OP_GEMM || !b.conv || a.bf16 != b.bf16 || a.bf16 > 1) return false;
     if (b.in[0] != a.out || b.region != a.region || b.lane != a.lane) return false;
+    if (a.bf16 && bneck0_member(i, batch) >= 0) return false;       // (the conv3 of a fused first bottleneck: that launch does not chain into the next block)
     return a.bf16 ? gemm_bf16_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch)) : gemm_f32_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch));
 }
 
