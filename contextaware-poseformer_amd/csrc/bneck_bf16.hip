@@ -26,7 +26,7 @@
 // TAP kernel's bit for bit (tests/test_gpu_bneck.py).
 #include "kernels.h"
 #ifndef BN_EXP
-#define BN_EXP 0               // (tools/ab_bneck.sh knock-outs: timing only)
+#define BN_EXP 0               // (tools/ab_define.sh knock-outs: timing only)
 #endif
 
 namespace capf {

@@ -318,6 +318,7 @@ int Engine::exec_op(const Op& op, hipStream_t s, int batch) {
                 a.feat[l] = ptr(op.in[l]);
                 a.H[l] = op.lvlH[l]; a.W[l] = op.lvlW[l]; a.Cl[l] = op.lvlC[l];
                 a.Wp[l] = pack_arena + packs[op.pq[l]].w_off; a.bp[l] = params[op.pb[l]].ptr;
+                a.U[l] = op.outs[l] >= 0 ? ptr(op.outs[l]) : nullptr;
             }
             a.Wao = pack_arena + pk.w_off; a.bao = pack_arena + pk.b_off; a.ldw = pk.Kpad;
             a.ln_g = params[op.p0].ptr; a.ln_b = params[op.p1].ptr; a.eps = op.eps;

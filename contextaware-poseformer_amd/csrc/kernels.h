@@ -381,6 +381,8 @@ struct CtxAttnArgs {
     int woff[4];                 // per-wave LDS section offsets (floats), filled by the launcher
     float* cpos;                 // optional taps (capf_set_debug): sampling positions [BJ, L, NH*NS, 2] and their NW corners
     int* cidx;
+    float* U[4];                 // optional: per level [BJ * NH][Cl] scratch -- the per-head weighted sample sums leave the kernel and embed_proj +
+                                 // residual run as ONE fp32-MFMA launch over all levels behind it (ctx_proj_kernel); null: inside the kernel
 };
 hipError_t launch_ctx_attn(const CtxAttnArgs& a, hipStream_t s);
 // tiny multi-head attention: QKV [G*N, 3*heads*d] -> O [G*N, heads*d]; N tokens per group

@@ -169,8 +169,14 @@ __device__ __forceinline__ f32x4 ld4(const float* base, long elem_off, int c) {
 // reference — softmax weight, tanh offset, clipped position, corner index, the four bilinear weights — is computed
 // ONCE by the lane that owns that sample (16 lanes), not redundantly by all 64 lanes: a wave64 VALU instruction
 // costs 4 cycles whatever the number of useful lanes, and 32 tanhf + 16 expf per wave were ~10 us of the serial chain.
-template <bool BF>
-__global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
+#ifndef CTX_EXP
+#define CTX_EXP 0                 // (tools/ab_define.sh knock-outs, timing only: 1 no attention / offset dot products, 2 no gather, 4 no embed_proj)
+#endif
+#ifndef CTX_MIN_BLOCKS
+#define CTX_MIN_BLOCKS 1          // (tools/ab_define.sh: A/B builds)
+#endif
+template <bool BF, bool PROJ = true>
+__global__ __launch_bounds__(256, CTX_MIN_BLOCKS) void ctx_attn_kernel(CtxAttnArgs a) {
     extern __shared__ float sm[];
     // per wave (level): Q [C] | AO [3*NK] | SW [NK][4] weights | SO [NK][4] pixel offsets (int) | U [NH * Cl]
     const int C = a.C;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
         const float* wr = a.Wao + (long)lane * 4;               // quad-interleaved pack: Wq[c / 4][3 * NK outputs][4]
         float acc = 0.f;
 #pragma unroll 16
-        for (int c = 0; c < C; c += 4) {
+        for (int c = 0; c < ((CTX_EXP & 1) ? 4 : C); c += 4) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wr + (long)c * (3 * CTX_NK));
             const f32x4 t = *reinterpret_cast<const f32x4*>(q + c);
             acc += ((t[0] * w[0] + t[1] * w[1]) + t[2] * w[2]) + t[3] * w[3];
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     // ---- gather + weighted sum: a lane owns 4 consecutive channels (one 16-byte load per corner)
     const float* feat = pixp<BF>(a.feat[l], (long)b * H * W, Cl);
-    for (int c = lane * 4; c < Cl; c += 256) {
+    for (int c = lane * 4; c < ((CTX_EXP & 2) ? 0 : Cl); c += 256) {
 #pragma unroll
         for (int h = 0; h < CTX_NH; ++h) {
             f32x4 u = {0.f, 0.f, 0.f, 0.f};
@@ -278,6 +284,11 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (!PROJ) {                                  // embed_proj runs behind this launch (ctx_proj_kernel): the sums leave as [b p][h][Cl], the wave's last act
+        float* ug = a.U[l] + (long)bp * CTX_NH * Cl;   // (stores inside the gather loop sit in front of the next head's loads in the memory counter)
+        for (int i = lane * 4; i < CTX_NH * Cl; i += 256) *reinterpret_cast<f32x4*>(ug + i) = *reinterpret_cast<const f32x4*>(U + i);
+        return;
+    }
     // ---- embed_proj[l] + residual: lane -> (output j, head slot hs); heads hs, hs + nhs, ...
     const int HD = C / CTX_NH;                    // 32 for embed 128
     const float* Wp = a.Wp[l];
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
         for (int t = 0; t < CTX_NH; ++t) acc[t] = 0.f;
         const float* wr = Wp + (long)j * 4;                     // quad-interleaved pack: Wq[c / 4][HD][4]
 #pragma unroll 8
-        for (int c = 0; c < Cl; c += 4) {
+        for (int c = 0; c < ((CTX_EXP & 4) ? 4 : Cl); c += 4) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wr + (long)c * HD);
 #pragma unroll
             for (int t = 0; t < CTX_NH; ++t) {
@@ -310,6 +321,74 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(CtxAttnArgs a) {
     }
 }
 
+// embed_proj[l] + residual of ALL levels as one launch (pose_dformer.py:130-135): X[b, p, 1 + l, h HD + j] += U_l[(b, p, h), :] . Wp_l[j, :] + bp_l[j].
+// Inside ctx_attn_kernel these were FMA dot products over weights streamed through L2 by every (frame, joint) block -- half of that kernel's
+// time at every batch (knock-outs, EXPERIMENTS R6.9) although they are 0.1 GFLOP: a chain of dependent load batches per wave.  Here a wave
+// takes 32 rows (8 joints x 4 heads) of one level through v_mfma_f32_32x32x2_f32 -- fp32 operands, exact products, fp32 accumulation: the
+// arithmetic of the reference's nn.Linear -- with HD = 32 output channels as the MFMA's other dimension; K runs 8 columns per step pair.
+struct CtxProjArgs {
+    const float* U[4]; const float* Wp[4]; const float* bp[4];
+    int Cl[4];
+    float* X;
+    int rows, L1, C;             // rows = BJ * NH
+};
+
+__global__ __launch_bounds__(256) void ctx_proj_kernel(CtxProjArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    // the four waves of a block split K: wave w takes the 8-column steps w, w + 4, ... (at most 12 of them: Cl <= 384), ALL of its loads
+    // requested before its first MFMA -- one load round trip per wave instead of one per step -- and the partial tiles meet in LDS
+    __shared__ float part[3][16][64];
+    const int l = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int Cl = a.Cl[l], nit = Cl >> 3;
+    const int r = blockIdx.x * 32 + col;                   // row (b p, h)
+    const bool ok = r < a.rows;
+    const float* urow = a.U[l] + (long)(ok ? r : 0) * Cl + 4 * half;
+    const float* wq = a.Wp[l] + col * 4 + (long)half * (32 * 4);       // quad-interleaved pack Wq[c / 4][HD = 32][4]: W[j = col][c .. c + 3]
+    constexpr int MAXIT = 12;
+    f32x4 w[MAXIT], u[MAXIT];
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+        const int it = wave + 4 * i;                        // (wave-uniform)
+        if (it < nit) {
+            w[i] = *reinterpret_cast<const f32x4*>(wq + (long)(2 * it) * (32 * 4));
+            u[i] = *reinterpret_cast<const f32x4*>(urow + 8 * it);
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {                      // lanes 0-31 carry k = c .. c + 3, lanes 32-63 k = c + 4 .. c + 7, one k of each per MFMA
+        if (wave + 4 * i < nit) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i][e], ok ? u[i][e] : 0.f, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0 || !ok) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += (part[0][e][lane] + part[1][e][lane]) + part[2][e][lane];
+    // accumulator register 4 g + e = output channel j = 8 g + 4 half + e of this lane's row
+    const int bpi = r >> 2, h = r & 3;                     // (CTX_NH == 4)
+    float* xo = a.X + ((long)bpi * a.L1 + 1 + l) * a.C + h * 32 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp[l] + 8 * g + 4 * half);
+        f32x4 x = *reinterpret_cast<const f32x4*>(xo + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += acc[4 * g + e] + b[e];
+        *reinterpret_cast<f32x4*>(xo + 8 * g) = x;
+    }
+#endif
+}
+
 hipError_t launch_ctx_attn(const CtxAttnArgs& a_in, hipStream_t s) {
     CtxAttnArgs a = a_in;
     if (a.NH != CTX_NH || a.NS != CTX_NS || a.L > 4 || a.C > 256 || a.C % 16 != 0) return hipErrorInvalidValue;
@@ -323,8 +402,19 @@ hipError_t launch_ctx_attn(const CtxAttnArgs& a_in, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)off;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     dim3 grid(a.BJ), block(256);
-    if (a.feat_bf16) hipLaunchKernelGGL(ctx_attn_kernel<true>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(ctx_attn_kernel<false>, grid, block, lds, s, a);
+    bool split = a.U[0] != nullptr && a.C == CTX_NH * 32;          // (HD = 32: the MFMA's width)
+    for (int l = 0; l < a.L; ++l) split = split && a.U[l] && a.Cl[l] % 8 == 0 && a.Cl[l] <= 384;
+    if (!split) {
+        if (a.feat_bf16) hipLaunchKernelGGL(ctx_attn_kernel<true>, grid, block, lds, s, a);
+        else hipLaunchKernelGGL(ctx_attn_kernel<false>, grid, block, lds, s, a);
+        return hipGetLastError();
+    }
+    if (a.feat_bf16) hipLaunchKernelGGL((ctx_attn_kernel<true, false>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((ctx_attn_kernel<false, false>), grid, block, lds, s, a);
+    CtxProjArgs q{};
+    for (int l = 0; l < a.L; ++l) { q.U[l] = a.U[l]; q.Wp[l] = a.Wp[l]; q.bp[l] = a.bp[l]; q.Cl[l] = a.Cl[l]; }
+    q.X = a.X; q.rows = a.BJ * CTX_NH; q.L1 = a.L1; q.C = a.C;
+    hipLaunchKernelGGL(ctx_proj_kernel, dim3((q.rows + 31) / 32, a.L), dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

@@ -741,6 +741,8 @@ void Engine::build_lifter(const Tensor feats[4]) {
                     op.pw[l] = pidx(*this, p + ".embed_proj." + std::to_string(l) + ".weight");
                     op.pb[l] = pidx(*this, p + ".embed_proj." + std::to_string(l) + ".bias");
                     op.pq[l] = make_linear_pack(*this, {p + ".embed_proj." + std::to_string(l)}, false, true);
+                    op.outs[l] = U[l];           // (the sample sums cross HBM to the embed_proj launch: lifter_fused.hip ctx_proj_kernel)
+                    use(U[l]);
                     op.flops_per_frame += 2.0 * J * NH * (double)HD * Cl[l];
                 }
                 op.flops_per_frame += 2.0 * J * L * (double)C * 3 * NH * NS;
