@@ -44,7 +44,7 @@ __device__ __forceinline__ const float* pixp(const float* base, long pixel_index
 static constexpr int EG = 1;
 
 // One block = EG consecutive (b, p) pairs; wave l = level l.  X layout [B, J, L1, C] ("b p l c").
-template <bool BF>
+template <bool BF, bool PROJ = true>
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     __shared__ float S[4][EG][512];           // sampled rows, level l: C_l <= 512 channels
     __shared__ float ref_s[EG][2];
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
             if (a.sampled[l]) a.sampled[l][(long)bp * Cl + c] = v;
         }
     }
+    if (!PROJ) return;                        // feat_embed + pos-embed: embed_feat_kernel, behind this launch, off the sampled rows
     __builtin_amdgcn_wave_barrier();          // S[l] is written and read by this wave only
     __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the LDS writes above have landed
     // ---- feat_embed[l]: X[b, p, 1 + l, j] = S . W_l[j, :] + b_l[j] + pos[1 + l, p, j],  lane -> outputs j, j + 64, ...
@@ -135,13 +136,23 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void embed_feat_kernel(EmbedArgs a);       // (below, beside its twin ctx_proj_kernel)
+
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
     if (a.L > 4 || a.C % 4 != 0) return hipErrorInvalidValue;
     for (int l = 0; l < a.L; ++l)
         if (a.Cl[l] > 512 || a.Cl[l] % 4 != 0) return hipErrorInvalidValue;
     dim3 grid((a.BJ + EG - 1) / EG), block(256);
-    if (a.feat_bf16) hipLaunchKernelGGL(embed_kernel<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(embed_kernel<false>, grid, block, 0, s, a);
+    bool split = a.C % 32 == 0;
+    for (int l = 0; l < a.L; ++l) split = split && a.sampled[l] && a.Cl[l] % 8 == 0 && a.Cl[l] <= 384;
+    if (!split) {
+        if (a.feat_bf16) hipLaunchKernelGGL(embed_kernel<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(embed_kernel<false>, grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.feat_bf16) hipLaunchKernelGGL((embed_kernel<true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((embed_kernel<false, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL(embed_feat_kernel, dim3((a.BJ + 31) / 32, a.L, a.C / 32), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -321,47 +332,37 @@ __global__ __launch_bounds__(256, CTX_MIN_BLOCKS) void ctx_attn_kernel(CtxAttnAr
     }
 }
 
-// embed_proj[l] + residual of ALL levels as one launch (pose_dformer.py:130-135): X[b, p, 1 + l, h HD + j] += U_l[(b, p, h), :] . Wp_l[j, :] + bp_l[j].
-// Inside ctx_attn_kernel these were FMA dot products over weights streamed through L2 by every (frame, joint) block -- half of that kernel's
-// time at every batch (knock-outs, EXPERIMENTS R6.9) although they are 0.1 GFLOP: a chain of dependent load batches per wave.  Here a wave
-// takes 32 rows (8 joints x 4 heads) of one level through v_mfma_f32_32x32x2_f32 -- fp32 operands, exact products, fp32 accumulation: the
-// arithmetic of the reference's nn.Linear -- with HD = 32 output channels as the MFMA's other dimension; K runs 8 columns per step pair.
-struct CtxProjArgs {
-    const float* U[4]; const float* Wp[4]; const float* bp[4];
-    int Cl[4];
-    float* X;
-    int rows, L1, C;             // rows = BJ * NH
-};
-
-__global__ __launch_bounds__(256) void ctx_proj_kernel(CtxProjArgs a) {
+// A 32 x 32 tile of  rows [32 of them, pitch Cl] . W[32 output channels, Cl]^T  with the calling 256-thread block: W in the quad-interleaved pack
+// Wq[c / 4][N][4] (N = the pack's output channels, j0 = this tile's first one).  The four waves split K: wave w takes the 8-column steps w, w + 4, ...
+// (at most 12 of them: Cl <= 384), ALL of its loads requested before its first MFMA -- one load round trip per wave instead of one per step -- and
+// the partial tiles meet in LDS.  True in wave 0 for lanes whose row exists: acc register 4 g + e = output channel j0 + 8 g + 4 (lane >> 5) + e of row
+// r0 + (lane & 31).  Lanes 0-31 carry k = c .. c + 3, lanes 32-63 k = c + 4 .. c + 7 of a step: one k of each per v_mfma_f32_32x32x2_f32.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ bool rows_tile_f32(const float* __restrict__ rows, int nrows, int r0, int Cl, const float* __restrict__ Wq, int N, int j0,
+                                              f32x16_t& acc, float (*part)[16][64]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    // the four waves of a block split K: wave w takes the 8-column steps w, w + 4, ... (at most 12 of them: Cl <= 384), ALL of its loads
-    // requested before its first MFMA -- one load round trip per wave instead of one per step -- and the partial tiles meet in LDS
-    __shared__ float part[3][16][64];
-    const int l = blockIdx.y, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int col = lane & 31, half = lane >> 5;
-    const int Cl = a.Cl[l], nit = Cl >> 3;
-    const int r = blockIdx.x * 32 + col;                   // row (b p, h)
-    const bool ok = r < a.rows;
-    const float* urow = a.U[l] + (long)(ok ? r : 0) * Cl + 4 * half;
-    const float* wq = a.Wp[l] + col * 4 + (long)half * (32 * 4);       // quad-interleaved pack Wq[c / 4][HD = 32][4]: W[j = col][c .. c + 3]
+    const int nit = Cl >> 3;
+    const int r = r0 + col;
+    const bool ok = r < nrows;
+    const float* urow = rows + (long)(ok ? r : 0) * Cl + 4 * half;
+    const float* wq = Wq + (long)(j0 + col) * 4 + (long)half * ((long)N * 4);
     constexpr int MAXIT = 12;
     f32x4 w[MAXIT], u[MAXIT];
 #pragma unroll
     for (int i = 0; i < MAXIT; ++i) {
         const int it = wave + 4 * i;                        // (wave-uniform)
         if (it < nit) {
-            w[i] = *reinterpret_cast<const f32x4*>(wq + (long)(2 * it) * (32 * 4));
+            w[i] = *reinterpret_cast<const f32x4*>(wq + (long)(2 * it) * ((long)N * 4));
             u[i] = *reinterpret_cast<const f32x4*>(urow + 8 * it);
         }
     }
-    f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXIT; ++i) {                      // lanes 0-31 carry k = c .. c + 3, lanes 32-63 k = c + 4 .. c + 7, one k of each per MFMA
+    for (int i = 0; i < MAXIT; ++i) {
         if (wave + 4 * i < nit) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i][e], ok ? u[i][e] : 0.f, acc, 0, 0, 0);
@@ -372,10 +373,34 @@ __global__ __launch_bounds__(256) void ctx_proj_kernel(CtxProjArgs a) {
         for (int e = 0; e < 16; ++e) part[wave - 1][e][lane] = acc[e];
     }
     __syncthreads();
-    if (wave > 0 || !ok) return;
+    if (wave > 0 || !ok) return false;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] += (part[0][e][lane] + part[1][e][lane]) + part[2][e][lane];
-    // accumulator register 4 g + e = output channel j = 8 g + 4 half + e of this lane's row
+    return true;
+#else
+    return false;
+#endif
+}
+
+// embed_proj[l] + residual of ALL levels as one launch (pose_dformer.py:130-135): X[b, p, 1 + l, h HD + j] += U_l[(b, p, h), :] . Wp_l[j, :] + bp_l[j].
+// Inside ctx_attn_kernel these were FMA dot products over weights streamed through L2 by every (frame, joint) block -- half of that kernel's
+// time at every batch (knock-outs, EXPERIMENTS R6.9) although they are 0.1 GFLOP: a chain of dependent load batches per wave.  Here a block
+// takes 32 rows (8 joints x 4 heads) of one level through v_mfma_f32_32x32x2_f32 -- fp32 operands, exact products, fp32 accumulation: the
+// arithmetic of the reference's nn.Linear -- with HD = 32 output channels as the MFMA's other dimension.
+struct CtxProjArgs {
+    const float* U[4]; const float* Wp[4]; const float* bp[4];
+    int Cl[4];
+    float* X;
+    int rows, L1, C;             // rows = BJ * NH
+};
+
+__global__ __launch_bounds__(256) void ctx_proj_kernel(CtxProjArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float part[3][16][64];
+    const int l = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5;
+    f32x16_t acc;
+    if (!rows_tile_f32(a.U[l], a.rows, blockIdx.x * 32, a.Cl[l], a.Wp[l], 32, 0, acc, part)) return;
+    const int r = blockIdx.x * 32 + (lane & 31);
     const int bpi = r >> 2, h = r & 3;                     // (CTX_NH == 4)
     float* xo = a.X + ((long)bpi * a.L1 + 1 + l) * a.C + h * 32 + 4 * half;
 #pragma unroll
@@ -384,6 +409,29 @@ __global__ __launch_bounds__(256) void ctx_proj_kernel(CtxProjArgs a) {
         f32x4 x = *reinterpret_cast<const f32x4*>(xo + 8 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] += acc[4 * g + e] + b[e];
+        *reinterpret_cast<f32x4*>(xo + 8 * g) = x;
+    }
+#endif
+}
+
+// feat_embed[l] + pos-embed of all levels (pose_dformer.py:220-225) the same way, behind embed_kernel<.., false>:
+// X[b, p, 1 + l, j] = (S_l[(b, p), :] . W_l[j, :] + b_l[j]) + pos[1 + l, p, j];  grid (row tiles, levels, C / 32)
+__global__ __launch_bounds__(256) void embed_feat_kernel(EmbedArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float part[3][16][64];
+    const int l = blockIdx.y, j0 = blockIdx.z * 32, lane = threadIdx.x & 63, half = lane >> 5;
+    f32x16_t acc;
+    if (!rows_tile_f32(a.sampled[l], a.BJ, blockIdx.x * 32, a.Cl[l], a.fw[l], a.C, j0, acc, part)) return;
+    const int bp = blockIdx.x * 32 + (lane & 31), p = bp % a.J;
+    float* xo = a.X + ((long)bp * a.L1 + 1 + l) * a.C + j0 + 4 * half;
+    const float* po = a.pos + ((long)(1 + l) * a.J + p) * a.C + j0 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.fb[l] + j0 + 8 * g + 4 * half);
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(po + 8 * g);
+        f32x4 x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = (acc[4 * g + e] + b[e]) + pe[e];
         *reinterpret_cast<f32x4*>(xo + 8 * g) = x;
     }
 #endif
