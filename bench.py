@@ -137,9 +137,10 @@ def workload_string(a, tag):
                "fp32-pipe plans are timed on the same line (exact_split_plan, fp32_pipe_plan)") +
               ("; every other conv / GEMM: fp32 MFMA" if getattr(a, "no_f32x3", False) else
                "; the other convs and the lifter's projections (LayerNorm-folded ones included): the same two-piece arithmetic (igemm_f32h2g); "
-               "pointwise layer1 convs and the stem: fp32 MFMA")) if a.dtype == "f32" else
+               "pointwise layer1 convs, the stem and the lifter's embed_proj / feat_embed rows: fp32 MFMA")) if a.dtype == "f32" else
              "bf16 MFMA operands, fp32 accumulate (backbone convs; lifter GEMMs fp32: --lifter-fp32)" if getattr(a, "lifter_fp32", False) else
-             "bf16 MFMA operands, fp32 accumulate (backbone convs + lifter GEMMs; LN/softmax/residual fp32)")
+             "bf16 MFMA operands, fp32 accumulate (backbone convs, layer1's first bottleneck as one kernel, lifter GEMMs; LN / softmax / samplers / "
+             "embed_proj / feat_embed / residual stream fp32)")
     if a.train:
         return (f"{head}: TRAINING step, {per} {a.backbone} {a.height}x{a.width} (frozen backbone forward, lifter "
                 f"fwd+bwd, MPJPE, flat-gradient all-reduce, fused AdamW, DropPath on), lifter embed {a.embed} levels 4, {arith}")

@@ -156,6 +156,10 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
             const int px = qi >> 2, qt = qi & 3;
             a_lds[j] = PIN ? (unsigned)((2 * (qt >> 1) + (qt & 1)) * HP + px * 16)       // (planes: quarter qt = piece qt >> 1, channels 8 (qt & 1) ..)
                            : (unsigned)((qt >> 1) * HP + px * 16 + (qt & 1) * 8);
+#if (H2_EXPERIMENT & 64)
+            a_voff[j] = (unsigned)(qi * 16 + q0);            // (timing only: no per-unit geometry)
+            continue;
+#endif
             const int g = ws_div(px, p.d_segp), rem = px - g * p.SEGP;
             const int rr = ws_div(rem, p.d_pw), ww = rem - rr * p.PW;
             if (PIN) a_cls |= (rr == 0 ? 1u : (rr == p.RH + 1 ? 2u : 0u)) << (2 * j);   // whose scale the unit's row carries: own tile / the one above / below
