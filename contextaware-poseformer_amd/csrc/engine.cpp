@@ -27,6 +27,10 @@ int Engine::repack(hipStream_t s, bool lifter_only) {
             return CAPF_ERR_STATE;
         }
     }
+    if (!utab_on_device && !utab_host.empty()) {        // the conv tile's unit tables: a function of the plan, uploaded once (synchronous: a pageable source)
+        HIP_TRY(hipMemcpy(pack_arena + utab_off, utab_host.data(), utab_host.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        utab_on_device = true;
+    }
     for (const Pack& pk : packs) {                      // the convs' two-fp16-piece copies (igemm_f32h2.hip); the linears' are packed lazily
         if (!pk.h2g || pk.kind != 0 || lifter_only) continue;
         HIP_TRY(launch_pack_f32h2_gemm(params[pk.w[0]].ptr, params[pk.bn_g].ptr, params[pk.bn_b].ptr, params[pk.bn_m].ptr, params[pk.bn_v].ptr,
@@ -144,6 +148,7 @@ GemmArgs Engine::gemm_args(const Op& op, int batch, bool planes) const {
     if (pk.rh) a.Wp2 = pack_arena + pk.w2_off;
     if (pk.ws || pk.x3) a.Wp3 = pack_arena + pk.w3_off;
     a.x3_h2 = pk.x3 && x3_h2;
+    if (a.x3_h2 && op.h2_utab >= 0 && utab_on_device) a.h2_utab = reinterpret_cast<const unsigned*>(pack_arena + utab_off) + op.h2_utab;
     // the plain fp32 MFMA kernels' problems on the two-fp16-piece GEMM from batch 5 (launch_gemm_f32 / _group route them; below, the fp32
     // kernels with split-K win); LayerNorm folds of up to 256 columns included (igemm_f32h2.hip, LNA)
     if (pk.h2g && batch >= H2G_MIN_BATCH && !op.bf16 && !op.pw_pair && !(op.wino && wino_now(op, batch))) a.Wh2 = pack_arena + pk.wh_off;

@@ -112,6 +112,7 @@ struct Op {
                                   // h2_peer = the other op's index: both must run the two-fp16-piece tile at a batch for the pair to use planes
     std::vector<int> chain;       // OP_RES_CHAIN: per block {pack qkv, proj, fc1, fc2, param norm1.weight, .bias, norm2.weight, .bias};
                                   // OP_MLP_CHAIN: {pack fc1, fc2, param norm2.weight, .bias}, rows through amap
+    long h2_utab = -1;            // two-fp16-piece conv tile: word offset of this conv's map geometry in the engine's unit tables (-1: none)
     int bneck_c3 = -1;            // conv1 / conv2 / downsample of a first bottleneck that may run as one kernel with its conv3 (that op's index; plan.cpp bneck0_mark)
     int lane = 0;                 // stream lane inside a fork/join region (0 = the caller's stream)
     int region = -1;              // index of the enclosing fork/join region, -1 outside
@@ -291,6 +292,9 @@ struct Engine {
     bool pwchain_head(int i, int batch, int last_op) const;
     bool use_pwchain = true;       // plan_flags & CAPF_PLAN_NO_PWCHAIN clears it
     bool has_res_chain = false;    // the plan holds an OP_RES_CHAIN (lifter_chain.hip): its two-piece packs are needed at every batch
+    std::vector<unsigned> utab_host;     // the unit tables of the two-fp16-piece conv tile, one per map geometry (H, W, Cin) of the plan (build())
+    size_t utab_off = 0;                 // ... and their place in the pack arena (uploaded once: they depend on the plan alone)
+    bool utab_on_device = false;
     bool use_bneck = true;         // plan_flags & CAPF_PLAN_NO_BNECK clears it
     // op i opens the fork / join region of a first bottleneck (conv1, conv2 | downsample) directly followed by its conv3, and the block runs as
     // ONE launch at this batch (bneck_bf16.hip); m = {conv1, conv2, downsample, conv3}

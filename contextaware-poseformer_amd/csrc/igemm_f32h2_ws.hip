@@ -39,6 +39,7 @@ static bool h2_from_args(const GemmArgs& a, H2Problem* q) {
     // conv1 / conv2, equal shapes by construction -- chunks of 16 channels must be whole, a producer adds no residual
     q->ein = a.h2_ein;
     q->eout = a.h2_eout;
+    q->utab = a.h2_utab;
     if (a.h2_eout && (a.res || a.N % 16 != 0 || a.omap.S1 != a.N)) return false;
     if (a.h2_ein && a.Cin % 16 != 0) return false;
     return true;
@@ -54,6 +55,7 @@ int f32h2_tiles_m(int B, int H, int W, int* tile_pixels) {
     if (tile_pixels) *tile_pixels = q.g.P;
     return q.g.tiles_m;
 }
+bool f32h2_unit_table(int H, int W, int Cin, unsigned* out) { return h2_unit_table(H, W, Cin, out); }
 bool f32h2_shape_ok(int B, int H, int W, int Cin, int Cout) {
     H2Problem q;
     return h2_plan(B, H, W, Cin, Cout, 32, &q);

@@ -30,6 +30,8 @@
 #ifndef H2_EXPERIMENT
 #define H2_EXPERIMENT 0      // (tools/f32h2_ws.hip knock-outs: timing only)
 #endif
+#include <algorithm>
+
 #include "igemm_bf16_ws_tile.h"
 
 namespace capf {
@@ -54,7 +56,14 @@ struct H2Problem {
     // halo rows that came from the neighbouring tiles onto the smallest of the three scales (exact: a power of two).  Same tiling on both sides.
     const int* ein;               // x holds planes: [tiles_m][C / 16] scale exponents (nullptr: x is fp32)
     int* eout;                    // y is written as planes: [tiles_m][N / 16] (nullptr: fp32)
+    // UNIT TABLE (round 6, optional): which bytes of x each lane stages is a function of the map's geometry alone -- [H2_NAU][256] words
+    // from h2_unit_table(): a lane's unit j = (byte offset from its tile's first row of pixels, a multiple of 16) | bit 0 the column exists,
+    // bit 1 / bit 2 the unit lies in the halo row above / below the tile's rows.  The kernel's prologue then loads seven words per lane where
+    // it otherwise runs three magic-number divisions and a validity chain per unit (~250 of its ~620 VALU instructions; H2_EXPERIMENT 64: -6 %
+    // of a batch-64 level).  nullptr, planes in, or a ragged last tile of several images: the computed path.  Same addresses, same bits.
+    const unsigned* utab;
 };
+static constexpr int H2_NAU = 7;
 
 // packed weights: [32-channel slice][C / 16][piece 2][tap 9][32][2 swizzled halves][8] fp16, then [slices * 32] fp32 inverse scales.  One
 // layout for both tile widths: a 64-channel tile stages two neighbouring slices side by side
@@ -71,6 +80,29 @@ inline bool h2_plan(int B, int H, int W, int C, int N, int NS, H2Problem* q) {
     q->g.ldy = q->g.ldr = N;
     q->g.NS = NS;
     q->g.NSL = (N + NS - 1) / NS;
+    q->utab = nullptr;
+    return true;
+}
+
+// the unit table of a map geometry (h2_plan's, for any batch and channel counts N): false = no table form (neither one segment per tile nor
+// whole images per tile); out: H2_NAU * 256 words
+inline bool h2_unit_table(int H, int W, int C, unsigned* out) {
+    H2Problem q;
+    if (!h2_plan(1, H, W, C, 32, 32, &q)) return false;      // (the tile geometry does not depend on the batch)
+    const WsProblem& p = q.g;
+    if (p.G != 1 && p.RGPI != 1) return false;
+    const int n_units = 4 * p.PP;
+    for (int j = 0; j < H2_NAU; ++j)
+        for (int tid = 0; tid < 256; ++tid) {
+            const int qi = std::min(j * 256 + tid, n_units - 1);
+            const int px = qi >> 2, qt = qi & 3;
+            const int g = px / p.SEGP, rem = px - g * p.SEGP;
+            const int rr = rem / p.PW, ww = rem - rr * p.PW;
+            const int col = ww - 1;
+            const long off = ((((long)g * p.H + rr - 1) * p.W + col) * p.C + qt * 4) * 4;      // (g = 0 unless a tile holds whole images)
+            if (off >= (1L << 31) || off < -(1L << 31)) return false;
+            out[j * 256 + tid] = ((unsigned)(int)off & ~15u) | (col >= 0 && col < p.W ? 1u : 0u) | (rr == 0 ? 2u : 0u) | (rr == p.RH + 1 ? 4u : 0u);
+        }
     return true;
 }
 
@@ -128,7 +160,7 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     constexpr int W2_BYTES = TN * WS_BYTES;                // the tile's chunk: TN slices side by side
     constexpr int NWI = W2_BYTES / 1024;                   // weight DMA instructions per chunk: 18 TN
     constexpr int NWS = (NWI + 3) / 4;                     // ... per wave
-    constexpr int NAU = 7;                                 // quarter-pixel units (4 channels = 16 B of fp32) per lane and chunk (1664 at most in all)
+    constexpr int NAU = H2_NAU;                            // quarter-pixel units (4 channels = 16 B of fp32) per lane and chunk (1664 at most in all)
     constexpr unsigned OOB = 0x80000000u;
     const WsProblem& p = q.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,7 +180,21 @@ __device__ __forceinline__ void igemm_f32h2_ws_tile(const H2Problem& q, const in
     unsigned a_voff[NAU], a_lds[NAU];
     [[maybe_unused]] unsigned a_cls = 0;
     const int n_units = 4 * p.PP;
-    {
+    // (block-uniform) the table form: one segment per tile, or whole images per tile and every one of this tile's images exists
+    const bool tab_ok = !(H2_EXPERIMENT & 128) && !PIN && q.utab != nullptr && (p.G == 1 || (p.RGPI == 1 && (tm + 1) * p.G <= p.RG));
+    if (tab_ok) {
+        const int k = tm * p.G - b_first * p.RGPI;           // the tile's row group inside its (first) image: 0 when a tile holds whole images
+        const unsigned kill = (k == 0 ? 2u : 0u) | (k == p.RGPI - 1 ? 4u : 0u);       // halo rows that lie outside the image
+        const int base = k * p.RH * p.W * p.C * 4;
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            const unsigned t = q.utab[j * 256 + tid];
+            const int qi = min(j * 256 + tid, n_units - 1);
+            const int px = qi >> 2, qt = qi & 3;
+            a_lds[j] = (unsigned)((qt >> 1) * HP + px * 16 + (qt & 1) * 8);
+            a_voff[j] = ((t & 1u) && !(t & kill)) ? (unsigned)((int)(t & ~15u) + base) : OOB;
+        }
+    } else {
         const int q0 = tm * p.G;
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {

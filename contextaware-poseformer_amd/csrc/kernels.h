@@ -144,6 +144,7 @@ struct GemmArgs {
     // scale exponents / out is written as planes and h2_eout receives the exponents.  nullptr = plain fp32 tensors
     const int* h2_ein;
     int* h2_eout;
+    const unsigned* h2_utab;     // ... and the map geometry's unit table (f32h2_unit_table; nullptr: the prologue computes its addresses)
 };
 
 // all res blocks of the lifter as one launch (lifter_chain.hip): per block LayerNorm weights, the two-fp16-piece packs of the four projections
@@ -254,6 +255,8 @@ hipError_t launch_pack_conv_f32x3(const float* w, const float* gamma, const floa
 long f32h2_pack_elems(int Cout, int Cin);
 hipError_t launch_gemm_f32h2_group(const GemmArgs* list, int n, hipStream_t s);
 bool gemm_f32h2_ok(const GemmArgs& a);
+static constexpr int F32H2_UNIT_TABLE_WORDS = 7 * 256;
+bool f32h2_unit_table(int H, int W, int Cin, unsigned* out);     // the tile's unit table of a map geometry (igemm_f32h2_ws_tile.h); false: none, the kernel computes
 bool f32h2_shape_ok(int B, int H, int W, int Cin, int Cout);     // (tensors of any size: the tile addresses from per-tile bases)
 const char* gemm_f32h2_kernel_name(const GemmArgs& a);
 hipError_t launch_pack_conv_f32h2(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <tuple>
 
 #include "engine.h"
 
@@ -1115,6 +1117,26 @@ bool Engine::build() {
         // the Winograd layout of this conv is dead weight when the tile covers every batch the Winograd kernels could be asked for
         if (lo <= wino_min_batch && hi >= cfg.max_batch) packs[op.pack].wino_skip = true;
     }
+    // unit tables of the two-fp16-piece conv tile: one per map geometry among the convs it can take (igemm_f32h2_ws_tile.h, UNIT TABLE)
+    utab_host.clear();
+    if (x3_h2 && use_x3) {
+        std::map<std::tuple<int, int, int>, long> seen;
+        for (Op& op : ops) {
+            if (op.kind != OP_GEMM || !op.wino || !packs[op.pack].x3 || op.x3_hi < op.x3_lo) continue;
+            const auto key = std::make_tuple(op.H, op.W, op.Cin);
+            auto it = seen.find(key);
+            if (it == seen.end()) {
+                std::vector<unsigned> t(F32H2_UNIT_TABLE_WORDS);
+                long at = -1;
+                if (f32h2_unit_table(op.H, op.W, op.Cin, t.data())) {
+                    at = (long)utab_host.size();
+                    utab_host.insert(utab_host.end(), t.begin(), t.end());
+                }
+                it = seen.emplace(key, at).first;
+            }
+            op.h2_utab = it->second;
+        }
+    }
     // pack arena layout
     size_t off = 0;
     for (Pack& pk : packs) {
@@ -1159,6 +1181,8 @@ bool Engine::build() {
     t_h2_plan();                            // the training step's weight table (train.cpp); its device image lives in the arena
     t_h2_tab_off = off;
     off += round64(t_h2_specs.size() * (sizeof(H2TrainW) / sizeof(float)) + 16);
+    utab_off = off;
+    off += round64(utab_host.size() + 16);
     pack_elems = off;
     return true;
 }

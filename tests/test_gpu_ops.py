@@ -1615,3 +1615,42 @@ def test_f32h2_planes_between_two_convs(B, H, W, C, spread):
     d_routes = ((y2_pl - y2_f32).double().cpu().permute(0, 3, 1, 2).abs() / (mass + slack * 2.0 ** 38 * 2.0 ** -23)).max().item()
     print(f"planes B={B} {H}x{W} C={C} spread 2^+-{spread}: conv2 vs fp64 on the decoded planes {(err / mass).max().item():.2e} of the sum of |terms|; vs the fp32-tensor route {d_routes:.2e}")
     assert d_routes <= 2e-6
+
+
+@pytest.mark.parametrize("backbone,B,H,W", [("hrnet_32", 9, 256, 256), ("hrnet_32", 6, 192, 160), ("cpn", 5, 256, 192)])
+def test_f32h2_unit_table_path_equals_the_computed_prologue(backbone, B, H, W):
+    """Inside the engine the two-fp16-piece conv tile reads which bytes a lane stages from a per-geometry UNIT TABLE (igemm_f32h2_ws_tile.h, round 6);
+    the stand-alone op (capf_op_conv_f32h2_group) has no table and computes the same addresses in its prologue.  Every such conv of a forward,
+    recomputed with the stand-alone op from the operands the ENGINE produced, must give the engine's output bit for bit -- odd batches put a
+    ragged last tile (which the table form leaves to the computed path) next to full ones; the maps cover one-segment-per-tile geometries
+    (64^2 ... 16^2, 48 x 40 ...) and whole-images-per-tile ones (8^2, 6 x 5)."""
+    from capf import lib as capf
+    from capf import synth
+    from test_gpu_fullsize import _model
+    model, sd = _model(backbone, "fp32", 91)
+    img, _, _ = synth.synth_inputs(B, H, W, seed=92, crop_range=(W, H))
+    img_d = img.cuda()
+    eng = model.engine_for(img_d)
+    names = [n for n, _, _ in eng.schema()]
+    table = eng.op_table(B)
+    todo = [i for i, (_, k, _) in enumerate(table) if k == "igemm_f32h2_group_ws"]
+    assert len(todo) >= (20 if B * H * W >= 9 * 256 * 256 else 4)      # (the tile takes a conv from 370 MFLOP)
+    descs = {i: eng.op_describe(i) for i in todo}
+    stream = torch.cuda.current_stream().cuda_stream
+    checked, geoms = 0, set()
+    for cp in sorted(set(descs[i].checkpoint for i in todo)):
+        eng.forward_prefix(img_d, cp, stream)
+        torch.cuda.synchronize()
+        for i in [i for i in todo if descs[i].checkpoint == cp]:
+            d = descs[i]
+            x = eng.op_tensor(i, 0, (B, d.H, d.W, d.Cin), d.in_dtype).clone()
+            res = eng.op_tensor(i, 4, (B, d.Ho, d.Wo, d.Cout), d.out_dtype).clone() if d.has_residual else None
+            got = eng.op_tensor(i, 5, (B, d.Ho, d.Wo, d.Cout), d.out_dtype).clone()
+            conv, bn = names[d.p_weight][:-len(".weight")], names[d.p_bn_weight][:-len(".weight")]
+            wp, bias = capf.pack_conv_f32h2(sd[conv + ".weight"].cuda(), tuple(sd[bn + s].cuda() for s in (".weight", ".bias", ".running_mean", ".running_var")))
+            want = capf.conv_nhwc_f32h2_group([(x, wp, bias, d.act, res, d.Cout)])[0]
+            assert torch.equal(got, want), table[i][0]
+            checked += 1
+            geoms.add((d.H, d.W, d.Cin))
+    print(f"{backbone} B={B} {H}x{W}: {checked} convs of the engine (unit tables) == the stand-alone op (computed prologue), bit for bit; geometries {sorted(geoms)}")
+    assert len(geoms) >= (3 if B * H * W >= 9 * 256 * 256 else 1)
