@@ -39,7 +39,10 @@ typedef __bf16 bn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __amdgpu_buffer_rsrc_t bn_rsrc_t;
 
 [[maybe_unused]] static constexpr int BN_W2_OFF = 0, BN_W3_OFF = 73728, BN_WD_OFF = 106496, BN_WK_OFF = 139264;
-static constexpr int BN_T2_BYTES = 8192, BN_EP_PITCH = 80, BN_EP_BYTES = 32 * BN_EP_PITCH;         // (work area: t1 12800 B | t2 8192 B + 4 x 2560 B of scratch)
+// (work area: t1 12800 B | t2 8192 B + 4 x 2560 B of scratch.  A scratch row = 64 B of bf16, its 16-byte column g kept at g ^ ((row >> 2) & 3): the
+// accumulator-layout writes -- 16 lanes = 16 rows, one column -- and the coalesced reads -- a lane group = four rows x four columns -- both touch 16
+// different bank quads; an 80-byte pitch served the writes and put three rows of a read group on the same banks)
+[[maybe_unused]] static constexpr int BN_T2_BYTES = 8192, BN_EP_PITCH = 64, BN_EP_BYTES = 2560;
 static constexpr int BN_WK_BYTES = BN_T2_BYTES + 4 * BN_EP_BYTES;
 static constexpr int BN_B_OFF = BN_WK_OFF + BN_WK_BYTES;
 static constexpr int BN_LDS_BYTES = BN_B_OFF + (64 + 64 + 256 + 256) * 4;
@@ -97,7 +100,11 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
     const int a_dh = s_a / 10 - 1, a_dw = s_a % 10 - 1;
     [[maybe_unused]] const bool a_interior = slot_ok && a_dh >= 0 && a_dh < 8 && a_dw >= 0 && a_dw < 8;
     const unsigned t1_wr = (unsigned)(s_a * 128 + fhalf * 8);
-    const int t1_sw = (s_a >> 1) & 7;
+    // quad swizzle of the t1 tile: halo pixel (r, c) keeps quad q at q ^ ((c >> 1) + 4 r) -- ds_read_b128 is served in lane groups {0-3, 12-15,
+    // 20-27} / {4-11, 16-19, 28-31}: with lanes = (row frow >> 3, column frow & 7) of a 4 x 8 pixel block a group is four 4-pixel runs of four
+    // different halo rows, and this choice gives its 16 lanes 16 different bank quads for every tap (the linear-pixel swizzle of the GEMM tiles put
+    // three of them on the same banks: SQ_LDS_BANK_CONFLICT 38 % of the LDS cycles, profiles/r06_pmc_bneck0.txt)
+    const int t1_sw = ((a_dw + 1) >> 1) + 4 * (a_dh + 1);
     // phases B / C: pixel block rb = wave >> 1 (tile rows 4 rb .. + 3), lane = (row frow >> 3, column frow & 7)
     const int rb = wave >> 1, wj = wave & 1;
     const int pr = 4 * rb + (frow >> 3), pc = frow & 7;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = in_img ? fmaxf(acc1[j][4 * g + e], 0.f) : 0.f;
                 const bn_u32x2 pk = bn_u32x2{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
-                if (slot_ok) *reinterpret_cast<bn_u32x2*>(wk + t1_wr + (((4 * j + g) ^ t1_sw) * 16)) = pk;
+                if (slot_ok) *reinterpret_cast<bn_u32x2*>(wk + t1_wr + ((((4 * j + g) ^ t1_sw) & 7) * 16)) = pk;
                 if (TAP && a_interior) *reinterpret_cast<bn_u32x2*>(a.t1 + (frame_px + (size_t)ha * a.W + wa) * 64 + 32 * j + 8 * g + 4 * fhalf) = pk;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
             bn_u32x4 afr[DEPTH + 1], bfr[DEPTH + 1];
             auto fetch = [&](int s) {             // step s = chunk s / 9 (16 channels), tap s % 9
                 const int cc = s / 9, tap = s - cc * 9;
-                const int p = (pr + tap / 3) * 10 + pc + tap % 3;
-                afr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(wk + p * 128 + (((2 * cc + fhalf) ^ ((p >> 1) & 7)) * 16));
+                const int hr = pr + tap / 3, hc = pc + tap % 3, p = hr * 10 + hc;
+                afr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(wk + p * 128 + ((((2 * cc + fhalf) ^ ((hc >> 1) + 4 * hr)) & 7) * 16));
                 bfr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(w2r + tap * (64 * 128) + (((2 * cc + fhalf) ^ fsw) * 16));
             };
 #pragma unroll
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
                 const f2_t s23 = f2_t{z[i][4 * g + 2], z[i][4 * g + 3]} + f2_t{__uint_as_float(r23 << 16), __uint_as_float(r23 & 0xFFFF0000u)};
                 const float y0 = fmaxf(s01[0], 0.f), y1 = fmaxf(s01[1], 0.f), y2 = fmaxf(s23[0], 0.f), y3 = fmaxf(s23[1], 0.f);
                 if (BN_EXP & 32) __builtin_amdgcn_raw_buffer_store_b64(bn_u32x2{pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)}, rs_y, (unsigned)(((th0 + pr) * a.W + tw0 + pc) * 256 + n0 + 8 * g + 4 * fhalf) * 2u, 0, 0);
-                else *reinterpret_cast<bn_u32x2*>(ep + frow * BN_EP_PITCH + (8 * g + 4 * fhalf) * 2) = bn_u32x2{pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
+                else *reinterpret_cast<bn_u32x2*>(ep + frow * BN_EP_PITCH + ((g ^ ((frow >> 2) & 3)) * 16) + fhalf * 8) = bn_u32x2{pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
                 if (TAP) *reinterpret_cast<bn_u32x2*>(a.r + (frame_px + (size_t)(th0 + pr) * a.W + tw0 + pc) * 256 + n0 + 8 * g + 4 * fhalf) = bn_u32x2{r01, r23};
             }
             if (BN_EXP & 32) continue;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = 16 * h + er;                      // pixel (4 rb + (row >> 3), row & 7) of the tile
-                const bn_u32x4 o = *reinterpret_cast<const bn_u32x4*>(ep + row * BN_EP_PITCH + ec * 2);
+                const bn_u32x4 o = *reinterpret_cast<const bn_u32x4*>(ep + row * BN_EP_PITCH + (((lane & 3) ^ ((row >> 2) & 3)) * 16));
                 const unsigned off = (unsigned)(((th0 + 4 * rb + (row >> 3)) * a.W + tw0 + (row & 7)) * 256 + n0 + ec) * 2u;
                 if (!(BN_EXP & 16) || (o[0] == 0x12345678u)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, off, 0, 0);
             }
