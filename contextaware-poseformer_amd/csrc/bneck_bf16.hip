@@ -57,8 +57,12 @@ struct Bneck0Args {
     int B, H, W, tiles_x, tiles_pf, ntiles;
 };
 
-template <bool TAP>
-__global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
+// DS = true: the first bottleneck (64 -> 64 -> 64 -> 256, projection shortcut, W1 in registers, Wd in LDS).
+// DS = false: an IDENTITY bottleneck (256 -> 64 -> 64 -> 256, y = relu(conv3 + x); networks/resnet.py:58-93 without downsample, pose_hrnet.py:98-136):
+// W1 (32 KiB, four [64][64] sub-chunks) takes Wd's place in LDS, conv1 reads 256-channel halo pixels (16 fragment loads per lane, a tile ahead), the
+// residual rows arrive in the coalesced layout (lane = 8 channels of a row) and cross the wave's scratch into the accumulator layout.
+template <bool TAP, bool DS>
+__global__ __launch_bounds__(256, 1) void bneck_bf16_kernel(Bneck0Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char bn_lds[];
     constexpr unsigned OOB = 0x80000000u;
@@ -79,19 +83,29 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
         const int n = i / 72, q = i - n * 72, tap = q >> 3, qq = q & 7;
         *reinterpret_cast<bn_u32x4*>(W2s + (tap * 64 + n) * 128 + ((qq ^ ((n >> 1) & 7)) * 16)) = *reinterpret_cast<const bn_u32x4*>(a.w2 + (size_t)n * 576 + q * 8);
     }
+    constexpr int CX = DS ? 64 : 256;         // channels of x
+    constexpr int NST = CX / 16;              // 16-deep k-steps of conv1
     for (int i = tid; i < 256 * 8; i += 256) {
         const int n = i >> 3, q = i & 7;
         *reinterpret_cast<bn_u32x4*>(W3s + n * 128 + ((q ^ ((n >> 1) & 7)) * 16)) = *reinterpret_cast<const bn_u32x4*>(a.w3 + (size_t)n * 64 + q * 8);
-        *reinterpret_cast<bn_u32x4*>(Wds + n * 128 + ((q ^ ((n >> 1) & 7)) * 16)) = *reinterpret_cast<const bn_u32x4*>(a.wd + (size_t)n * 64 + q * 8);
+        if (DS) *reinterpret_cast<bn_u32x4*>(Wds + n * 128 + ((q ^ ((n >> 1) & 7)) * 16)) = *reinterpret_cast<const bn_u32x4*>(a.wd + (size_t)n * 64 + q * 8);
+    }
+    if (!DS) {                                // W1 [64][256] -> sub-chunk k / 64: [64][64], in Wd's place
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int n = i >> 5, q = i & 31, sub = q >> 3, qq = q & 7;
+            *reinterpret_cast<bn_u32x4*>(Wds + (sub * 64 + n) * 128 + ((qq ^ ((n >> 1) & 7)) * 16)) = *reinterpret_cast<const bn_u32x4*>(a.w1 + (size_t)n * 256 + q * 8);
+        }
     }
     if (tid < 64) { B1s[tid] = a.b1[tid]; B2s[tid] = a.b2[tid]; }
     B3s[tid] = a.b3[tid];
-    BDs[tid] = a.bd[tid];
-    bn_u32x4 w1f[2][4];                       // conv1's weights as MFMA fragments: row 32 j + frow, k = 16 st + 8 fhalf .. + 7
+    if (DS) BDs[tid] = a.bd[tid];
+    [[maybe_unused]] bn_u32x4 w1f[2][4];      // DS: conv1's weights as MFMA fragments: row 32 j + frow, k = 16 st + 8 fhalf .. + 7
+    if constexpr (DS) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int st = 0; st < 4; ++st) w1f[j][st] = *reinterpret_cast<const bn_u32x4*>(a.w1 + (size_t)(32 * j + frow) * 64 + st * 16 + fhalf * 8);
+            for (int st = 0; st < 4; ++st) w1f[j][st] = *reinterpret_cast<const bn_u32x4*>(a.w1 + (size_t)(32 * j + frow) * 64 + st * 16 + fhalf * 8);
+    }
     __syncthreads();
 
     // ---- this lane's pixels (the same for every tile).  Phase A: halo slot s = 32 wave + frow -> (s / 10, s % 10) of the 10 x 10 halo tile
@@ -118,7 +132,8 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
     const int t_end = min((xcd + 1) * tpx, a.ntiles);
     int tile = xcd * tpx + ((int)blockIdx.x >> 3);
 
-    bn_u32x4 xa[4], xc[4];                     // conv1's pixel fragments (halo slot) and the downsample's (own pixel), k = 16 st + 8 fhalf .. + 7
+    bn_u32x4 xa[NST];                          // conv1's pixel fragments (halo slot), k = 16 st + 8 fhalf .. + 7
+    [[maybe_unused]] bn_u32x4 xc[4];           // DS: the downsample's (own pixel)
     auto tile_origin = [&](int t, int& b, int& th0, int& tw0) {
         b = t / a.tiles_pf;
         const int rem = t - b * a.tiles_pf;
@@ -130,10 +145,10 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
         tile_origin(t < t_end ? t : 0, b, th0, tw0);
         const int h = th0 + a_dh, w = tw0 + a_dw;
         const bool ok = !(BN_EXP & 8) && t < t_end && slot_ok && h >= 0 && h < a.H && w >= 0 && w < a.W;
-        const bn_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * a.H * a.W * 64), 0, 0x7FFFFF00u, 0x00020000);
-        const unsigned off = ok ? (unsigned)((h * a.W + w) * 64 + fhalf * 8) * 2u : OOB;
+        const bn_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)b * a.H * a.W * CX), 0, 0x7FFFFF00u, 0x00020000);
+        const unsigned off = ok ? (unsigned)((h * a.W + w) * CX + fhalf * 8) * 2u : OOB;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) xa[st] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + st * 32u : OOB, 0, 0);
+        for (int st = 0; st < NST; ++st) xa[st] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + st * 32u : OOB, 0, 0);
     };
     auto request_xc = [&](int t) {
         int b, th0, tw0;
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
     };
 
     request_xa(tile);
-    request_xc(tile);
+    if constexpr (DS) request_xc(tile);
     for (; tile < t_end; tile += per) {
         int b, th0, tw0;
         tile_origin(tile, b, th0, tw0);
@@ -160,11 +175,29 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc1[j][4 * g + e] = bv[e];
             }
+        if constexpr (DS) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, w1f[j][st]), __builtin_bit_cast(bn_bf16x8, xa[st]), acc1[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, w1f[j][st]), __builtin_bit_cast(bn_bf16x8, xa[st]), acc1[j], 0, 0, 0);
+        } else {                              // W1 fragments from LDS, the ring of the other loops: step s = (k-step s / 2, channel block s % 2)
+            constexpr int DEPTH = 3, NSTEP = 2 * NST;
+            bn_u32x4 wfr[DEPTH + 1];
+            auto fetch = [&](int s) {
+                const int st = s >> 1, j = s & 1;
+                wfr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(Wds + ((st >> 2) * 64 + 32 * j + frow) * 128 + (((2 * (st & 3) + fhalf) ^ fsw) * 16));
+            };
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) fetch(s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + DEPTH < NSTEP) fetch(s + DEPTH);
+                acc1[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, wfr[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, xa[s >> 1]), acc1[s & 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         const int ha = th0 + a_dh, wa = tw0 + a_dw;
         const bool in_img = slot_ok && ha >= 0 && ha < a.H && wa >= 0 && wa < a.W;
         request_xa(tile + per);               // (xa is dead: the next tile's halo pixels fly under phases B and C)
@@ -231,24 +264,42 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
         bn_u32x4 a2[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) a2[st] = *reinterpret_cast<const bn_u32x4*>(wk + px2 * 128 + (((2 * st + fhalf) ^ ((px2 >> 1) & 7)) * 16));
-        bn_f32x16 z[4], d[4];
+        const bn_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + frame_px * 256), 0, 0x7FFFFF00u, 0x00020000);
+        [[maybe_unused]] bn_u32x4 resq[4][2];  // identity block: the residual rows of this wave's four channel blocks, coalesced layout (rows 16 h + er, channels n0 + ec .. + 7)
+        if constexpr (!DS) {
+            const bn_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + frame_px * 256), 0, 0x7FFFFF00u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 16 * h + er;
+                    resq[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (unsigned)(((th0 + 4 * rb + (row >> 3)) * a.W + tw0 + (row & 7)) * 256 + 32 * (4 * wj + i) + ec) * 2u, 0, 0);
+                }
+        }
+        bn_f32x16 z[4];
+        [[maybe_unused]] bn_f32x16 d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const bn_f32x4 b3v = *reinterpret_cast<const bn_f32x4*>(B3s + 32 * (4 * wj + i) + 8 * g + 4 * fhalf);
-                const bn_f32x4 bdv = *reinterpret_cast<const bn_f32x4*>(BDs + 32 * (4 * wj + i) + 8 * g + 4 * fhalf);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { z[i][4 * g + e] = b3v[e]; d[i][4 * g + e] = bdv[e]; }
+                for (int e = 0; e < 4; ++e) z[i][4 * g + e] = b3v[e];
+                if constexpr (DS) {
+                    const bn_f32x4 bdv = *reinterpret_cast<const bn_f32x4*>(BDs + 32 * (4 * wj + i) + 8 * g + 4 * fhalf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[i][4 * g + e] = bdv[e];
+                }
             }
         if (!(BN_EXP & 2)) {
             constexpr int DEPTH = 3, NSTEP = 16;   // step s = (k-step s / 4, channel block s % 4): the same ring as conv2's
-            bn_u32x4 f3r[DEPTH + 1], fdr[DEPTH + 1];
+            bn_u32x4 f3r[DEPTH + 1];
+            [[maybe_unused]] bn_u32x4 fdr[DEPTH + 1];
             auto fetch = [&](int s) {
                 const int st = s >> 2, i = s & 3;
                 const unsigned wo = (unsigned)((32 * (4 * wj + i) + frow) * 128 + (((2 * st + fhalf) ^ fsw) * 16));
                 f3r[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(W3s + wo);
-                fdr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(Wds + wo);
+                if constexpr (DS) fdr[s & DEPTH] = *reinterpret_cast<const bn_u32x4*>(Wds + wo);
             };
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) fetch(s);
@@ -258,28 +309,48 @@ __global__ __launch_bounds__(256, 1) void bneck0_bf16_kernel(Bneck0Args a) {
                 const int st = s >> 2, i = s & 3;
                 if (s + DEPTH < NSTEP) fetch(s + DEPTH);
                 z[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, f3r[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, a2[st]), z[i], 0, 0, 0);
-                d[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, fdr[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, xc[st]), d[i], 0, 0, 0);
+                if constexpr (DS) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bn_bf16x8, fdr[s & DEPTH]), __builtin_bit_cast(bn_bf16x8, xc[st]), d[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        request_xc(tile + per);
-        // ---- y = relu(acc3 + bf16(acc_d)), one 32 x 32 block at a time through this wave's scratch
-        const bn_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + frame_px * 256), 0, 0x7FFFFF00u, 0x00020000);
+        if constexpr (DS) request_xc(tile + per);
+        // ---- y = relu(acc3 + shortcut), shortcut = bf16(acc_d) or the residual rows; one 32 x 32 block at a time through this wave's scratch
 #pragma unroll
         for (int i = 0; i < ((BN_EXP & 4) ? 1 : 4); ++i) {
             const int n0 = 32 * (4 * wj + i);
             __builtin_amdgcn_wave_barrier();
+            if constexpr (!DS) {                  // the residual rows cross the scratch: coalesced layout in, accumulator layout out
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 16 * h + er;
+                    *reinterpret_cast<bn_u32x4*>(ep + row * BN_EP_PITCH + (((lane & 3) ^ ((row >> 2) & 3)) * 16)) = resq[i][h];
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            bn_u32x2 rres[4];
+            if constexpr (!DS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rres[g] = *reinterpret_cast<const bn_u32x2*>(ep + frow * BN_EP_PITCH + ((g ^ ((frow >> 2) & 3)) * 16) + fhalf * 8);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // (every lane has its residual: the scratch takes y)
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const unsigned r01 = pack_bf16x2(d[i][4 * g], d[i][4 * g + 1]);
-                const unsigned r23 = pack_bf16x2(d[i][4 * g + 2], d[i][4 * g + 3]);
+                unsigned r01, r23;
+                if constexpr (DS) {
+                    r01 = pack_bf16x2(d[i][4 * g], d[i][4 * g + 1]);
+                    r23 = pack_bf16x2(d[i][4 * g + 2], d[i][4 * g + 3]);
+                } else {
+                    r01 = rres[g][0]; r23 = rres[g][1];
+                }
                 typedef float f2_t __attribute__((ext_vector_type(2)));
                 const f2_t s01 = f2_t{z[i][4 * g], z[i][4 * g + 1]} + f2_t{__uint_as_float(r01 << 16), __uint_as_float(r01 & 0xFFFF0000u)};
                 const f2_t s23 = f2_t{z[i][4 * g + 2], z[i][4 * g + 3]} + f2_t{__uint_as_float(r23 << 16), __uint_as_float(r23 & 0xFFFF0000u)};
                 const float y0 = fmaxf(s01[0], 0.f), y1 = fmaxf(s01[1], 0.f), y2 = fmaxf(s23[0], 0.f), y3 = fmaxf(s23[1], 0.f);
                 if (BN_EXP & 32) __builtin_amdgcn_raw_buffer_store_b64(bn_u32x2{pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)}, rs_y, (unsigned)(((th0 + pr) * a.W + tw0 + pc) * 256 + n0 + 8 * g + 4 * fhalf) * 2u, 0, 0);
                 else *reinterpret_cast<bn_u32x2*>(ep + frow * BN_EP_PITCH + ((g ^ ((frow >> 2) & 3)) * 16) + fhalf * 8) = bn_u32x2{pack_bf16x2(y0, y1), pack_bf16x2(y2, y3)};
-                if (TAP) *reinterpret_cast<bn_u32x2*>(a.r + (frame_px + (size_t)(th0 + pr) * a.W + tw0 + pc) * 256 + n0 + 8 * g + 4 * fhalf) = bn_u32x2{r01, r23};
+                if (TAP && DS) *reinterpret_cast<bn_u32x2*>(a.r + (frame_px + (size_t)(th0 + pr) * a.W + tw0 + pc) * 256 + n0 + 8 * g + 4 * fhalf) = bn_u32x2{r01, r23};
             }
             if (BN_EXP & 32) continue;
             __builtin_amdgcn_wave_barrier();
@@ -329,11 +400,50 @@ hipError_t launch_bneck0_bf16(const GemmArgs& c1, const GemmArgs& c2, const Gemm
     a.H = c1.H; a.W = c1.W; a.B = c1.M / (c1.H * c1.W);
     a.tiles_x = a.W / 8; a.tiles_pf = (a.H / 8) * a.tiles_x; a.ntiles = a.B * a.tiles_pf;
     static DynLdsAttr attr_p, attr_t;
-    const void* k = tap ? reinterpret_cast<const void*>(&bneck0_bf16_kernel<true>) : reinterpret_cast<const void*>(&bneck0_bf16_kernel<false>);
+    const void* k = tap ? reinterpret_cast<const void*>(&bneck_bf16_kernel<true, true>) : reinterpret_cast<const void*>(&bneck_bf16_kernel<false, true>);
     const hipError_t e = (tap ? attr_t : attr_p).ensure(k, BN_LDS_BYTES);
     if (e != hipSuccess) return e;
-    if (tap) hipLaunchKernelGGL(bneck0_bf16_kernel<true>, dim3(256), dim3(256), BN_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(bneck0_bf16_kernel<false>, dim3(256), dim3(256), BN_LDS_BYTES, s, a);
+    if (tap) hipLaunchKernelGGL((bneck_bf16_kernel<true, true>), dim3(256), dim3(256), BN_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((bneck_bf16_kernel<false, true>), dim3(256), dim3(256), BN_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+// an identity bottleneck: c1 (1x1 256 -> 64, ReLU), c2 (3x3 pad 1 on c1's output, ReLU), c3 (1x1 64 -> 256 on c2's output + c1's INPUT, ReLU)
+bool bneck1_bf16_ok(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& c3) {
+    auto base = [](const GemmArgs& g, int ks, int pad, int cin, int n) {
+        return g.conv && g.ks == ks && g.stride == 1 && g.pad == pad && g.Cin == cin && g.N == n && g.K == ks * ks * cin && g.Kpad == g.K && g.act == ACT_RELU &&
+               g.omap.G == 1 && g.omap.S1 == n && g.omap.off == 0 && !g.rscale && !g.ln_g && !g.up && g.splits <= 1 && g.Ho == g.H && g.Wo == g.W;
+    };
+    if (!base(c1, 1, 0, 256, 64) || !base(c2, 3, 1, 64, 64) || !base(c3, 1, 0, 64, 256)) return false;
+    if (c1.res || c2.res || c3.rmap.G != 1 || c3.rmap.S1 != 256 || c3.rmap.off != 0) return false;
+    if (c1.H != c2.H || c1.W != c2.W || c1.H != c3.H || c1.W != c3.W || c1.M != c2.M || c1.M != c3.M) return false;
+    if (c1.H % 8 != 0 || c1.W % 8 != 0 || c1.M % (c1.H * c1.W) != 0) return false;
+    if ((double)c1.H * c1.W * 256.0 * 2.0 >= 2.0e9) return false;
+    return true;
+}
+
+const char* bneck1_bf16_kernel_name() { return "bneck1_bf16<8x8>"; }
+
+hipError_t launch_bneck1_bf16(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& c3, bool tap, hipStream_t s) {
+    if (!bneck1_bf16_ok(c1, c2, c3)) return hipErrorInvalidValue;
+    for (const GemmArgs* g : {&c1, &c2, &c3})
+        if (!g->A || !g->Wp || !g->bias || !g->out) return hipErrorInvalidValue;
+    if (c2.A != c1.out || c3.A != c2.out || c3.res != c1.A || c3.out == c1.A) return hipErrorInvalidValue;
+    typedef const unsigned short* hp;
+    Bneck0Args a{};
+    a.x = reinterpret_cast<hp>(c1.A);
+    a.y = reinterpret_cast<unsigned short*>(c3.out);
+    a.w1 = reinterpret_cast<hp>(c1.Wp); a.w2 = reinterpret_cast<hp>(c2.Wp); a.w3 = reinterpret_cast<hp>(c3.Wp);
+    a.b1 = c1.bias; a.b2 = c2.bias; a.b3 = c3.bias;
+    a.t1 = reinterpret_cast<unsigned short*>(c1.out); a.t2 = reinterpret_cast<unsigned short*>(c2.out);
+    a.H = c1.H; a.W = c1.W; a.B = c1.M / (c1.H * c1.W);
+    a.tiles_x = a.W / 8; a.tiles_pf = (a.H / 8) * a.tiles_x; a.ntiles = a.B * a.tiles_pf;
+    static DynLdsAttr attr_p, attr_t;
+    const void* k = tap ? reinterpret_cast<const void*>(&bneck_bf16_kernel<true, false>) : reinterpret_cast<const void*>(&bneck_bf16_kernel<false, false>);
+    const hipError_t e = (tap ? attr_t : attr_p).ensure(k, BN_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (tap) hipLaunchKernelGGL((bneck_bf16_kernel<true, false>), dim3(256), dim3(256), BN_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((bneck_bf16_kernel<false, false>), dim3(256), dim3(256), BN_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 

@@ -221,13 +221,30 @@ int Engine::bneck0_member(int i, int batch) const {
     return -1;
 }
 
+bool Engine::bneck1_head(int i, int batch, int last_op) const {
+    if (!use_bneck || !bf16() || i < 0 || i + 2 >= last_op || i + 2 >= (int)ops.size()) return false;
+    const Op &c1 = ops[i], &c2 = ops[i + 1], &c3 = ops[i + 2];
+    for (const Op* o : {&c1, &c2, &c3})
+        if (o->kind != OP_GEMM || !o->conv || o->bf16 != 1 || o->region != c1.region || o->lane != c1.lane || o->in[1] >= 0) return false;
+    if (c1.bneck_c3 != i + 2 || c2.in[0] != c1.out || c3.in[0] != c2.out || c3.aux != c1.in[0] || c1.aux >= 0 || c2.aux >= 0) return false;
+    if (c1.rows_per_frame * batch < 65536) return false;
+    return bneck1_bf16_ok(gemm_args(c1, batch), gemm_args(c2, batch), gemm_args(c3, batch));
+}
+
+int Engine::bneck1_member(int i, int batch) const {
+    for (int f = i - 2; f <= i; ++f)
+        if (f >= 0 && bneck1_head(f, batch, (int)ops.size())) return f;
+    return -1;
+}
+
 bool Engine::pwchain_head(int i, int batch, int last_op) const {
     if (!use_pwchain || i < 0 || i + 1 >= last_op || i + 1 >= (int)ops.size()) return false;
     const Op& a = ops[i];
     const Op& b = ops[i + 1];
     if (a.kind != OP_GEMM || !a.conv || b.kind != OP_GEMM || !b.conv || a.bf16 != b.bf16 || a.bf16 > 1) return false;
     if (b.in[0] != a.out || b.region != a.region || b.lane != a.lane) return false;
-    if (a.bf16 && bneck0_member(i, batch) >= 0) return false;       // (the conv3 of a fused first bottleneck: that launch does not chain into the next block)
+    if (a.bf16 && (bneck0_member(i, batch) >= 0 || bneck1_member(i, batch) >= 0 || bneck1_head(i + 1, batch, last_op))) return false;   // (the conv3 of a
+                                                      // fused bottleneck does not chain into the next block; a fused next block runs its own conv1)
     return a.bf16 ? gemm_bf16_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch)) : gemm_f32_pwchain_ok(gemm_args(a, batch), gemm_args(b, batch));
 }
 
@@ -515,6 +532,14 @@ int Engine::run(hipStream_t s, int batch, int first_op, int last_op, hipEvent_t*
                 break;
             default: {
                 if (op.kind == OP_FUSE && op.i0 == 1 && !debug) break;
+                if (!ev && op.kind == OP_GEMM && bneck1_head(oi, batch, last_op)) {      // an identity bottleneck as one launch (bneck_bf16.hip, DS = false)
+                    const int tri[3] = {oi, oi + 1, oi + 2};
+                    if (log) HIP_TRY(log->mark(s, tri, 3));
+                    HIP_TRY(launch_bneck1_bf16(gemm_args(op, batch), gemm_args(ops[oi + 1], batch), gemm_args(ops[oi + 2], batch),
+                                               debug || last_op < (int)ops.size(), s));
+                    oi += 2;
+                    break;
+                }
                 // a 64 -> 256 pointwise conv directly followed by the 256 -> 64 one that reads it (layer1's conv3 -> next conv1): one launch
                 if (!ev && pwchain_head(oi, batch, last_op)) {
                     const int pair[2] = {oi, oi + 1};
@@ -1255,6 +1280,11 @@ int capf_op_info(const capf_handle* h, int index, int batch, const char** name, 
                                "layernorm", "deform_sample", "attention", "head", "", "", "embed", "ctx_attn", "res_chain", "mlp_chain"};
     if (name) *name = op.name.c_str();
     const int n_all = (int)h->e.ops.size();
+    if (kernel && op.kind == capf::OP_GEMM && h->e.bneck1_member(index, batch) >= 0) {
+        *kernel = capf::bneck1_bf16_kernel_name();                      // (the block's three convs ride in one launch)
+        if (flops) *flops = op.flops_per_frame * batch;
+        return CAPF_OK;
+    }
     if (kernel && op.kind == capf::OP_GEMM && h->e.bneck0_member(index, batch) >= 0) {
         *kernel = capf::bneck0_bf16_kernel_name();                      // (the block's four convs ride in one launch)
         if (flops) *flops = op.flops_per_frame * batch;

@@ -300,6 +300,9 @@ struct Engine {
     // ONE launch at this batch (bneck_bf16.hip); m = {conv1, conv2, downsample, conv3}
     bool bneck0_head(int i, int batch, int last_op, int m[4]) const;
     int bneck0_member(int i, int batch) const;       // op i rides in such a launch: index of its fork op, -1 otherwise
+    // ops i, i + 1, i + 2 are an identity bottleneck (conv1 256 -> 64, conv2 3x3, conv3 64 -> 256 + conv1's input) that runs as ONE launch at this batch
+    bool bneck1_head(int i, int batch, int last_op) const;
+    int bneck1_member(int i, int batch) const;       // op i rides in such a launch: index of its conv1, -1 otherwise
     bool use_upadd = true;         // plan_flags & CAPF_PLAN_NO_UPADD clears it (CPN bf16: lateral conv + upsampled add in one launch)
     int run_region_grouped(hipStream_t s, int batch, int region, LaunchLog* log, unsigned lane_mask = ~0u);
     GemmArgs gemm_args(const Op& op, int batch, bool planes = true) const;

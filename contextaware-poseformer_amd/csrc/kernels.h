@@ -181,6 +181,10 @@ const char* gemm_f32_pwchain_kernel_name();
 bool bneck0_bf16_ok(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& ds, const GemmArgs& c3);
 hipError_t launch_bneck0_bf16(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& ds, const GemmArgs& c3, bool tap, hipStream_t s);
 const char* bneck0_bf16_kernel_name();
+// ... and an identity bottleneck (256 -> 64 -> 64 -> 256, y = relu(conv3 + x)) the same way
+bool bneck1_bf16_ok(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& c3);
+hipError_t launch_bneck1_bf16(const GemmArgs& c1, const GemmArgs& c2, const GemmArgs& c3, bool tap, hipStream_t s);
+const char* bneck1_bf16_kernel_name();
 // the bf16 twin (igemm_bf16_pwchain.hip): CPN's / HRNet's layer1 pairs under compute_dtype = bf16
 bool gemm_bf16_pwchain_ok(const GemmArgs& a, const GemmArgs& b);
 hipError_t launch_gemm_bf16_pwchain(const GemmArgs& a, const GemmArgs& b, hipStream_t s);

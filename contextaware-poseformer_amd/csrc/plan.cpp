@@ -230,6 +230,20 @@ static void bneck0_mark(Engine& e, int fork) {
     for (int k : {c1, c2, ds}) e.ops[k].bneck_c3 = c3;
 }
 
+// ... and an identity bottleneck (conv1 at `c1`, conv2, conv3 + x): x, conv1's and conv2's outputs and y alive from conv1 to conv3
+static void bneck1_mark(Engine& e, int c1) {
+    if (!e.use_bneck || !e.bf16() || c1 + 2 >= (int)e.ops.size()) return;
+    const Op &o1 = e.ops[c1], &o2 = e.ops[c1 + 1], &o3 = e.ops[c1 + 2];
+    if (o1.kind != OP_GEMM || o2.kind != OP_GEMM || o3.kind != OP_GEMM || o1.Cin != 256 || o1.N != 64 || o2.ks != 3 || o2.stride != 1 || o3.N != 256 || o3.aux != o1.in[0]) return;
+    for (int b : {o1.in[0], o1.out, o2.out, o3.out}) {
+        if (b < 0) continue;
+        e.bufs[b].def_op = std::min(e.bufs[b].def_op, c1);
+        e.bufs[b].last_op = std::max(e.bufs[b].last_op, c1 + 2);
+    }
+    e.ops[c1].bneck_c3 = c1 + 2;
+    e.ops[c1 + 1].bneck_c3 = c1 + 2;
+}
+
 static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, int planes, bool down) {  // :98-136
     const int fork_at = (int)e.ops.size();
     if (down) e.fork(2);             // the projection shortcut only reads x: independent of conv1 / conv2
@@ -243,6 +257,7 @@ static Tensor hr_bottleneck(Engine& e, const std::string& p, const Tensor& x, in
     }
     Tensor out = e.conv_bn(p + ".conv3", p + ".bn3", y, planes * 4, 1, 1, ACT_RELU, &r);
     if (down) bneck0_mark(e, fork_at);
+    else bneck1_mark(e, fork_at);
     return out;
 }
 
@@ -396,6 +411,7 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
             }
             x = conv_bn(p + ".conv3", p + ".bn3", y, planes[li] * 4, 1, 1, ACT_RELU, &r);
             if (k == 0 && st == 1) bneck0_mark(*this, fork_at);
+            if (k > 0) bneck1_mark(*this, fork_at);
         }
         c[li] = x;
     }

@@ -105,12 +105,12 @@ def test_cfg3_layerwise_hrnet32_fp32_batch512():
 
 def test_cfg2_layerwise_hrnet48_bf16_batch256():
     k = layerwise("hrnet_48", "bf16", 256, 256, 256, [0, 85, 170, 255])
-    assert "bneck0_bf16<8x8>" in k                    # layer1.0 as one kernel: its four convs checked from the operands the kernel itself stored (TAP variant)
+    assert "bneck0_bf16<8x8>" in k and "bneck1_bf16<8x8>" in k          # layer1.0 / layer1.1-3 as one kernel each: its four convs checked from the operands the kernel itself stored (TAP variant)
 
 
 def test_cfg4_layerwise_cpn_bf16_batch128():
     k = layerwise("cpn", "bf16", 128, 384, 288, [0, 42, 85, 127])
-    assert "bneck0_bf16<8x8>" in k                    # (round 6: the first bottleneck fused, networks/resnet.py:58-93)
+    assert "bneck0_bf16<8x8>" in k and "bneck1_bf16<8x8>" in k          # (round 6: every layer1 bottleneck fused, networks/resnet.py:58-93)
     assert layerwise.fused_upsample_adds == 3          # globalNet's three lateral convs carry the upsampled path in their epilogue (round 6)
 
 
