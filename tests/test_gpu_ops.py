@@ -413,10 +413,12 @@ def test_bf16_pointwise_chain_agrees_with_its_two_launches(backbone, B, H, W):
     """The bf16 twin (igemm_bf16_pwchain: y rounded once in registers, the second conv's 16-product groups summed in a permuted slot
     order) against CAPF_PLAN_NO_PWCHAIN.  The first conv is bit-identical; the second differs by fp32 summation order inside an MFMA,
     i.e. by at most one bf16 rounding of its output -- which a deep bf16 network amplifies to its rounding-noise floor (bf16_report.py),
-    so the context maps are held to that floor (the layer-wise test checks the chained ops themselves one by one)."""
+    so the context maps are held to that floor (the layer-wise test checks the chained ops themselves one by one).
+    Since round 6 every layer1 bottleneck of a bf16 plan is one fused launch (bneck_bf16.hip), so the chained pairs exist only under
+    CAPF_PLAN_NO_BNECK: both plans of this test carry that flag."""
     import copy, contextlib, io
     from capf import synth
-    from capf.lib import PLAN_NO_PWCHAIN
+    from capf.lib import PLAN_NO_BNECK, PLAN_NO_PWCHAIN
     from mvn.models.conpose import CA_PF
     from mvn.utils.cfg import backbone_preset, config
     cfg = backbone_preset(copy.deepcopy(config), backbone)
@@ -424,7 +426,7 @@ def test_bf16_pointwise_chain_agrees_with_its_two_launches(backbone, B, H, W):
     img, k2d, kc = synth.synth_inputs(B, H, W, seed=21, crop_range=(W, H))
     img, k2d, kc = img.cuda(), k2d.cuda(), kc.cuda()
     res = []
-    for flags in (0, PLAN_NO_PWCHAIN):
+    for flags in (PLAN_NO_BNECK, PLAN_NO_BNECK | PLAN_NO_PWCHAIN):
         with contextlib.redirect_stdout(io.StringIO()):
             m = CA_PF(cfg, compute_dtype="bf16", plan_flags=flags).eval()
         synth.load_synthetic(m, seed=3, bn_mode="random")
