@@ -270,6 +270,20 @@ def compare(name, rec, path):
         a, b = np.asarray(rec[k]), old[k]
         if a.shape != b.shape or a.dtype.kind != b.dtype.kind:
             bad.append(f"{k}: shape/dtype {a.shape}{a.dtype} vs {b.shape}{b.dtype}")
+        elif ":ac:" in k:
+            # autocast("cpu") hands convolutions / linears to oneDNN's bf16 kernels, and WHICH kernel depends on the host's ISA (avx512_bf16 /
+            # AMX boxes multiply in bf16 natively, others convert and run fp32 FMAs with other blockings): the autocast distances are
+            # reproducible per host, not across hosts (seen: 1.0e-2 vs 1.15e-2 m mean joint distance on W48 between two survey containers).
+            # They stay a statement about magnitude: scalar distances within 40 % of the committed ones, the joint set within the sum of the
+            # two evaluations' own distances from fp32.  The ":opr:" keys are fp32 arithmetic on rounded operands and stay on the exact rule.
+            if a.ndim == 0:
+                if not (0.6 * float(b) <= float(a) <= 1.4 * float(b)):
+                    bad.append(f"{k}: regenerated {float(a):.3e} vs committed {float(b):.3e} (autocast, 40 % band)")
+            else:
+                lim = 2.0 * float(old[k.rsplit(":", 1)[0] + ":joints_maxabs"])
+                d = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
+                if d > lim:
+                    bad.append(f"{k}: max |regenerated - committed| = {d:.3e} > {lim:.3e} (autocast)")
         elif a.dtype.kind in "fc":
             d = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
             # bitwise on this container's torch build; 1e-6 relative slack for a different CPU's oneDNN dispatch
