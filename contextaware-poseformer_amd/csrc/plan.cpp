@@ -471,6 +471,10 @@ void Engine::build_cpn(Tensor img, Tensor feats[4]) {
             Tensor r = conv_bn(p + ".downsample.0", p + ".downsample.1", y, 256, 1, 1, ACT_NONE, nullptr);
             y = conv_bn(p + ".conv3", p + ".bn3", t, 256, 1, 1, ACT_RELU, &r);
         }
+        // cascade 3 is nn.Upsample alone (refineNet.py:58-64 with num = 0) on a map that already has output_shape: under align_corners the
+        // source index of output pixel i is i * (H - 1) / (H - 1) = i with weight 1 (ATen: lambda 0 -> 1 * x[i] + 0 * x[i + 1]), the identity for
+        // finite values -- the level IS the lateral map; no launch, no second copy of it (201 MB written + read back at batch 128)
+        if (y.H == oh && y.W == ow) { feats[i] = y; continue; }
         feats[i] = pool_or_resize(*this, OP_RESIZE, F + ".cascade." + std::to_string(i) + ".resize", y, oh, ow);
     }
     join();
