@@ -136,6 +136,9 @@ struct TrainLayout {
     size_t dX, gA, gB, gC, cat, dU[4], tA, tB, wT, slabs, red;
     size_t h2w, h2max;                       // the step's weights as two-fp16-piece packs (W and W^T: Engine::t_h2_specs), and their maxima scratch
     size_t slabs_elems = 0, red_elems = 0;   // capacities of the two scratch areas above (what the weight-gradient slicing may use)
+    size_t red_cap = 0;                      // ... and one column reduction's partial sums of red_elems (the same arrangement: t_col_flush)
+    size_t slab_cap = 0;                     // what ONE weight gradient's slabs may take of slabs_elems (the slab area holds several layers' slabs
+                                             // until Engine::t_slab_flush sums them in one launch)
     size_t total;
 };
 
@@ -275,6 +278,19 @@ struct Engine {
     size_t t_h2_elems = 0, t_h2_max_elems = 0;
     int t_h2_tiles = 0;
     bool t_h2_on_device = false;
+    // weight-gradient slabs waiting for their sum (backward): the slab area is a bump allocator, the sums run as ONE launch when it is
+    // full, when SLAB_BATCH_MAX jobs wait, and at the end of backward -- 64 slab_sum launches per step -> a handful
+    SlabBatch t_slab_jobs{};
+    size_t t_slab_cur = 0;
+    float* t_slab_take(hipStream_t s, float* area, size_t cap, size_t elems, int* rc);
+    int t_slab_defer(hipStream_t s, const float* slabs, int nslab, long n, float* dst);
+    int t_slab_flush(hipStream_t s);
+    // the same for the second stages of the backward's column reductions (bias / LayerNorm gradients): 32 launches per step -> one or two
+    ColFinalBatch t_col_jobs{};
+    size_t t_col_cur = 0;
+    int t_colreduce(hipStream_t s, const TrainLayout& L, float* tw, const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode,
+                    int rows, int C, float* dst, long dst_stride, float* dst2, size_t cap_elems);
+    int t_col_flush(hipStream_t s);
     float* t_h2_base = nullptr;          // this step's packs (set by t_h2_prepare; nullptr: the step runs on the fp32 matrix pipe)
     void t_h2_plan();
     int t_h2_prepare(hipStream_t s, const TrainLayout& L, float* tw, int B);

@@ -405,10 +405,36 @@ hipError_t launch_layernorm_train(const float* in, RowMap imap, const float* add
 hipError_t launch_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dX,
                                 RowMap omap, float* second, RowMap smap, int rows, int GRP, int C, hipStream_t s);
 // dst[c*dst_stride] (+)= sum_r A[amap(r)+c] * B(r,c); bmode 0 none, 1 B[bmap(r)+c], 2 B[bmap(r)]; scratch >= 64*C floats
+// `defer` (optional): the second stage is NOT launched but appended to the batch (launch_colreduce_final_batch runs every waiting one in a
+// single launch; the scratch must stay untouched until then)
+static constexpr int COL_BATCH_MAX = 40;
+struct ColFinalBatch {
+    const float* partial[COL_BATCH_MAX];
+    const float* partial2[COL_BATCH_MAX];
+    float* dst[COL_BATCH_MAX];
+    float* dst2[COL_BATCH_MAX];
+    int chunks[COL_BATCH_MAX], C[COL_BATCH_MAX], dst_stride[COL_BATCH_MAX];
+    int blk_end[COL_BATCH_MAX];       // running block count (64 columns per block)
+    int count;
+};
+int colreduce_chunks(int rows, int C, int nout, size_t scratch_elems, int* rows_per_chunk = nullptr);   // row chunks of the first stage: scratch = nout * chunks * C floats
 hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
                             float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s,
-                            float* dst2 = nullptr, size_t scratch_elems = 0);   // dst2: plain column sums of A as well
+                            float* dst2 = nullptr, size_t scratch_elems = 0, ColFinalBatch* defer = nullptr);   // dst2: plain column sums of A as well
+hipError_t launch_colreduce_final_batch(const ColFinalBatch& b, hipStream_t s);
 hipError_t launch_slab_sum(const float* slabs, int nslab, long n, float* dst, hipStream_t s);
+// the same sums for up to SLAB_BATCH_MAX weight gradients in ONE launch (the backward defers them: Engine::t_slab_flush).  Every job: n % 4 == 0,
+// 16-byte aligned slabs; slabs summed in order k = 0, 1, ... per element exactly as slab_sum_kernel does (same bits)
+static constexpr int SLAB_BATCH_MAX = 48;
+struct SlabBatch {
+    const float* src[SLAB_BATCH_MAX];
+    float* dst[SLAB_BATCH_MAX];
+    int n[SLAB_BATCH_MAX];            // elements per slab
+    int nslab[SLAB_BATCH_MAX];
+    int blk_end[SLAB_BATCH_MAX];      // running block count: job j owns blocks [blk_end[j - 1], blk_end[j]), 1024 elements each
+    int count;
+};
+hipError_t launch_slab_sum_batch(const SlabBatch& b, hipStream_t s);
 // dW[n][k] = sum_m dY[m][n] X[m][k] (+ db[n] = sum_m dY[m][n] behind it) from row-major operands, no transposes (train_kernels.hip);
 // N % 4 == 0, K % 4 == 0; slice s of `splits` row ranges writes N * K (+ N) floats at out + s * slab.  h2: both operands as two fp16
 // pieces split in the kernel, three piece products on the 16-bit matrix pipe, 128 x 128 tiles (N % 128 == 0, K % 128 == 0)

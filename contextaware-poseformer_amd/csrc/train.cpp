@@ -70,9 +70,11 @@ void Engine::train_layout(int B, TrainLayout& L) const {
     L.tA = take(maxNR, (size_t)3 * D * 32);
     L.tB = take(maxNR, (size_t)3 * D * 32);
     L.wT = take(0, (size_t)3 * D * D + 64 * 2 * D);            // largest transposed weight [K][Npad]
-    L.slabs_elems = (size_t)16 * (3 * D * D + 3 * D);          // split-K slabs of the largest weight gradient (+ its bias gradient)
+    L.slab_cap = (size_t)16 * (3 * D * D + 3 * D);             // split-K slabs of the largest weight gradient (+ its bias gradient) ...
+    L.slabs_elems = 8 * L.slab_cap;                            // ... and room for several layers' slabs: their sums are deferred (t_slab_flush)
     L.slabs = take(0, L.slabs_elems);
-    L.red_elems = (size_t)64 * 3 * D;
+    L.red_cap = (size_t)64 * 3 * D;                            // one column reduction's partial sums ...
+    L.red_elems = 40 * L.red_cap;                              // ... times the reductions whose second stages wait for one launch (t_col_flush)
     L.red = take(0, L.red_elems);
     L.h2w = take(0, t_h2_elems);
     L.h2max = take(0, t_h2_max_elems);
@@ -195,37 +197,105 @@ int Engine::t_gemm(hipStream_t s, const float* A, RowMap amap, int M, int N, int
     return CAPF_OK;
 }
 
+// ---- deferred slab sums ---------------------------------------------------------------------------------------------------------------
+// a weight gradient's slabs: `elems` floats of the slab area (64-float granules); a full area sums what waits first
+float* Engine::t_slab_take(hipStream_t s, float* area, size_t cap, size_t elems, int* rc) {
+    const size_t need = (elems + 63) & ~(size_t)63;
+    *rc = CAPF_OK;
+    if (need > cap) { err = "capf_backward: a weight gradient's slabs exceed the slab area"; *rc = CAPF_ERR_STATE; return nullptr; }
+    if (t_slab_cur + need > cap) {
+        if ((*rc = t_slab_flush(s))) return nullptr;
+    }
+    float* p = area + t_slab_cur;
+    t_slab_cur += need;
+    return p;
+}
+
+int Engine::t_slab_defer(hipStream_t s, const float* slabs, int nslab, long n, float* dst) {
+    if ((n & 3) || n >= (1L << 31) - 4096) {                 // (no 16-byte form: summed at once, the area stays taken until the next flush)
+        HIP_TRY(launch_slab_sum(slabs, nslab, n, dst, s));
+        return CAPF_OK;
+    }
+    SlabBatch& b = t_slab_jobs;
+    const int j = b.count;
+    b.src[j] = slabs; b.dst[j] = dst; b.n[j] = (int)n; b.nslab[j] = nslab;
+    b.blk_end[j] = (j ? b.blk_end[j - 1] : 0) + (int)((n + 1023) / 1024);
+    b.count = j + 1;
+    if (b.count == SLAB_BATCH_MAX) return t_slab_flush(s);
+    return CAPF_OK;
+}
+
+// a column reduction of the backward: first stage now (into its own piece of the red area), second stage with the others' in t_col_flush.
+// cap_elems: what the first stage may use (0: the kernel's 64-chunk default) -- it decides the chunking, i.e. the summation order
+int Engine::t_colreduce(hipStream_t s, const TrainLayout& L, float* tw, const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode,
+                        int rows, int C, float* dst, long dst_stride, float* dst2, size_t cap_elems) {
+    const int nout = dst2 ? 2 : 1;
+    const size_t need = (((size_t)nout * colreduce_chunks(rows, C, nout, cap_elems) * C) + 63) & ~(size_t)63;
+    if (need > L.red_elems) { err = "capf_backward: a column reduction's partial sums exceed the red area"; return CAPF_ERR_STATE; }
+    if (t_col_cur + need > L.red_elems || t_col_jobs.count == COL_BATCH_MAX) {
+        if (int rc = t_col_flush(s)) return rc;
+    }
+    float* scratch = tw + L.red + t_col_cur;
+    t_col_cur += need;
+    HIP_TRY(launch_colreduce(A, amap, Bm, bmap, bmode, rows, C, dst, dst_stride, 0, scratch, s, dst2, cap_elems, &t_col_jobs));
+    return CAPF_OK;
+}
+
+int Engine::t_col_flush(hipStream_t s) {
+    if (t_col_jobs.count > 0) HIP_TRY(launch_colreduce_final_batch(t_col_jobs, s));
+    t_col_jobs.count = 0;
+    t_col_cur = 0;
+    return CAPF_OK;
+}
+
+int Engine::t_slab_flush(hipStream_t s) {
+    if (t_slab_jobs.count > 0) HIP_TRY(launch_slab_sum_batch(t_slab_jobs, s));
+    t_slab_jobs.count = 0;
+    t_slab_cur = 0;                                          // (stream order: the next layer's slabs are written behind the sums that read these)
+    return CAPF_OK;
+}
+
 // gradients of y = x W^T + b :  gW [N][K], gb [N], and (optionally) dX (+)= dY W
 int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const float* dY, RowMap dymap, int rows, int N,
                          int K, const float* Xin, RowMap xmap, const float* W, float* dX, RowMap dxmap, bool acc_dx,
                          float* gW, float* gb) {
-    float* red = tw + L.red;
-    const size_t red_elems = L.red_elems;
     // dW (and db, when it sits right behind dW in the flat gradient -- every nn.Linear's weight / bias pair does) straight from the
     // row-major dY and X: no transposes, no column-reduction launches (wgrad_tn_kernel; multiples of four and plain row pitches only)
     // (its operand tiles are 16-byte LDS-DMA loads: row pitches and offsets must be multiples of four elements)
     if (gW && N % 4 == 0 && K % 4 == 0 && dymap.G == 1 && xmap.G == 1 && ((dymap.S1 | dymap.off | xmap.S1 | xmap.off) & 3) == 0 &&
         (double)rows * (double)std::max(dymap.S1, xmap.S1) * 4.0 < 2.0e9) {
         const bool bias_here = gb && gb == gW + (long)N * K;
-        if (gb && !bias_here) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
+        if (gb && !bias_here) {
+            if (int rc = t_colreduce(s, L, tw, dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, nullptr, L.red_cap)) return rc;
+        }
         const bool h2 = t_h2_base && N % 128 == 0 && K % 128 == 0;      // (this step runs its products on the 16-bit matrix pipe)
         const int tiles = h2 ? (N / 128) * (K / 128) : ((N + 63) / 64) * ((K + 63) / 64), chunks = (rows + 31) / 32;
         const long slab = (long)N * K + (bias_here ? N : 0);
         // row slices: ~2048 blocks per launch (four rounds of two per CU, so that a tile count that is no multiple of 256 costs a few per
         // cent, not a half-empty round), at least 16 chunks each, as many as the slab buffer holds -- the small layers (128 x 128:
         // four tiles, 43520 rows) ran 64 blocks of 85 chunks
-        const long slab_cap = (long)L.slabs_elems;                  // (the layout's own number: train_layout)
+        const long slab_cap = (long)L.slab_cap;                     // (the layout's own number: train_layout)
         int splits = std::max(1, ((h2 ? 512 : 2048) + tiles - 1) / tiles);       // (the two-piece kernel: one round of two blocks per CU -- its slabs are 128 x 128)
         splits = std::min(splits, std::max(1, chunks / 16));
         splits = (int)std::min<long>(splits, std::max<long>(1, slab_cap / slab));
         const int cps = (chunks + splits - 1) / splits, slices = (chunks + cps - 1) / cps;
-        HIP_TRY(launch_wgrad_tn(dY + dymap.off, dymap.S1, Xin + xmap.off, xmap.S1, rows, N, K, slices > 1 ? tw + L.slabs : gW, slab, splits,
+        float* slabs = nullptr;
+        if (slices > 1) {
+            int rc = CAPF_OK;
+            slabs = t_slab_take(s, tw + L.slabs, L.slabs_elems, (size_t)slices * slab, &rc);
+            if (rc) return rc;
+        }
+        HIP_TRY(launch_wgrad_tn(dY + dymap.off, dymap.S1, Xin + xmap.off, xmap.S1, rows, N, K, slices > 1 ? slabs : gW, slab, splits,
                                 bias_here ? 1 : 0, s, h2));
-        if (slices > 1) HIP_TRY(launch_slab_sum(tw + L.slabs, slices, slab, gW, s));
+        if (slices > 1) {
+            if (int rc = t_slab_defer(s, slabs, slices, slab, gW)) return rc;      // (summed with the other layers' slabs: t_slab_flush)
+        }
         gW = nullptr;
         gb = nullptr;
     }
-    if (gb) HIP_TRY(launch_colreduce(dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, 0, red, s, nullptr, red_elems));
+    if (gb) {
+        if (int rc = t_colreduce(s, L, tw, dY, dymap, nullptr, row_ld(0), 0, rows, N, gb, 1, nullptr, L.red_cap)) return rc;
+    }
     if (gW) {
         const int Mp = r32(rows);
         float* tA = tw + L.tA;
@@ -240,14 +310,18 @@ int Engine::t_linear_bwd(hipStream_t s, const TrainLayout& L, float* tw, const f
         int splits = std::min(16, std::max(1, 512 / std::max(1, tiles)));
         splits = std::min(splits, chunks);
         if (splits > 1) {
-            a.out = tw + L.slabs;
+            int rc = CAPF_OK;
+            a.out = t_slab_take(s, tw + L.slabs, L.slabs_elems, (size_t)splits * N * K, &rc);
+            if (rc) return rc;
             a.splits = splits;
             a.cps = (chunks + splits - 1) / splits;
             a.splits = (chunks + a.cps - 1) / a.cps;
             a.split_stride = (long)N * K;
         }
         HIP_TRY(launch_gemm_f32(a, s));
-        if (a.splits > 1) HIP_TRY(launch_slab_sum(tw + L.slabs, a.splits, (long)N * K, gW, s));
+        if (a.splits > 1) {
+            if (int rc = t_slab_defer(s, a.out, a.splits, (long)N * K, gW)) return rc;
+        }
     }
     if (dX) {
         const int Np = r32(N);
@@ -395,11 +469,13 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
     TrainLayout L;
     train_layout(B, L);
     float* tw = ws + ws_elems_per_frame * (size_t)B;
+    t_slab_jobs.count = 0;                                   // (an earlier backward that failed half-way may have left jobs behind)
+    t_slab_cur = 0;
+    t_col_jobs.count = 0;
+    t_col_cur = 0;
     float* dX = tw + L.dX;
     float* gA = tw + L.gA;
     float* gB = tw + L.gB;
-    float* red = tw + L.red;
-    const size_t red_elems = L.red_elems;
     auto G = [&](const std::string& n) { return flat + grad_off[param_index.at(n)]; };
     const float* m_ctx = masks;
     const float* m_res = masks ? masks + (size_t)2 * Lv * B : nullptr;
@@ -410,12 +486,11 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
     // ---- head: out = LN(X) W^T + b
     {
         const int R = B * J;
-        HIP_TRY(launch_colreduce(dOut, row_ld(3), nullptr, row_ld(0), 0, R, 3, G(V + ".head.1.bias"), 1, 0, red, s));
+        if (int rc2 = t_colreduce(s, L, tw, dOut, row_ld(3), nullptr, row_ld(0), 0, R, 3, G(V + ".head.1.bias"), 1, nullptr, 0)) return rc2;
         for (int o = 0; o < 3; ++o)
-            HIP_TRY(launch_colreduce(tw + L.yh, row_ld(D), dOut + o, row_ld(3), 2, R, D, G(V + ".head.1.weight") + (size_t)o * D, 1, 0, red, s));
+            if (int rc2 = t_colreduce(s, L, tw, tw + L.yh, row_ld(D), dOut + o, row_ld(3), 2, R, D, G(V + ".head.1.weight") + (size_t)o * D, 1, nullptr, 0)) return rc2;
         HIP_TRY(launch_head_dgrad(dOut, P(*this, V + ".head.1.weight"), gA, R, D, 3, s));
-        HIP_TRY(launch_colreduce(gA, row_ld(D), tw + L.xhh, row_ld(D), 1, R, D, G(V + ".head.0.weight"), 1, 0, red, s,
-                                 G(V + ".head.0.bias"), red_elems));      // d(gamma) and d(beta) in one pass
+        if (int rc2 = t_colreduce(s, L, tw, gA, row_ld(D), tw + L.xhh, row_ld(D), 1, R, D, G(V + ".head.0.weight"), 1, G(V + ".head.0.bias"), L.red_cap)) return rc2;      // d(gamma) and d(beta) in one pass
         HIP_TRY(launch_layernorm_bwd(gA, tw + L.xhh, tw + L.rsh, P(*this, V + ".head.0.weight"), dX, row_ld(D), nullptr, row_ld(0), R, 1, D, s));
     }
 
@@ -437,8 +512,7 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
         rc = t_linear_bwd(s, L, tw, gA, row_ld(2 * dim), R, 2 * dim, dim, tw + y2, row_ld(dim), P(*this, p + ".mlp.fc1.weight"), gB,
                           row_ld(dim), false, G(p + ".mlp.fc1.weight"), G(p + ".mlp.fc1.bias"));
         if (rc) return rc;
-        HIP_TRY(launch_colreduce(gB, row_ld(dim), tw + xh2, row_ld(dim), 1, R, dim, G(p + ".norm2.weight"), 1, 0, red, s,
-                                 G(p + ".norm2.bias"), red_elems));      // d(gamma) and d(beta) in one pass
+        if (int rc2 = t_colreduce(s, L, tw, gB, row_ld(dim), tw + xh2, row_ld(dim), 1, R, dim, G(p + ".norm2.weight"), 1, G(p + ".norm2.bias"), L.red_cap)) return rc2;      // d(gamma) and d(beta) in one pass
         HIP_TRY(launch_layernorm_bwd(gB, tw + xh2, tw + rs2, P(*this, p + ".norm2.weight"), dX, xm, nullptr, row_ld(0), R, 1, dim, s));
         return CAPF_OK;
     };
@@ -468,8 +542,7 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
             rc = t_linear_bwd(s, L, tw, gB, row_ld(3 * dim), R, 3 * dim, dim, tw + a.y1, row_ld(dim), P(*this, p + ".attn.qkv.weight"),
                               gA, row_ld(dim), false, G(p + ".attn.qkv.weight"), G(p + ".attn.qkv.bias"));
             if (rc) return rc;
-            HIP_TRY(launch_colreduce(gA, row_ld(dim), tw + a.xh1, row_ld(dim), 1, R, dim, G(p + ".norm1.weight"), 1, 0, red, s,
-                                 G(p + ".norm1.bias"), red_elems));      // d(gamma) and d(beta) in one pass
+            if (int rc2 = t_colreduce(s, L, tw, gA, row_ld(dim), tw + a.xh1, row_ld(dim), 1, R, dim, G(p + ".norm1.weight"), 1, G(p + ".norm1.bias"), L.red_cap)) return rc2;      // d(gamma) and d(beta) in one pass
             HIP_TRY(launch_layernorm_bwd(gA, tw + a.xh1, tw + a.rs1, P(*this, p + ".norm1.weight"), dX, row_ld(dim), nullptr, row_ld(0), R, 1, dim, s));
         }
     }
@@ -514,12 +587,12 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
         rc = t_linear_bwd(s, L, tw, gA, row_ld(64), R, NA + NO, C, tw + c.y1, row_ld(C), pack_arena + pk.w_off, dq,
                           row_ld(C), false, gWcat, gbcat);
         if (rc) return rc;
+        if ((rc = t_slab_flush(s))) return rc;           // (the copies below read the temp: its slabs are summed now, with whatever else waits)
         HIP_TRY(hipMemcpyAsync(G(p + ".attention_weights.weight"), gWcat, sizeof(float) * NA * C, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(G(p + ".sampling_offsets.weight"), gWcat + (size_t)NA * C, sizeof(float) * NO * C, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(G(p + ".attention_weights.bias"), gbcat, sizeof(float) * NA, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(G(p + ".sampling_offsets.bias"), gbcat + NA, sizeof(float) * NO, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(launch_colreduce(dq, row_ld(C), tw + c.xh1, row_ld(C), 1, R, C, G(p + ".norm1.weight"), 1, 0, red, s,
-                                 G(p + ".norm1.bias"), red_elems));      // d(gamma) and d(beta) in one pass
+        if (int rc2 = t_colreduce(s, L, tw, dq, row_ld(C), tw + c.xh1, row_ld(C), 1, R, C, G(p + ".norm1.weight"), 1, G(p + ".norm1.bias"), L.red_cap)) return rc2;      // d(gamma) and d(beta) in one pass
         HIP_TRY(launch_layernorm_bwd(dq, tw + c.xh1, tw + c.rs1, P(*this, p + ".norm1.weight"), dX, tok, dX, tok0, R, Lv, C, s));
     }
 
@@ -532,12 +605,13 @@ int Engine::backward(hipStream_t s, int B, const float* dOut, float* flat, const
                                   P(*this, fe + ".weight"), nullptr, row_ld(0), false, G(fe + ".weight"), G(fe + ".bias"));
             if (rc) return rc;
         }
-        HIP_TRY(launch_colreduce(dX, row_ld(D), nullptr, row_ld(0), 0, R, C, G(V + ".coord_embed.bias"), 1, 0, red, s));
+        if (int rc2 = t_colreduce(s, L, tw, dX, row_ld(D), nullptr, row_ld(0), 0, R, C, G(V + ".coord_embed.bias"), 1, nullptr, 0)) return rc2;
         for (int j = 0; j < 2; ++j)
-            HIP_TRY(launch_colreduce(dX, row_ld(D), k2d + j, row_ld(2), 2, R, C, G(V + ".coord_embed.weight") + j, 2, 0, red, s));
+            if (int rc2 = t_colreduce(s, L, tw, dX, row_ld(D), k2d + j, row_ld(2), 2, R, C, G(V + ".coord_embed.weight") + j, 2, nullptr, 0)) return rc2;
         HIP_TRY(launch_pos_grad(dX, G(V + ".Spatial_pos_embed"), B, J, L1, C, s));
     }
-    return CAPF_OK;
+    if (int rc = t_col_flush(s)) return rc;                  // every bias / LayerNorm gradient still in partial sums
+    return t_slab_flush(s);                                  // every weight gradient still in slabs
 }
 
 }  // namespace capf

@@ -223,12 +223,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 
 // stage 2: 64 columns per block as 16 column quads x 16 chunk lanes; each lane sums every 16th chunk partial in order (four
 // 16-byte loads in flight), then a fixed 16-way LDS reduce
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int chunks, int C,
-                                                              float* __restrict__ dst, long dst_stride, int accumulate,
-                                                              const float* __restrict__ partial2, float* __restrict__ dst2) {
-    __shared__ float red[2][16][64];
+__device__ __forceinline__ void colreduce_final_body(float (&red)[2][16][64], const int bx, const float* __restrict__ partial, int chunks, int C,
+                                                     float* __restrict__ dst, long dst_stride, int accumulate,
+                                                     const float* __restrict__ partial2, float* __restrict__ dst2) {
     const int cq = threadIdx.x & 15, kl = threadIdx.x >> 4;
-    const int col = blockIdx.x * 64 + cq * 4;
+    const int col = bx * 64 + cq * 4;
     const bool vec = col + 4 <= C && (C & 3) == 0;
     auto sum_col = [&](const float* src, float (&acc)[4]) {
 #pragma unroll
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
     }
     __syncthreads();
     if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int which = threadIdx.x >> 6, c = bx * 64 + (threadIdx.x & 63);
         if (c < C && (which == 0 || dst2)) {
             float t = 0.f;
 #pragma unroll
@@ -278,20 +277,56 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
     }
 }
 
-// scratch must hold (dst2 ? 2 : 1) * chunks * C floats; chunks is chosen so that the first stage has ~2048 blocks
-hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
-                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s, float* dst2,
-                            size_t scratch_elems) {
-    const int colblocks = (C + 63) / 64, nout = dst2 ? 2 : 1;
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ partial, int chunks, int C,
+                                                              float* __restrict__ dst, long dst_stride, int accumulate,
+                                                              const float* __restrict__ partial2, float* __restrict__ dst2) {
+    __shared__ float red[2][16][64];
+    colreduce_final_body(red, blockIdx.x, partial, chunks, C, dst, dst_stride, accumulate, partial2, dst2);
+}
+
+// the second stages of many column reductions as ONE launch (the backward defers them: Engine::t_col_flush); same body, same bits
+__global__ __launch_bounds__(256) void colreduce_final_batch_kernel(ColFinalBatch b) {
+    __shared__ float red[2][16][64];
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.blk_end[j]) ++j;
+    const int bx = (int)blockIdx.x - (j ? b.blk_end[j - 1] : 0);
+    colreduce_final_body(red, bx, b.partial[j], b.chunks[j], b.C[j], b.dst[j], b.dst_stride[j], 0, b.partial2[j], b.dst2[j]);
+}
+
+hipError_t launch_colreduce_final_batch(const ColFinalBatch& b, hipStream_t s) {
+    if (b.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colreduce_final_batch_kernel, dim3((unsigned)b.blk_end[b.count - 1]), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+int colreduce_chunks(int rows, int C, int nout, size_t scratch_elems, int* rows_per_chunk) {
+    const int colblocks = (C + 63) / 64;
     int chunks = (2048 + colblocks - 1) / colblocks;
     chunks = std::min(std::min(chunks, 512), std::max(1, rows / 64));
     if (scratch_elems) chunks = std::min<long>(chunks, std::max<long>(1, (long)(scratch_elems / ((size_t)C * nout))));
     else chunks = std::min(chunks, 64);
     const int rpc = (rows + chunks - 1) / chunks;
-    chunks = (rows + rpc - 1) / rpc;
+    if (rows_per_chunk) *rows_per_chunk = rpc;
+    return (rows + rpc - 1) / rpc;
+}
+
+// scratch must hold (dst2 ? 2 : 1) * chunks * C floats; chunks is chosen so that the first stage has ~2048 blocks
+hipError_t launch_colreduce(const float* A, RowMap amap, const float* Bm, RowMap bmap, int bmode, int rows, int C,
+                            float* dst, long dst_stride, int accumulate, float* scratch, hipStream_t s, float* dst2,
+                            size_t scratch_elems, ColFinalBatch* defer) {
+    const int colblocks = (C + 63) / 64, nout = dst2 ? 2 : 1;
+    int rpc = 0;
+    const int chunks = colreduce_chunks(rows, C, nout, scratch_elems, &rpc);
     float* p2 = dst2 ? scratch + (size_t)chunks * C : nullptr;
     hipLaunchKernelGGL(colreduce_kernel, dim3(colblocks, chunks), dim3(256), 0, s, A, amap, Bm, bmap, bmode, scratch, p2, rows, C,
                        rpc);
+    if (defer && !accumulate && defer->count < COL_BATCH_MAX) {      // second stage with the other reductions' (the scratch stays the caller's until then)
+        const int j = defer->count++;
+        defer->partial[j] = scratch; defer->partial2[j] = p2; defer->dst[j] = dst; defer->dst2[j] = dst2;
+        defer->chunks[j] = chunks; defer->C[j] = C; defer->dst_stride[j] = (int)dst_stride;
+        defer->blk_end[j] = (j ? defer->blk_end[j - 1] : 0) + colblocks;
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(colreduce_final_kernel, dim3(colblocks), dim3(256), 0, s, scratch, chunks, C, dst, dst_stride,
                        accumulate, p2, dst2);
     return hipGetLastError();
@@ -309,6 +344,37 @@ __global__ void slab_sum_kernel(const float* __restrict__ slabs, int nslab, long
 hipError_t launch_slab_sum(const float* slabs, int nslab, long n, float* dst, hipStream_t s) {
     const long want = (n + 255) / 256;
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, slabs, nslab, n, dst);
+    return hipGetLastError();
+}
+
+// one launch for many (slabs -> gradient) sums: a block takes 1024 consecutive elements of one job (16 bytes per lane), eight slabs in flight
+__global__ __launch_bounds__(256) void slab_sum_batch_kernel(SlabBatch b) {
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.blk_end[j]) ++j;      // (block-uniform: scalar loads from the kernel arguments)
+    const int first = j ? b.blk_end[j - 1] : 0;
+    const long n = b.n[j];
+    const long i = ((long)((int)blockIdx.x - first) * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* __restrict__ src = b.src[j] + i;
+    const int ns = b.nslab[j];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= ns; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)(k + u) * n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; k < ns; ++k) acc += *reinterpret_cast<const f32x4*>(src + (long)k * n);
+    float* dst = b.dst[j] + i;
+    if (((size_t)dst & 15) == 0) *reinterpret_cast<f32x4*>(dst) = acc;
+    else { dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3]; }
+}
+
+hipError_t launch_slab_sum_batch(const SlabBatch& b, hipStream_t s) {
+    if (b.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slab_sum_batch_kernel, dim3((unsigned)b.blk_end[b.count - 1]), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
