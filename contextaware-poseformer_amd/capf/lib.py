@@ -8,7 +8,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 LIB_PATH = os.environ.get("CAPF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapf.so")
 HRNET, CPN50 = 0, 1
 F32, BF16 = 0, 1
-PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM, PLAN_NO_UPADD, PLAN_H2_PLANES, PLAN_NO_BNECK = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096     # capf_plan_flag
+PLAN_NO_FUSED_LIFTER, PLAN_NO_WINOGRAD, PLAN_NO_ROW_HALO, PLAN_WINOGRAD_F23_ONLY, PLAN_NO_PWCHAIN, PLAN_NO_WS, PLAN_LIFTER_FP32, PLAN_NO_F32X3, PLAN_F32X3_EXACT, PLAN_NO_F32H2_GEMM, PLAN_NO_UPADD, PLAN_H2_PLANES, PLAN_NO_BNECK, PLAN_NO_BATCHED_REDUCE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192     # capf_plan_flag
 ABI_VERSION = 6        # include/capf.h :: CAPF_ABI_VERSION (checked against capf_abi_version() at load)
 
 EXPORTS = [  # every symbol include/capf.h declares (checked by tests/test_abi.py)

@@ -591,7 +591,7 @@ int capf_create(const capf_config* cfg, int device, capf_handle** out) {
         delete h;
         return CAPF_ERR_UNSUPPORTED;
     }
-    if (cfg->plan_flags & ~8191) {
+    if (cfg->plan_flags & ~16383) {
         g_create_error = "unknown capf_plan_flag bits";
         delete h;
         return CAPF_ERR_INVALID;

@@ -312,6 +312,7 @@ struct Engine {
     size_t utab_off = 0;                 // ... and their place in the pack arena (uploaded once: they depend on the plan alone)
     bool utab_on_device = false;
     bool use_bneck = true;         // plan_flags & CAPF_PLAN_NO_BNECK clears it
+    bool batch_reduce = true;      // plan_flags & CAPF_PLAN_NO_BATCHED_REDUCE clears it: the backward's second-stage reductions one launch each
     // op i opens the fork / join region of a first bottleneck (conv1, conv2 | downsample) directly followed by its conv3, and the block runs as
     // ONE launch at this batch (bneck_bf16.hip); m = {conv1, conv2, downsample, conv3}
     bool bneck0_head(int i, int batch, int last_op, int m[4]) const;

@@ -1042,6 +1042,7 @@ bool Engine::build() {
     if (cfg.plan_flags & CAPF_PLAN_NO_PWCHAIN) use_pwchain = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_UPADD) use_upadd = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_BNECK) use_bneck = false;
+    if (cfg.plan_flags & CAPF_PLAN_NO_BATCHED_REDUCE) batch_reduce = false;
     if (cfg.plan_flags & CAPF_PLAN_H2_PLANES) use_h2_planes = true;
     if (cfg.plan_flags & CAPF_PLAN_NO_WS) use_ws = false;
     if (cfg.plan_flags & CAPF_PLAN_NO_F32X3) use_x3 = false;

@@ -212,6 +212,11 @@ float* Engine::t_slab_take(hipStream_t s, float* area, size_t cap, size_t elems,
 }
 
 int Engine::t_slab_defer(hipStream_t s, const float* slabs, int nslab, long n, float* dst) {
+    if (!batch_reduce) {                                     // CAPF_PLAN_NO_BATCHED_REDUCE: the per-layer kernel, right away; the area is free again
+        HIP_TRY(launch_slab_sum(slabs, nslab, n, dst, s));
+        if (t_slab_jobs.count == 0) t_slab_cur = 0;
+        return CAPF_OK;
+    }
     if ((n & 3) || n >= (1L << 31) - 4096) {                 // (no 16-byte form: summed at once, the area stays taken until the next flush)
         HIP_TRY(launch_slab_sum(slabs, nslab, n, dst, s));
         return CAPF_OK;
@@ -237,7 +242,8 @@ int Engine::t_colreduce(hipStream_t s, const TrainLayout& L, float* tw, const fl
     }
     float* scratch = tw + L.red + t_col_cur;
     t_col_cur += need;
-    HIP_TRY(launch_colreduce(A, amap, Bm, bmap, bmode, rows, C, dst, dst_stride, 0, scratch, s, dst2, cap_elems, &t_col_jobs));
+    HIP_TRY(launch_colreduce(A, amap, Bm, bmap, bmode, rows, C, dst, dst_stride, 0, scratch, s, dst2, cap_elems, batch_reduce ? &t_col_jobs : nullptr));
+    if (!batch_reduce) t_col_cur = 0;                        // (its second stage ran: the scratch is free again)
     return CAPF_OK;
 }
 

@@ -99,6 +99,10 @@ enum capf_plan_flag {
                                      * (capf_op_conv_f32h2_planes) where both convs run the two-fp16-piece tile; default: plain fp32 tensors          */
     CAPF_PLAN_NO_BNECK = 4096,      /* compute_dtype = CAPF_BF16: the first bottleneck of layer1 (conv1 / conv2 / downsample / conv3; networks/resnet.py:58-93,
                                      * pose_hrnet.py:98-136) as its five launches instead of ONE kernel with t1 / t2 / the shortcut on chip (bneck_bf16.hip) */
+    CAPF_PLAN_NO_BATCHED_REDUCE = 8192, /* training: every weight gradient's slab sum and every bias / LayerNorm gradient's second reduction stage as its
+                                     * own launch behind its producer (96 launches per step) instead of a handful of batched ones when the scratch
+                                     * fills and at the end of capf_backward (csrc/train.cpp t_slab_flush / t_col_flush).  Same summation order per
+                                     * element either way: bit-identical gradients (tests/test_gpu_train.py); an A/B aid                        */
     CAPF_PLAN_F32X3_EXACT = 256     /* ... on round 4's tile instead of the default one: every operand split EXACTLY into three bf16 pieces,
                                      * six piece products per fp32 MAC (igemm_f32x3_ws.hip).  The default (ABI 5) carries an operand as two
                                      * block-scaled fp16 pieces (to 2^-23) and issues three products: half the MFMAs, the same measured

@@ -308,7 +308,7 @@ def test_plan_flags_select_kernel_families_and_nothing_else_does(monkeypatch):
     assert not any(k in ("ctx_attn", "embed") for _, k in unfused) and any(k == "deform_sample" for _, k in unfused)
     assert not any(k.startswith(("igemm_wino", "igemm_f32x3", "igemm_f32h2_")) for _, k in kernels(PLAN_NO_WINOGRAD))
     with pytest.raises(CapfError):
-        kernels(1 << 13)
+        kernels(1 << 14)
     # embed_dim_ratio beyond the fused kernels' register / LDS budget: the plan falls back to one kernel per op
     wide = kernels(0, embed=288)
     assert not any(k in ("ctx_attn", "embed") for _, k in wide) and any(k == "deform_sample" for _, k in wide)

@@ -150,3 +150,37 @@ def test_training_step_on_the_two_piece_gemm_agrees_with_the_fp32_pipe(drop_path
         assert (g1[n] - g0[n]).abs().max().item() <= 2e-5 * scale, n
     print(f"two-piece GEMM vs fp32 pipe, batch {B}, drop_path {drop_path}: worst gradient difference {worst:.2e} of the gradient's largest entry")
     assert len(g0) == 191
+
+
+@pytest.mark.parametrize("B", [12, 96])
+def test_batched_second_stage_reductions_leave_the_same_bits(B):
+    """capf_backward defers every weight gradient's slab sum and every bias / LayerNorm gradient's second reduction stage into a handful of
+    batched launches (csrc/train.cpp t_slab_flush / t_col_flush, train_kernels.hip slab_sum_batch_kernel / colreduce_final_batch_kernel:
+    64 + 32 launches per step -> ~8).  Per element the batched kernels add the same partial sums in the same order as the per-layer
+    launches (CAPF_PLAN_NO_BATCHED_REDUCE): loss and all 191 gradients bit for bit, with DropPath on.  Batch 12: most weight gradients
+    are one slice (no slabs at all) and the column reductions carry the test; batch 96: split-K slabs for every matrix and the flushes in
+    front of the context blocks' temp copies (the flush-when-full path needs ~0.6 GB of slabs: it runs in test_gpu_fullsize.py's
+    batch-512 steps, which hold the gradients to the oracle / fp64)."""
+    from capf import synth
+    from capf.lib import PLAN_NO_BATCHED_REDUCE
+    from mvn.models.loss import MPJPE
+    case = CASES["w32_256x256_b2"]
+    img, k2d, kc, gt = synth.synth_inputs(B, case["H"], case["W"], seed=977, crop_range=case["crop"], with_gt=True)
+    got = []
+    for flags in (0, PLAN_NO_BATCHED_REDUCE):
+        model, _ = make_model(case["backbone"], device="cuda", wseed=case["wseed"], bn=case["bn"], plan_flags=flags)
+        model.train(); model.backbone.eval(); model.volume_net.train()
+        model.drop_path_rate = 0.3
+        torch.manual_seed(11)
+        pred = model(img.cuda(), k2d.cuda(), kc.clone().cuda())
+        loss = MPJPE()(pred, gt.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        got.append((loss.item(), {n: p.grad.detach().clone() for n, p in model.volume_net.named_parameters()}))
+        del model
+    (l1, g1), (l0, g0) = got
+    assert l1 == l0
+    assert len(g0) == 191
+    for n in g0:
+        assert torch.isfinite(g0[n]).all(), n
+        assert torch.equal(g1[n], g0[n]), n
